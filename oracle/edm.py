@@ -1,0 +1,49 @@
+"""ORACLE (test infrastructure, not product code) -- EDM schedule, preconditioning
+and denoise wrapper, restated on CPU fp32.  See oracle/unet1d.py for the rules on who
+may import this package and for the parity-pinning status."""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from audiodiffuser_amd.config import UNet1dConfig
+from .unet1d import unet1d_forward, P
+
+
+def karras_sigmas(sigma_min: float, sigma_max: float, rho: float, num_steps: int) -> torch.Tensor:
+    """src/models/components/scheduler.py:17-22 (EDM eq. 5), fp32."""
+    inv = 1.0 / rho
+    i = torch.arange(num_steps, dtype=torch.float32)
+    return (sigma_max ** inv + i / (num_steps - 1) * (sigma_min ** inv - sigma_max ** inv)) ** rho
+
+
+def edm_scale_weights(sigmas: torch.Tensor, sigma_data: float, ndim: int) -> Tuple[torch.Tensor, ...]:
+    """src/models/components/diffusion.py:232-241 -> (c_skip, c_out, c_in, c_noise)."""
+    c_noise = torch.log(sigmas) * 0.25
+    s = sigmas.view(*sigmas.shape, *((1,) * (ndim - sigmas.ndim)))   # components/utils.py:16-18
+    c_skip = (sigma_data ** 2) / (s ** 2 + sigma_data ** 2)
+    c_out = s * sigma_data * (sigma_data ** 2 + s ** 2) ** -0.5
+    c_in = (s ** 2 + sigma_data ** 2) ** -0.5
+    return c_skip, c_out, c_in, c_noise
+
+
+def denoise(net: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x_noisy: torch.Tensor,
+            sigma_data: float, sigma=None, sigmas: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src/models/components/diffusion.py:32-63 with cond_scale == 1 and dynamic_threshold == 0
+    (clip = clamp(-1, 1), components/utils.py:20-22).  Exactly one of sigma / sigmas."""
+    assert (sigma is None) ^ (sigmas is None), "Either sigma or sigmas must be provided"
+    b = x_noisy.shape[0]
+    if sigmas is None:
+        sigmas = torch.full((b,), float(sigma), dtype=torch.float32)   # components/utils.py:41-52
+    c_skip, c_out, c_in, c_noise = edm_scale_weights(sigmas, sigma_data, x_noisy.ndim)
+    pred = net(c_in * x_noisy, c_noise)
+    return (c_skip * x_noisy + c_out * pred).clamp(-1.0, 1.0)
+
+
+def make_denoiser(p: P, cfg: UNet1dConfig, sigma_data: float) -> Callable:
+    """fn(x, sigma) -> denoised, the closure the samplers call (module call site:
+    src/models/diffunet_complex_module.py:86-89)."""
+    def fn(x, sigma=None, sigmas=None):
+        return denoise(lambda xi, t: unet1d_forward(p, cfg, xi, t), x, sigma_data, sigma=sigma, sigmas=sigmas)
+    return fn

@@ -1,0 +1,306 @@
+"""ORACLE tooling (build container only): import the reference on CPU, pin the CPU
+restatement in ``oracle/`` against it, and emit the golden fixtures under
+``tests/golden/``.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [--check-only]
+
+The reference lives read-only at /root/reference and never travels to the GPU box;
+only the *data* written here (inputs + expected outputs) is committed.  Two in-memory
+stand-ins are registered for third-party modules the image lacks (``einops_exts``:
+only ``rearrange_many`` is used, attention_utils.py:5; ``torchsde``: imported at
+components/utils.py:6 but only used by a Brownian-tree sampler outside the path).
+Weights and noise come from the repo's own name-keyed generator
+(audiodiffuser_amd/weights.py), so every fixture can be regenerated without the
+reference present.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("ADF_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    import einops
+    if "einops_exts" not in sys.modules:
+        m = types.ModuleType("einops_exts")
+        m.rearrange_many = lambda ts, pat, **kw: tuple(einops.rearrange(t, pat, **kw) for t in ts)
+        sys.modules["einops_exts"] = m
+    if "torchsde" not in sys.modules:
+        sys.modules["torchsde"] = types.ModuleType("torchsde")
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from src.models.backbones.unet1d import UNet1dBase
+    from src.models.components.diffusion import EluDiffusion
+    from src.models.components.sampler_edm import EDMSampler, EDMAlphaSampler, DPMSampler
+    from src.models.components.scheduler import KarrasSchedule
+    return dict(UNet1dBase=UNet1dBase, EluDiffusion=EluDiffusion, EDMSampler=EDMSampler,
+                EDMAlphaSampler=EDMAlphaSampler, DPMSampler=DPMSampler, KarrasSchedule=KarrasSchedule)
+
+
+def build_ref_net(ref, cfg, weights):
+    net = ref["UNet1dBase"](**cfg.to_kwargs())
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(weights.keys()), "state_dict key order/name mismatch"
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(weights[k].shape), (k, v.shape, weights[k].shape)
+    net.load_state_dict(weights, strict=True)
+    return net.eval()
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def sub(t, stride=64):
+    return t.reshape(t.shape[0], -1)[:, ::stride].contiguous().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    from audiodiffuser_amd.config import config_c1, config_c2, config_c3, config_tiny
+    from audiodiffuser_amd.weights import generate_weights, generate_noise, param_specs, count_parameters
+    from oracle import unet1d as O, edm as E, samplers as S
+
+    os.makedirs(GOLD, exist_ok=True)
+    report = {}
+    out = {}
+
+    # ---- 1. sigma schedules -------------------------------------------------
+    for n in (18, 35, 50):
+        r = ref["KarrasSchedule"](sigma_min=0.002, sigma_max=80.0, rho=7.0, num_steps=n)()
+        o = E.karras_sigmas(0.002, 80.0, 7.0, n)
+        assert torch.equal(r, o), f"schedule N={n}"
+        out[f"karras_{n}"] = r.numpy()
+    report["schedule"] = "bit-exact"
+
+    # ---- 2. preconditioning -------------------------------------------------
+    diff = ref["EluDiffusion"](sigma_data=0.2)
+    grid = torch.tensor([80.0, 57.586, 10.0, 1.0, 0.5, 0.2, 0.05, 0.0075280, 0.002], dtype=torch.float32)
+    rw = diff.get_scale_weights(grid, 3)
+    ow = E.edm_scale_weights(grid, 0.2, 3)
+    for a, b in zip(rw, ow):
+        assert torch.equal(a, b)
+    out["scale_sigmas"] = grid.numpy()
+    for name, a in zip(("c_skip", "c_out", "c_in", "c_noise"), rw):
+        out[f"scale_{name}"] = a.reshape(-1).numpy()
+    report["scale_weights"] = "bit-exact"
+
+    # ---- 3. state-dict layout ------------------------------------------------
+    layout = {}
+    for tag, cfg in (("c1", config_c1()), ("c2", config_c2()), ("c3", config_c3()), ("tiny", config_tiny())):
+        net = ref["UNet1dBase"](**cfg.to_kwargs())
+        sd = net.state_dict()
+        specs = param_specs(cfg)
+        assert list(sd.keys()) == list(specs.keys()), tag
+        for k, v in sd.items():
+            assert tuple(v.shape) == specs[k][0], (tag, k)
+        nparam = sum(p.numel() for p in net.parameters())
+        assert nparam == count_parameters(cfg)
+        layout[tag] = {"num_params": nparam, "num_tensors": len(sd)}
+        if tag in ("c1", "tiny"):
+            layout[tag]["keys"] = {k: list(v.shape) for k, v in sd.items()}
+        del net
+    assert layout["c1"]["num_params"] == 1510040 and layout["c2"]["num_params"] == 23937632
+    report["state_dict"] = {k: v["num_params"] for k, v in layout.items()}
+
+    # ---- 4. whole-net + block taps (reference forward hooks vs oracle taps) ---
+    def hooked_forward(net, x, t):
+        taps, hs = {}, []
+        u = net.unet
+
+        def add(mod, name):
+            hs.append(mod.register_forward_hook(lambda m, i, o, name=name: taps.__setitem__(name, o.detach())))
+        add(u.to_in, "to_in"); add(u.to_time, "temb")
+        for i, d in enumerate(u.downsamples):
+            add(d.downsample, f"down{i}.conv")
+            for j, b in enumerate(d.blocks):
+                add(b, f"down{i}.block{j}")
+            if d.use_attention:
+                add(d.transformer, f"down{i}.attn")
+        add(u.bottleneck.pre_block, "mid.pre")
+        if u.bottleneck.use_attention:
+            add(u.bottleneck.transformer, "mid.attn")
+        add(u.bottleneck.post_block, "mid.post")
+        for k, up in enumerate(u.upsamples):
+            for j, b in enumerate(up.blocks):
+                add(b, f"up{k}.block{j}")
+            if up.use_attention:
+                add(up.transformer, f"up{k}.attn")
+            add(up.upsample, f"up{k}.conv")
+        with torch.no_grad():
+            y = net(x, t, cond_drop_prob=0.0)
+        for h in hs:
+            h.remove()
+        return y, taps
+
+    net_cases = (("tiny", config_tiny(), 2, 256), ("c1", config_c1(), 2, 2048))
+    nets = {}
+    for tag, cfg, B, L in net_cases:
+        w = generate_weights(cfg, seed=0)
+        net = build_ref_net(ref, cfg, w)
+        nets[tag] = (cfg, w, net)
+        x = generate_noise(0, B, L) * 0.7
+        t = torch.tensor([-0.9, 0.35][:B], dtype=torch.float32)
+        y_ref, taps_ref = hooked_forward(net, x, t)
+        taps_o = {}
+        with torch.no_grad():
+            y_o = O.unet1d_forward(w, cfg, x, t, taps=taps_o)
+        errs = {k: rel_err(taps_o[k], taps_ref[k]) for k in taps_ref}
+        errs["out"] = rel_err(y_o, y_ref)
+        worst = max(errs.values())
+        assert set(taps_o) == set(taps_ref)
+        assert worst < 2e-5, (tag, errs)
+        report[f"net_{tag}"] = {"max_rel_err_over_taps": worst, "out_rel_err": errs["out"]}
+        out[f"net_{tag}_x"] = x.numpy(); out[f"net_{tag}_t"] = t.numpy()
+        out[f"net_{tag}_y"] = y_ref.numpy()
+        for k, v in taps_ref.items():
+            out[f"net_{tag}_tap_{k}"] = sub(v, 7 if tag == "tiny" else 61)
+
+    # C1 at the full 16384 length, sub-sampled
+    cfg, w, net = nets["c1"]
+    x = generate_noise(100, 1, 16384) * 0.5
+    t = torch.tensor([0.1], dtype=torch.float32)
+    with torch.no_grad():
+        y_ref = net(x, t, cond_drop_prob=0.0)
+        y_o = O.unet1d_forward(w, cfg, x, t)
+    assert rel_err(y_o, y_ref) < 2e-5
+    report["net_c1_L16384"] = rel_err(y_o, y_ref)
+    out["net_c1_16k_t"] = t.numpy()
+    out["net_c1_16k_y_sub"] = sub(y_ref, 64)
+    out["net_c1_16k_y_l2"] = np.array([float(y_ref.norm())], dtype=np.float32)
+    out["net_c1_16k_y_absmax"] = np.array([float(y_ref.abs().max())], dtype=np.float32)
+
+    # ---- 5. denoise_fn at three sigmas (exercises the clamp) ------------------
+    for tag in ("tiny", "c1"):
+        cfg, w, net = nets[tag]
+        B, L = (2, 256) if tag == "tiny" else (2, 2048)
+        xn = generate_noise(7, B, L)
+        fn_o = E.make_denoiser(w, cfg, 0.2)
+        for si, sg in enumerate((20.0, 1.5, 0.05)):
+            xs = xn * sg
+            with torch.no_grad():
+                r = diff.denoise_fn(xs, net=net, sigma=torch.tensor(sg), inference=True, cond_scale=1.0)
+                o = fn_o(xs, sigma=torch.tensor(sg))
+            assert rel_err(o, r) < 2e-5, (tag, sg, rel_err(o, r))
+            out[f"denoise_{tag}_{si}"] = r.numpy()
+        # per-sample sigmas variant
+        sv = torch.tensor([3.0, 0.3], dtype=torch.float32)
+        with torch.no_grad():
+            r = diff.denoise_fn(xn * sv[:, None, None], net=net, sigmas=sv, inference=True, cond_scale=1.0)
+            o = fn_o(xn * sv[:, None, None], sigmas=sv)
+        assert rel_err(o, r) < 2e-5
+        out[f"denoise_{tag}_vec"] = r.numpy()
+    report["denoise"] = "ok (<2e-5)"
+
+    # ---- 6. sampler trajectories ---------------------------------------------
+    def ref_traj(sampler, noise, fn, net, sigmas):
+        tr = []
+        orig = sampler.step if hasattr(sampler, "step") else None
+        if orig is not None:
+            def step(*a, **k):
+                r = orig(*a, **k); tr.append(r.clone()); return r
+            sampler.step = step
+        with torch.no_grad():
+            y = sampler(noise, fn=fn, net=net, sigmas=sigmas)
+        if orig is not None:
+            sampler.step = orig
+        return y, tr
+
+    mock = lambda x, net=None, sigma=None, **kw: 0.5 * x
+    mock_o = lambda x, sigma=None: 0.5 * x
+    sampler_report = {}
+    for tag in ("tiny", "c1"):
+        cfg, w, net = nets[tag]
+        B, L = (2, 256) if tag == "tiny" else (2, 2048)
+        noise = generate_noise(40, B, L)
+        fn_o = E.make_denoiser(w, cfg, 0.2)
+        for fn_tag, fn_r, fn_oo, nn_ in (("net", diff.denoise_fn, fn_o, net), ("mock", mock, mock_o, None)):
+            if fn_tag == "mock" and tag == "c1":
+                continue
+            # EDM Heun, no churn, N=18
+            sg = E.karras_sigmas(0.002, 80.0, 7.0, 18)
+            smp = ref["EDMSampler"](s_churn=0.0, s_noise=1.0, num_steps=18, use_heun=True)
+            y, tr = ref_traj(smp, noise, fn_r, nn_, sg)
+            tro = []
+            with torch.no_grad():
+                yo = S.edm_sampler(noise, fn_oo, sg, 18, s_churn=0.0, s_noise=1.0, trace=tro)
+            e = max([rel_err(yo, y)] + [rel_err(a, b) for a, b in zip(tro, tr)])
+            sampler_report[f"heun18_{tag}_{fn_tag}"] = e
+            out[f"smp_heun18_{tag}_{fn_tag}_final"] = y.numpy()
+            out[f"smp_heun18_{tag}_{fn_tag}_traj"] = np.stack([sub(a, 16) for a in tr])
+            # EDM alpha (alpha = 1), N=18
+            smp = ref["EDMAlphaSampler"](alpha=1.0, num_steps=18, use_heun=True)
+            y, tr = ref_traj(smp, noise, fn_r, nn_, sg)
+            tro = []
+            with torch.no_grad():
+                yo = S.edm_alpha_sampler(noise, fn_oo, sg, 18, alpha=1.0, trace=tro)
+            e = max([rel_err(yo, y)] + [rel_err(a, b) for a, b in zip(tro, tr)])
+            sampler_report[f"alpha18_{tag}_{fn_tag}"] = e
+            out[f"smp_alpha18_{tag}_{fn_tag}_final"] = y.numpy()
+            # DPM-Solver multistep order 3, 50 sigmas (49 NFE)
+            sg50 = E.karras_sigmas(0.002, 80.0, 7.0, 50)
+            smp = ref["DPMSampler"](cond_scale=1.0, order=3, num_steps=50, multisteps=True,
+                                    x0_pred=True, log_time_spacing=False)
+            nfe = [0]
+            def counted(*a, _f=fn_r, **k):
+                nfe[0] += 1
+                return _f(*a, **k)
+            with torch.no_grad():
+                y = smp(noise, fn=counted, net=nn_, sigmas=sg50)
+                yo = S.dpm_multistep_sampler(noise, fn_oo, sg50, 50, order=3)
+            assert nfe[0] == 49, nfe
+            sampler_report[f"dpm50_{tag}_{fn_tag}"] = rel_err(yo, y)
+            out[f"smp_dpm50_{tag}_{fn_tag}_final"] = y.numpy()
+        # churn sampler (config-4 style settings) with recorded randn draws, N=12
+        sg = E.karras_sigmas(0.002, 80.0, 7.0, 12)
+        draws = []
+        real_randn_like = torch.randn_like
+        def rec_randn_like(x, *a, **k):
+            g = torch.Generator(); g.manual_seed(9000 + len(draws))
+            z = torch.randn(x.shape, generator=g, dtype=x.dtype); draws.append(z); return z
+        torch.randn_like = rec_randn_like
+        try:
+            smp = ref["EDMSampler"](s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, num_steps=12, use_heun=True)
+            with torch.no_grad():
+                y = smp(noise, fn=diff.denoise_fn, net=net, sigmas=sg)
+        finally:
+            torch.randn_like = real_randn_like
+        inj = torch.stack(draws)
+        with torch.no_grad():
+            yo = S.edm_sampler(noise, fn_o, sg, 12, s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, injected_noise=inj)
+        sampler_report[f"churn12_{tag}_net"] = rel_err(yo, y)
+        out[f"smp_churn12_{tag}_net_final"] = y.numpy()
+        out[f"smp_churn12_{tag}_noise_seed0"] = np.array([9000], dtype=np.int64)
+    worst = max(sampler_report.values())
+    assert worst < 5e-4, sampler_report
+    report["samplers"] = sampler_report
+
+    print(json.dumps(report, indent=1))
+    if args.check_only:
+        return
+    np.savez_compressed(os.path.join(GOLD, "hotpath_golden.npz"), **out)
+    with open(os.path.join(GOLD, "state_dict_layout.json"), "w") as f:
+        json.dump(layout, f, indent=0)
+    with open(os.path.join(GOLD, "oracle_vs_reference_report.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()
