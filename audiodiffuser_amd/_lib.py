@@ -1,0 +1,123 @@
+"""ctypes binding of ``libadf_hip.so`` (C ABI declared in include/audiodiffuser_amd.h).
+
+There is no fallback: if the library is missing or cannot be loaded the import of any
+product entry point raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .config import UNet1dConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libadf_hip.so")
+ADF_MAX_LAYERS = 12
+DTYPE_F32, DTYPE_BF16 = 0, 1
+FLAG_SEPARATE_GN_STATS = 1
+SAMPLER_EDM, SAMPLER_EDM_ALPHA, SAMPLER_DPM_MULTISTEP = 0, 1, 2
+
+
+class AdfNetConfig(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int32), ("num_filters", C.c_int32), ("window_length", C.c_int32), ("stride", C.c_int32),
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32),
+        ("resnet_groups", C.c_int32), ("kernel_multiplier_downsample", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("multipliers", C.c_int32 * (ADF_MAX_LAYERS + 1)),
+        ("factors", C.c_int32 * ADF_MAX_LAYERS),
+        ("num_blocks", C.c_int32 * ADF_MAX_LAYERS),
+        ("attentions", C.c_int32 * ADF_MAX_LAYERS),
+        ("attention_heads", C.c_int32), ("attention_multiplier", C.c_int32),
+        ("use_skip_scale", C.c_int32), ("use_attention_bottleneck", C.c_int32),
+        ("dtype", C.c_int32), ("flags", C.c_int32),
+    ]
+
+
+class AdfSamplerDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("num_steps", C.c_int32),
+        ("s_tmin", C.c_float), ("s_tmax", C.c_float), ("s_churn", C.c_float), ("s_noise", C.c_float),
+        ("use_heun", C.c_int32), ("alpha", C.c_float), ("order", C.c_int32), ("sigma_data", C.c_float),
+        ("use_graph", C.c_int32),
+    ]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "adf_create": (C.c_int, [C.POINTER(AdfNetConfig), C.POINTER(C.c_void_p)]),
+    "adf_destroy": (None, [C.c_void_p]),
+    "adf_last_error": (C.c_char_p, [C.c_void_p]),
+    "adf_num_weights": (C.c_int, [C.c_void_p]),
+    "adf_weight_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "adf_weight_numel": (C.c_int64, [C.c_void_p, C.c_int]),
+    "adf_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "adf_weights_missing": (C.c_int, [C.c_void_p]),
+    "adf_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "adf_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "adf_sampler_run": (C.c_int, [C.c_void_p, C.POINTER(AdfSamplerDesc), C.POINTER(C.c_float), C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "adf_sampler_nfe": (C.c_int, [C.POINTER(AdfSamplerDesc), C.POINTER(C.c_float), C.c_int]),
+    "adf_debug_tap_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "adf_debug_tap_copy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "adf_debug_tap_count": (C.c_int, [C.c_void_p]),
+    "adf_debug_tap_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "adf_device_bytes": (C.c_int64, [C.c_void_p]),
+    "adf_bench_resblock": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """Load libadf_hip.so and bind every symbol of the public header; raise if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m audiodiffuser_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU/PyTorch fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def make_config(cfg: UNet1dConfig, dtype: int, flags: int = 0) -> AdfNetConfig:
+    cfg.validate()
+    n = cfg.num_layers
+    if n > ADF_MAX_LAYERS:
+        raise ValueError("too many layers")
+    c = AdfNetConfig()
+    c.channels, c.num_filters, c.window_length, c.stride = cfg.channels, cfg.num_filters, cfg.window_length, cfg.stride
+    c.in_channels, c.out_channels = cfg.in_channels, cfg.out_channels
+    c.resnet_groups, c.kernel_multiplier_downsample = cfg.resnet_groups, cfg.kernel_multiplier_downsample
+    c.num_layers = n
+    for i, m in enumerate(cfg.multipliers):
+        c.multipliers[i] = int(m)
+    for i in range(n):
+        c.factors[i] = int(cfg.factors[i])
+        c.num_blocks[i] = int(cfg.num_blocks[i])
+        c.attentions[i] = 1 if cfg.attentions[i] else 0
+    c.attention_heads, c.attention_multiplier = cfg.attention_heads, cfg.attention_multiplier
+    c.use_skip_scale = 1 if cfg.use_skip_scale else 0
+    c.use_attention_bottleneck = 1 if cfg.use_attention_bottleneck else 0
+    c.dtype, c.flags = dtype, flags
+    return c
+
+
+class AdfError(RuntimeError):
+    pass
+
+
+def check(lib: C.CDLL, handle, rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.adf_last_error(handle)
+        raise AdfError(f"{what}: {msg.decode() if msg else 'unknown error'}")

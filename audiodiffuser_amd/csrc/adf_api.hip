@@ -1,0 +1,856 @@
+// C-ABI implementation (include/audiodiffuser_amd.h): weight registry keyed by the reference state_dict
+// names, per-(B, L) workspace, the U-Net walk that launches the fused kernels, and the sampler drivers
+// (EDM Heun/churn, EDM-alpha, DPM-Solver multistep) with whole-loop hipGraph capture.
+//
+// Host logic mirrors (does not copy) the reference control flow:
+//   UNet1d.forward            src/models/backbones/unet1d.py:771-816
+//   Down/UpsampleBlock1d      src/models/backbones/unet1d.py:441-468, :542-566
+//   Diffusion.denoise_fn      src/models/components/diffusion.py:32-63
+//   EDMSampler / Alpha / DPM  src/models/components/sampler_edm.py:333-397, :251-300, :624-768
+#include "../../include/audiodiffuser_amd.h"
+#include "adf_gemm.h"
+#include "adf_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace adf;
+
+namespace {
+
+std::string g_create_error;
+
+struct ConvW {
+    void* w = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cin = 0, K = 0, n = 0, n_pad = 0, nchunk = 0, taps = 0, f = 0;
+};
+struct ResW {
+    int cin = 0, cout = 0, film_off = 0;
+    float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr;
+    ConvW c1, c2, cr;
+    bool has_res = false;
+};
+struct TrW {
+    int c = 0, mid = 0;
+    float *lnw = nullptr, *lnb = nullptr, *g0 = nullptr, *g3 = nullptr;
+    ConvW qkv, proj, ff1, ff2;
+};
+struct DownW { ConvW down; std::vector<ResW> blocks; bool attn = false; TrW tr; int factor = 1, cin = 0, cout = 0; };
+struct UpW { std::vector<ResW> blocks; bool attn = false; TrW tr; ConvW up; int factor = 1, cin = 0, cout = 0; };
+
+struct Slot {
+    int kind = 0;  // 0 = fp32 copy, 1 = pack conv/linear, 2 = pack transposed conv
+    void* dst = nullptr;
+    int64_t numel = 0;
+    bool loaded = false;
+    int cout = 0, cin = 0, K = 0, f = 0, n_offset = 0, n_pad = 0, nchunk = 0;
+};
+
+struct Act { void* p = nullptr; int C = 0, L = 0; double* stats = nullptr; };
+struct TapRec { std::string name; void* p; int C, L; };
+struct RbRec { std::string name; GemmArgs g1, g2; int cin, cout, L; };
+
+struct Plan {
+    int B = 0, L = 0;
+    char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
+    char* stats = nullptr; size_t stats_bytes = 0, stats_off = 0;
+    bool dry = false;
+    std::vector<TapRec> taps;
+    std::vector<RbRec> rbs;
+    float *temb = nullptr, *film = nullptr, *coef = nullptr;
+    // sampler state (fp32 [B][C][L] each)
+    float* sb[10] = {nullptr};
+    float* noise_stage = nullptr; float* out_stage = nullptr; float* inj_stage = nullptr; size_t inj_cap = 0;
+    std::map<std::string, hipGraphExec_t> graphs;
+};
+
+}  // namespace
+
+struct adf_handle {
+    adf_net_config cfg;
+    bool bf16 = false;
+    int esz = 4, kc = 32;
+    std::string err;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    std::vector<std::string> names;
+    std::map<std::string, Slot> slots;
+    float *to_in_w = nullptr, *to_out_w = nullptr, *fourier = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr,
+          *t_b2 = nullptr, *film_w = nullptr, *film_b = nullptr;
+    int film_total = 0;
+    std::vector<DownW> downs;
+    ResW mid_pre, mid_post;
+    TrW mid_tr;
+    std::vector<UpW> ups;
+    std::map<std::pair<int, int>, Plan*> plans;
+    Plan* last_plan = nullptr;
+};
+
+namespace {
+
+int fail(adf_handle* h, const std::string& m) { h->err = m; return 1; }
+
+void* dalloc(adf_handle* h, size_t bytes) {
+    void* p = nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    hipMemset(p, 0, bytes);
+    h->allocs.push_back(p);
+    h->bytes += (int64_t)bytes;
+    return p;
+}
+
+// ---- weight registry ---------------------------------------------------------------------------
+struct Registrar {
+    adf_handle* h;
+    bool ok = true;
+    float* reg_f32(const std::string& name, int64_t numel, float* dst = nullptr) {
+        if (!dst) dst = (float*)dalloc(h, (size_t)numel * 4);
+        if (!dst) { ok = false; return nullptr; }
+        Slot s; s.kind = 0; s.dst = dst; s.numel = numel;
+        h->names.push_back(name); h->slots[name] = s;
+        return dst;
+    }
+    // Conv1d / Linear weight (cout, cin, K) packed as GEMM operand; several tensors may share one packed
+    // buffer at different row offsets (fused qkv).
+    void reg_pack(const std::string& name, ConvW& w, int cout, int cin, int K, int n_offset, int n_total, bool transposed, int f) {
+        if (!w.w) {
+            w.cin = cin; w.K = K; w.f = f;
+            w.taps = transposed ? 2 : K;
+            w.n = n_total; w.n_pad = round_up(n_total, 32);
+            w.nchunk = ceil_div(cin, h->kc);
+            w.w = dalloc(h, (size_t)w.nchunk * w.taps * w.n_pad * kRowBytes);
+            if (!w.w) { ok = false; return; }
+        }
+        w.cout = cout;
+        Slot s; s.kind = transposed ? 2 : 1; s.dst = w.w; s.numel = (int64_t)cout * cin * K;
+        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = n_offset; s.n_pad = w.n_pad; s.nchunk = w.nchunk;
+        h->names.push_back(name); h->slots[name] = s;
+    }
+    void conv(const std::string& pre, ConvW& w, int cout, int cin, int K, bool bias) {
+        reg_pack(pre + ".weight", w, cout, cin, K, 0, cout, false, 0);
+        if (bias) w.bias = reg_f32(pre + ".bias", cout);
+    }
+    void resblock(const std::string& pre, ResW& r, int cin, int cout, int temb) {
+        r.cin = cin; r.cout = cout;
+        r.film_off = h->film_total;
+        h->film_total += 2 * cout;
+        // FiLM weights are registered later (one concatenated matrix), remember the order via names
+        film_names.push_back({pre, r.film_off, 2 * cout});
+        r.g1w = reg_f32(pre + ".block1.groupnorm.weight", cin);
+        r.g1b = reg_f32(pre + ".block1.groupnorm.bias", cin);
+        conv(pre + ".block1.project", r.c1, cout, cin, 3, true);
+        r.g2w = reg_f32(pre + ".block2.groupnorm.weight", cout);
+        r.g2b = reg_f32(pre + ".block2.groupnorm.bias", cout);
+        conv(pre + ".block2.project", r.c2, cout, cout, 3, true);
+        r.has_res = cin != cout;
+        if (r.has_res) conv(pre + ".to_out", r.cr, cout, cin, 1, true);
+        (void)temb;
+    }
+    void transformer(const std::string& pre, TrW& t, int c, int mult) {
+        t.c = c; t.mid = c * mult;
+        t.lnw = reg_f32(pre + ".norm.weight", c);
+        t.lnb = reg_f32(pre + ".norm.bias", c);
+        reg_pack(pre + ".attention.to_q.weight", t.qkv, c, c, 1, 0, 3 * c, false, 0);
+        reg_pack(pre + ".attention.to_kv.weight", t.qkv, 2 * c, c, 1, c, 3 * c, false, 0);
+        t.qkv.cout = 3 * c;
+        conv(pre + ".attention.to_out", t.proj, c, c, 1, false);
+        t.g0 = reg_f32(pre + ".feed_forward.0.g", c);
+        conv(pre + ".feed_forward.1", t.ff1, t.mid, c, 1, false);
+        t.g3 = reg_f32(pre + ".feed_forward.3.g", t.mid);
+        conv(pre + ".feed_forward.4", t.ff2, c, t.mid, 1, false);
+    }
+    struct FilmName { std::string pre; int off, rows; };
+    std::vector<FilmName> film_names;
+};
+
+int build_weights(adf_handle* h) {
+    const adf_net_config& c = h->cfg;
+    Registrar R{h};
+    const int ch = c.channels, temb = 4 * ch, n = c.num_layers;
+    h->to_in_w = R.reg_f32("unet.to_in.to_in.weight", (int64_t)c.num_filters * c.in_channels * c.window_length);
+    h->to_out_w = R.reg_f32("unet.to_out.to_out.weight", (int64_t)c.num_filters * c.out_channels * c.window_length);
+    h->fourier = R.reg_f32("unet.to_time.0.0.weights", ch / 2);
+    h->t_w1 = R.reg_f32("unet.to_time.0.1.weight", (int64_t)temb * (ch + 1));
+    h->t_b1 = R.reg_f32("unet.to_time.0.1.bias", temb);
+    h->t_w2 = R.reg_f32("unet.to_time.2.weight", (int64_t)temb * temb);
+    h->t_b2 = R.reg_f32("unet.to_time.2.bias", temb);
+    h->downs.resize(n);
+    for (int i = 0; i < n; ++i) {
+        DownW& d = h->downs[i];
+        d.cin = ch * c.multipliers[i]; d.cout = ch * c.multipliers[i + 1]; d.factor = c.factors[i];
+        const std::string pre = "unet.downsamples." + std::to_string(i);
+        R.conv(pre + ".downsample", d.down, d.cout, d.cin, d.factor * c.kernel_multiplier_downsample + 1, true);
+        d.blocks.resize(c.num_blocks[i]);
+        for (int j = 0; j < c.num_blocks[i]; ++j) R.resblock(pre + ".blocks." + std::to_string(j), d.blocks[j], d.cout, d.cout, temb);
+        d.attn = c.attentions[i] != 0;
+        if (d.attn) R.transformer(pre + ".transformer", d.tr, d.cout, c.attention_multiplier);
+    }
+    const int cb = ch * c.multipliers[n];
+    R.resblock("unet.bottleneck.pre_block", h->mid_pre, cb, cb, temb);
+    if (c.use_attention_bottleneck) R.transformer("unet.bottleneck.transformer", h->mid_tr, cb, c.attention_multiplier);
+    R.resblock("unet.bottleneck.post_block", h->mid_post, cb, cb, temb);
+    h->ups.resize(n);
+    for (int u = 0; u < n; ++u) {
+        const int i = n - 1 - u;
+        UpW& up = h->ups[u];
+        up.cin = ch * c.multipliers[i + 1]; up.cout = ch * c.multipliers[i]; up.factor = c.factors[i];
+        const std::string pre = "unet.upsamples." + std::to_string(u);
+        const int nb = c.num_blocks[i] + (c.attentions[i] ? 1 : 0);
+        up.blocks.resize(nb);
+        for (int j = 0; j < nb; ++j) R.resblock(pre + ".blocks." + std::to_string(j), up.blocks[j], 2 * up.cin, up.cin, temb);
+        up.attn = c.attentions[i] != 0;
+        if (up.attn) R.transformer(pre + ".transformer", up.tr, up.cin, c.attention_multiplier);
+        const int f = up.factor;
+        R.reg_pack(pre + ".upsample.weight", up.up, up.cout, up.cin, 2 * f, 0, f * up.cout, true, f);
+        up.up.bias = R.reg_f32(pre + ".upsample.bias", up.cout);
+    }
+    // one concatenated FiLM projection for all resblocks
+    h->film_w = (float*)dalloc(h, (size_t)h->film_total * temb * 4);
+    h->film_b = (float*)dalloc(h, (size_t)h->film_total * 4);
+    if (!h->film_w || !h->film_b) R.ok = false;
+    for (const auto& fn : R.film_names) {
+        R.reg_f32(fn.pre + ".to_cond_embedding.1.weight", (int64_t)fn.rows * temb, h->film_w + (size_t)fn.off * temb);
+        R.reg_f32(fn.pre + ".to_cond_embedding.1.bias", fn.rows, h->film_b + fn.off);
+    }
+    return R.ok ? 0 : fail(h, "device allocation failed while building the weight registry");
+}
+
+// ---- per-(B, L) plan -----------------------------------------------------------------------------
+struct Walker {
+    adf_handle* h;
+    Plan* p;
+    hipStream_t s;
+    bool bad = false;
+
+    void check(const char* e) { if (e && !bad) { bad = true; h->err = e; } }
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        const size_t off = p->arena_off;
+        p->arena_off += bytes;
+        if (p->dry) return nullptr;
+        if (p->arena_off > p->arena_bytes) { check("arena overflow"); return nullptr; }
+        return p->arena + off;
+    }
+    double* alloc_stats() {
+        const size_t bytes = ((size_t)p->B * h->cfg.resnet_groups * 2 * sizeof(double) + 255) & ~(size_t)255;
+        const size_t off = p->stats_off;
+        p->stats_off += bytes;
+        if (p->dry) return (double*)(uintptr_t)(off + 256);  // non-null marker
+        if (p->stats_off > p->stats_bytes) { check("stats arena overflow"); return nullptr; }
+        return (double*)(p->stats + off);
+    }
+    Act new_act(int C, int L) { Act a; a.C = C; a.L = L; a.p = alloc((size_t)p->B * L * C * h->esz); return a; }
+    void tap(const std::string& name, const Act& a) { p->taps.push_back({name, a.p, a.C, a.L}); }
+    bool live() const { return !p->dry && !bad; }
+
+    bool can_fuse_stats(int C) const {
+        if (h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS) return false;
+        const int G = h->cfg.resnet_groups;
+        if (C % G) return false;
+        const int gs = C / G;
+        return (gs & (gs - 1)) == 0;
+    }
+    double* ensure_stats(Act& t) {
+        if (!t.stats) {
+            t.stats = alloc_stats();
+            if (live()) check(launch_gn_stats(t.p, h->bf16, p->B, t.L, t.C, h->cfg.resnet_groups, t.stats, s));
+        }
+        return t.stats;
+    }
+
+    GemmArgs gemm_base(const Act& out, int lin, int mrows, const ConvW& w) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.nseg = 1; g.B = p->B; g.lin = lin; g.mrows = mrows; g.n = w.n; g.n_pad = w.n_pad;
+        g.bias0 = w.bias; g.bias_mod = w.n > 0 ? w.n : 1;
+        g.out = out.p; g.out_rows = out.L; g.out_c = out.C;
+        return g;
+    }
+    static GemmSeg seg_of(const Act& x, const Act* skip, const float* ab, float scale1, int act, int taps, int stride, int off0,
+                          int step, const ConvW& w) {
+        GemmSeg sg;
+        memset(&sg, 0, sizeof(sg));
+        sg.src0 = x.p; sg.c0 = x.C;
+        sg.src1 = skip ? skip->p : nullptr; sg.c1 = skip ? skip->C : 0;
+        sg.ab = ab; sg.scale1 = scale1; sg.act = act;
+        sg.taps = taps; sg.stride = stride; sg.off0 = off0; sg.step = step;
+        sg.w = w.w; sg.nchunk = w.nchunk;
+        return sg;
+    }
+    void run_gemm(GemmArgs& g, Act& out, bool want_stats) {
+        if (want_stats && can_fuse_stats(out.C) && !g.scatter_f) {
+            out.stats = alloc_stats();
+            g.stats = out.stats; g.stats_groups = h->cfg.resnet_groups;
+        }
+        if (live()) check(launch_conv_gemm(g, h->bf16, s));
+    }
+
+    Act linear(const Act& x, const ConvW& w, const void* res, int gelu, bool want_stats) {
+        Act out = new_act(w.n, x.L);
+        GemmArgs g = gemm_base(out, x.L, x.L, w);
+        g.seg[0] = seg_of(x, nullptr, nullptr, 1.f, 0, 1, 1, 0, 1, w);
+        g.res = res; g.gelu = gelu;
+        run_gemm(g, out, want_stats);
+        return out;
+    }
+
+    Act resblock(const std::string& name, Act& x, Act* skip, const ResW& r, int nb) {
+        const int B = p->B, G = h->cfg.resnet_groups;
+        const float sscale = h->cfg.use_skip_scale ? 0.70710678118654752440f : 1.0f;
+        const int ctot = x.C + (skip ? skip->C : 0);
+        if (ctot != r.cin) check("resblock: channel mismatch");
+        double* s0 = ensure_stats(x);
+        double* s1 = skip ? ensure_stats(*skip) : nullptr;
+        float* ab1 = (float*)alloc((size_t)B * ctot * 2 * 4);
+        if (live()) {
+            GnFinalizeArgs f;
+            memset(&f, 0, sizeof(f));
+            f.stats0 = s0; f.stats1 = s1; f.c0 = x.C; f.c1 = skip ? skip->C : 0; f.L = x.L; f.G = G; f.B = B;
+            f.scale1 = sscale; f.eps = 1e-5f; f.gamma = r.g1w; f.beta = r.g1b; f.film = nullptr; f.ab = ab1;
+            check(launch_gn_finalize(f, s));
+        }
+        Act h1 = new_act(r.cout, x.L);
+        GemmArgs g1 = gemm_base(h1, x.L, x.L, r.c1);
+        g1.seg[0] = seg_of(x, skip, ab1, sscale, 1, 3, 1, -1, 1, r.c1);
+        run_gemm(g1, h1, true);
+        double* sh = ensure_stats(h1);
+        float* ab2 = (float*)alloc((size_t)B * r.cout * 2 * 4);
+        if (live()) {
+            GnFinalizeArgs f;
+            memset(&f, 0, sizeof(f));
+            f.stats0 = sh; f.c0 = r.cout; f.L = x.L; f.G = G; f.B = B; f.scale1 = 1.f; f.eps = 1e-5f;
+            f.gamma = r.g2w; f.beta = r.g2b;
+            f.film = p->film + r.film_off; f.film_bstride = nb == 1 ? 0 : h->film_total; f.ab = ab2;
+            check(launch_gn_finalize(f, s));
+        }
+        Act y = new_act(r.cout, x.L);
+        GemmArgs g2 = gemm_base(y, x.L, x.L, r.c2);
+        g2.seg[0] = seg_of(h1, nullptr, ab2, 1.f, 1, 3, 1, -1, 1, r.c2);
+        if (r.has_res) {
+            g2.nseg = 2;
+            g2.seg[1] = seg_of(x, skip, nullptr, sscale, 0, 1, 1, 0, 1, r.cr);
+            g2.bias1 = r.cr.bias;
+        } else {
+            if (skip) check("resblock: identity residual with a skip input");
+            g2.res = x.p;
+        }
+        run_gemm(g2, y, true);
+        p->rbs.push_back({name, g1, g2, r.cin, r.cout, x.L});
+        tap(name, y);
+        return y;
+    }
+
+    Act transformer(const std::string& name, Act& x, const TrW& t) {
+        const long long rows = (long long)p->B * x.L;
+        Act xn = new_act(t.c, x.L);
+        if (live()) check(launch_ln_rows(x.p, xn.p, h->bf16, rows, t.c, t.lnw, t.lnb, 1e-5f, s));
+        Act qkv = linear(xn, t.qkv, nullptr, 0, false);
+        Act att = new_act(t.c, x.L);
+        if (live()) check(launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
+        Act x1 = linear(att, t.proj, x.p, 0, false);
+        Act n1 = new_act(t.c, x.L);
+        if (live()) check(launch_ln_rows(x1.p, n1.p, h->bf16, rows, t.c, t.g0, nullptr, 1e-5f, s));
+        Act f1 = linear(n1, t.ff1, nullptr, 1, false);
+        Act n2 = new_act(t.mid, x.L);
+        if (live()) check(launch_ln_rows(f1.p, n2.p, h->bf16, rows, t.mid, t.g3, nullptr, 1e-5f, s));
+        Act x2 = linear(n2, t.ff2, x1.p, 0, true);
+        tap(name, x2);
+        return x2;
+    }
+};
+
+struct FwdIO {
+    const float* x; float* out;
+    const float* t; int t_stride; int nb;
+    const float* coef; int coef_bstride; int mode; const float* x_noisy;
+};
+
+int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
+    const adf_net_config& c = h->cfg;
+    Walker W{h, p, s};
+    p->arena_off = 0; p->stats_off = 0;
+    p->taps.clear(); p->rbs.clear();
+    const int B = p->B, L = p->L, n = c.num_layers;
+    const int pad = c.window_length / 2 - c.stride / 2;
+    const int tdim = 4 * c.channels;
+    if (!p->dry && p->stats_bytes) {
+        if (hipMemsetAsync(p->stats, 0, p->stats_bytes, s) != hipSuccess) return fail(h, "hipMemsetAsync(stats) failed");
+    }
+    // sigma embedding + every resblock's FiLM projection
+    if (W.live()) {
+        TimeEmbedArgs te;
+        te.t = io.t; te.t_stride = io.t_stride; te.nb = io.nb; te.ch = c.channels;
+        te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb;
+        W.check(launch_time_embed(te, s));
+        W.check(launch_film(p->temb, h->film_w, h->film_b, p->film, io.nb, tdim, h->film_total, s));
+    }
+    Act x = W.new_act(c.num_filters, L / c.stride);
+    if (W.live())
+        W.check(launch_to_in(io.x, h->to_in_w, x.p, h->bf16, B, c.in_channels, L, c.num_filters, c.window_length, c.stride, pad,
+                             io.coef, io.coef_bstride, s));
+    W.tap("to_in", x);
+    std::vector<std::vector<Act>> skips_list;
+    for (int i = 0; i < n; ++i) {
+        const DownW& d = h->downs[i];
+        const int f = d.factor, km = c.kernel_multiplier_downsample;
+        Act y = W.new_act(d.cout, x.L / f);
+        GemmArgs g = W.gemm_base(y, x.L, y.L, d.down);
+        g.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, f * km + 1, f, -f * (km / 2), 1, d.down);
+        W.run_gemm(g, y, true);
+        W.tap("down" + std::to_string(i) + ".conv", y);
+        x = y;
+        std::vector<Act> skips;
+        for (size_t j = 0; j < d.blocks.size(); ++j) {
+            x = W.resblock("down" + std::to_string(i) + ".block" + std::to_string(j), x, nullptr, d.blocks[j], io.nb);
+            skips.push_back(x);
+        }
+        if (d.attn) {
+            x = W.transformer("down" + std::to_string(i) + ".attn", x, d.tr);
+            skips.push_back(x);
+        }
+        skips_list.push_back(skips);
+    }
+    x = W.resblock("mid.pre", x, nullptr, h->mid_pre, io.nb);
+    if (c.use_attention_bottleneck) x = W.transformer("mid.attn", x, h->mid_tr);
+    x = W.resblock("mid.post", x, nullptr, h->mid_post, io.nb);
+    for (int u = 0; u < n; ++u) {
+        const UpW& up = h->ups[u];
+        std::vector<Act>& skips = skips_list.back();
+        for (size_t j = 0; j < up.blocks.size(); ++j) {
+            if (skips.empty()) { W.check("upsample: skip stack underflow"); break; }
+            Act sk = skips.back();
+            skips.pop_back();
+            x = W.resblock("up" + std::to_string(u) + ".block" + std::to_string(j), x, &sk, up.blocks[j], io.nb);
+        }
+        skips_list.pop_back();
+        if (up.attn) x = W.transformer("up" + std::to_string(u) + ".attn", x, up.tr);
+        const int f = up.factor;
+        Act y = W.new_act(up.cout, x.L * f);
+        GemmArgs g = W.gemm_base(y, x.L, x.L + 1, up.up);
+        g.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, 2, 1, 0, -1, up.up);
+        g.bias_mod = up.cout;
+        g.scatter_f = f; g.scatter_pad = f / 2 + f % 2;
+        W.run_gemm(g, y, u + 1 < n);
+        W.tap("up" + std::to_string(u) + ".conv", y);
+        x = y;
+    }
+    if (W.live())
+        W.check(launch_to_out(x.p, h->to_out_w, io.out, h->bf16, B, c.out_channels, x.L, c.num_filters, c.window_length, c.stride, pad,
+                              io.mode, io.x_noisy, io.coef, io.coef_bstride, s));
+    return W.bad ? 1 : 0;
+}
+
+int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
+    const adf_net_config& c = h->cfg;
+    int total = c.stride;
+    for (int i = 0; i < c.num_layers; ++i) total *= c.factors[i];
+    if (B < 1 || L < 1 || L % total) return fail(h, "length must be a positive multiple of the total down-sampling factor");
+    if (adf_weights_missing(h)) return fail(h, "weights are not fully loaded");
+    auto it = h->plans.find({B, L});
+    if (it != h->plans.end()) { *out = it->second; h->last_plan = it->second; return 0; }
+    Plan* p = new Plan();
+    p->B = B; p->L = L;
+    p->dry = true;
+    FwdIO io;
+    memset(&io, 0, sizeof(io));
+    io.nb = B;
+    if (forward(h, p, io, s)) { delete p; return 1; }
+    p->arena_bytes = p->arena_off; p->stats_bytes = p->stats_off;
+    p->arena = (char*)dalloc(h, p->arena_bytes);
+    p->stats = (char*)dalloc(h, p->stats_bytes ? p->stats_bytes : 256);
+    const size_t wave = (size_t)B * c.out_channels * L;
+    p->temb = (float*)dalloc(h, (size_t)B * 4 * c.channels * 4);
+    p->film = (float*)dalloc(h, (size_t)B * h->film_total * 4);
+    p->coef = (float*)dalloc(h, (size_t)B * 4 * 4);
+    bool ok = p->arena && p->stats && p->temb && p->film && p->coef;
+    for (int i = 0; i < 10; ++i) { p->sb[i] = (float*)dalloc(h, wave * 4); ok = ok && p->sb[i]; }
+    p->noise_stage = (float*)dalloc(h, wave * 4);
+    p->out_stage = (float*)dalloc(h, wave * 4);
+    ok = ok && p->noise_stage && p->out_stage;
+    if (!ok) { delete p; return fail(h, "device allocation failed for the workspace"); }
+    p->dry = false;
+    // eager warm-up (loads code objects, sets kernel attributes) so a later graph capture is clean
+    io.x = p->noise_stage; io.out = p->out_stage; io.t = p->coef; io.t_stride = 1; io.nb = B; io.mode = 0;
+    if (forward(h, p, io, s)) { delete p; return 1; }
+    if (hipStreamSynchronize(s) != hipSuccess) { delete p; return fail(h, std::string("warm-up forward failed: ") + hipGetErrorString(hipGetLastError())); }
+    h->plans[{B, L}] = p;
+    h->last_plan = p;
+    *out = p;
+    return 0;
+}
+
+int denoise_scalar(adf_handle* h, Plan* p, const float* x, float sigma, float sigma_data, float* out, hipStream_t s) {
+    if (const char* e = launch_edm_coef(nullptr, sigma, 1, sigma_data, p->coef, s)) return fail(h, e);
+    FwdIO io;
+    io.x = x; io.out = out; io.t = p->coef + 1; io.t_stride = 4; io.nb = 1;
+    io.coef = p->coef; io.coef_bstride = 0; io.mode = 1; io.x_noisy = x;
+    return forward(h, p, io, s);
+}
+
+// ---- sampler drivers -----------------------------------------------------------------------------------
+struct SamplerCtx {
+    adf_handle* h; Plan* p; const adf_sampler_desc* d; const float* sig; int nsig; hipStream_t s; long long n;
+    int nfe = 0;
+    bool count_only = false;
+    int den(const float* x, float sigma, float* out) {
+        ++nfe;
+        if (count_only) return 0;
+        return denoise_scalar(h, p, x, sigma, d->sigma_data, out, s);
+    }
+    int ck(const char* e) { if (e) { h->err = e; return 1; } return 0; }
+};
+
+// returns the buffer holding the final sample through *result
+int run_edm(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int N = d.num_steps;
+    if (c.nsig < N) return c.count_only ? 1 : fail(c.h, "EDMSampler: need at least num_steps sigmas");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* XH = c.count_only ? nullptr : p->sb[2];
+    float* XE = c.count_only ? nullptr : p->sb[3];
+    float* D = c.count_only ? nullptr : p->sb[4];
+    float* DEN = c.count_only ? nullptr : p->sb[5];
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    const float gmax = fminf(d.s_churn / (float)N, (float)(std::sqrt(2.0) - 1.0));
+    for (int i = 0; i < N; ++i) {
+        const float sg = c.sig[i];
+        const float sn = (i + 1 < c.nsig) ? c.sig[i + 1] : 0.0f;
+        const float gamma = (sg >= d.s_tmin && sg <= d.s_tmax) ? gmax : 0.0f;
+        float s_hat = sg;
+        const float* xh = X;
+        if (gamma > 0.f) {
+            s_hat = sg + gamma * sg;
+            const float cc = sqrtf(s_hat * s_hat - sg * sg);
+            if (!c.count_only) {
+                if (!p->inj_stage) return fail(c.h, "EDMSampler with churn needs injected_noise");
+                if (c.ck(launch_churn(XH, X, p->inj_stage + (size_t)i * c.n, cc, d.s_noise, c.n, c.s))) return 1;
+            }
+            xh = XH;
+        }
+        if (c.den(xh, s_hat, DEN)) return 1;
+        const float dt = sn - s_hat;
+        if (!c.count_only && c.ck(launch_euler(XE, D, xh, DEN, s_hat, dt, c.n, c.s))) return 1;
+        if (sn != 0.f && d.use_heun) {
+            if (c.den(XE, sn, DEN)) return 1;
+            if (!c.count_only && c.ck(launch_rk2(XN, xh, D, XE, DEN, sn, 0.5f * dt, 1.0f, 1.0f, c.n, c.s))) return 1;
+            std::swap(X, XN);
+        } else {
+            std::swap(X, XE);
+        }
+    }
+    *result = X;
+    return 0;
+}
+
+int run_edm_alpha(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int N = d.num_steps;
+    if (c.nsig < N) return c.count_only ? 1 : fail(c.h, "EDMAlphaSampler: need at least num_steps sigmas");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* XE = c.count_only ? nullptr : p->sb[3];
+    float* D = c.count_only ? nullptr : p->sb[4];
+    float* DEN = c.count_only ? nullptr : p->sb[5];
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    const float alpha = d.alpha;
+    for (int i = 0; i + 1 < N; ++i) {
+        const float sg = c.sig[i], sn = c.sig[i + 1];
+        const float hh = sn - sg;
+        if (c.den(X, sg, DEN)) return 1;
+        const float sp = sg + alpha * hh;
+        if (sp != 0.f && d.use_heun) {
+            if (!c.count_only && c.ck(launch_euler(XE, D, X, DEN, sg, alpha * hh, c.n, c.s))) return 1;
+            if (c.den(XE, sp, DEN)) return 1;
+            const float w1 = (float)(1.0 - 0.5 / (double)alpha), w2 = (float)(0.5 / (double)alpha);
+            if (!c.count_only && c.ck(launch_rk2(XN, X, D, XE, DEN, sp, hh, w1, w2, c.n, c.s))) return 1;
+            std::swap(X, XN);
+        } else {
+            if (!c.count_only && c.ck(launch_euler(XE, D, X, DEN, sg, hh, c.n, c.s))) return 1;
+            std::swap(X, XE);
+        }
+    }
+    *result = X;
+    return 0;
+}
+
+int run_dpm(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int steps = d.num_steps - 1;  // log_time_spacing=False: sampler_edm.py:526
+    const int order = d.order;
+    if (order < 1 || order > 3) return c.count_only ? 1 : fail(c.h, "DPMSampler: order must be 1, 2 or 3");
+    if (steps < order || c.nsig < steps + 1) return c.count_only ? 1 : fail(c.h, "DPMSampler: not enough steps / sigmas");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* M[3] = {c.count_only ? nullptr : p->sb[6], c.count_only ? nullptr : p->sb[7], c.count_only ? nullptr : p->sb[8]};
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    auto lam = [](float s_) { return -logf(s_); };
+    // history: index 0 = most recent
+    float sh[3] = {c.sig[0], 0.f, 0.f};
+    int nh = 1;
+    if (c.den(X, c.sig[0], M[0])) return 1;
+    for (int step = 1; step <= steps; ++step) {
+        const int ord = step < order ? step : std::min(order, steps + 1 - step);
+        const float sc = c.sig[step];
+        const float hcur = lam(sc) - lam(sh[0]);
+        DpmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.order = ord;
+        a.ratio = sc / sh[0];
+        a.phi1 = expm1f(-hcur);
+        a.m0 = M[0]; a.m1 = M[1]; a.m2 = M[2];
+        if (ord == 2) {
+            const float h1 = lam(sh[0]) - lam(sh[1]);
+            const float r0 = h1 / hcur;
+            a.inv_r0 = 1.0f / r0;
+        } else if (ord == 3) {
+            const float h1 = lam(sh[1]) - lam(sh[2]);
+            const float h0 = lam(sh[0]) - lam(sh[1]);
+            const float r0 = h0 / hcur, r1 = h1 / hcur;
+            a.inv_r0 = 1.0f / r0; a.inv_r1 = 1.0f / r1;
+            a.r0_frac = r0 / (r0 + r1);
+            a.inv_r01 = 1.0f / (r0 + r1);
+            a.phi2 = a.phi1 / hcur + 1.0f;
+            a.phi3 = a.phi2 / hcur - 0.5f;
+        }
+        (void)nh;
+        const int last = step == steps;
+        if (!c.count_only && c.ck(launch_dpm_update(XN, X, a, last, c.n, c.s))) return 1;
+        std::swap(X, XN);
+        sh[2] = sh[1]; sh[1] = sh[0]; sh[0] = sc;
+        nh = std::min(nh + 1, 3);
+        if (!last) {
+            float* oldest = M[2];
+            M[2] = M[1]; M[1] = M[0]; M[0] = oldest;
+            if (c.den(X, sc, M[0])) return 1;
+        }
+    }
+    *result = X;
+    return 0;
+}
+
+int run_sampler(SamplerCtx& c, float** result) {
+    switch (c.d->kind) {
+        case ADF_SAMPLER_EDM: return run_edm(c, result);
+        case ADF_SAMPLER_EDM_ALPHA: return run_edm_alpha(c, result);
+        case ADF_SAMPLER_DPM_MULTISTEP: return run_dpm(c, result);
+        default: return c.count_only ? 1 : fail(c.h, "unknown sampler kind");
+    }
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int adf_create(const adf_net_config* cfg, adf_handle** out) {
+    if (!cfg || !out) { g_create_error = "adf_create: null argument"; return 1; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "adf_create: no HIP device available"; return 1; }
+    const adf_net_config& c = *cfg;
+    if (c.num_layers < 1 || c.num_layers > ADF_MAX_LAYERS) { g_create_error = "adf_create: bad num_layers"; return 1; }
+    if (c.num_filters != c.channels * c.multipliers[0]) { g_create_error = "adf_create: num_filters must equal channels*multipliers[0]"; return 1; }
+    if (c.channels % 2 || c.channels < 2) { g_create_error = "adf_create: channels must be even"; return 1; }
+    if (c.dtype != ADF_DTYPE_F32 && c.dtype != ADF_DTYPE_BF16) { g_create_error = "adf_create: bad dtype"; return 1; }
+    adf_handle* h = new adf_handle();
+    h->cfg = c;
+    h->bf16 = c.dtype == ADF_DTYPE_BF16;
+    h->esz = h->bf16 ? 2 : 4;
+    h->kc = kRowBytes / h->esz;
+    if (build_weights(h)) { g_create_error = h->err; adf_destroy(h); return 1; }
+    *out = h;
+    return 0;
+}
+
+void adf_destroy(adf_handle* h) {
+    if (!h) return;
+    for (auto& kv : h->plans) {
+        for (auto& g : kv.second->graphs) hipGraphExecDestroy(g.second);
+        delete kv.second;
+    }
+    for (void* p : h->allocs) hipFree(p);
+    delete h;
+}
+
+const char* adf_last_error(const adf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int adf_num_weights(const adf_handle* h) { return (int)h->names.size(); }
+const char* adf_weight_name(const adf_handle* h, int i) { return (i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : nullptr; }
+int64_t adf_weight_numel(const adf_handle* h, int i) {
+    if (i < 0 || i >= (int)h->names.size()) return -1;
+    return h->slots.at(h->names[i]).numel;
+}
+
+int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t numel, void* stream) {
+    auto it = h->slots.find(name ? name : "");
+    if (it == h->slots.end()) return fail(h, std::string("unexpected state_dict key: ") + (name ? name : "(null)"));
+    Slot& sl = it->second;
+    if (numel != sl.numel) return fail(h, std::string("size mismatch for ") + name + ": expected " + std::to_string(sl.numel) + " got " + std::to_string(numel));
+    hipStream_t s = (hipStream_t)stream;
+    if (sl.kind == 0) {
+        if (hipMemcpyAsync(sl.dst, dev, (size_t)numel * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "hipMemcpyAsync failed");
+    } else {
+        const char* e = launch_pack_weight(dev, sl.dst, h->bf16, sl.kind == 2 ? 1 : 0, sl.cout, sl.cin, sl.K, sl.f, sl.n_offset, sl.n_pad, sl.nchunk, s);
+        if (e) return fail(h, e);
+    }
+    sl.loaded = true;
+    return 0;
+}
+
+int adf_weights_missing(const adf_handle* h) {
+    int m = 0;
+    for (const auto& kv : h->slots) m += kv.second.loaded ? 0 : 1;
+    return m;
+}
+
+int adf_net_forward(adf_handle* h, const float* x, const float* t, float* out, int B, int L, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Plan* p;
+    if (get_plan(h, B, L, s, &p)) return 1;
+    FwdIO io;
+    io.x = x; io.out = out; io.t = t; io.t_stride = 1; io.nb = B; io.coef = nullptr; io.coef_bstride = 0; io.mode = 0; io.x_noisy = nullptr;
+    return forward(h, p, io, s);
+}
+
+int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, float sigma, float sigma_data, float* out, int B,
+                int L, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Plan* p;
+    if (get_plan(h, B, L, s, &p)) return 1;
+    if (!sigmas_dev) return denoise_scalar(h, p, x_noisy, sigma, sigma_data, out, s);
+    if (const char* e = launch_edm_coef(sigmas_dev, 0.f, B, sigma_data, p->coef, s)) return fail(h, e);
+    FwdIO io;
+    io.x = x_noisy; io.out = out; io.t = p->coef + 1; io.t_stride = 4; io.nb = B;
+    io.coef = p->coef; io.coef_bstride = 4; io.mode = 1; io.x_noisy = x_noisy;
+    return forward(h, p, io, s);
+}
+
+int adf_sampler_nfe(const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas) {
+    SamplerCtx c{nullptr, nullptr, desc, sigmas_host, n_sigmas, nullptr, 0};
+    c.count_only = true;
+    float* r = nullptr;
+    if (run_sampler(c, &r)) return -1;
+    return c.nfe;
+}
+
+int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas, const float* noise,
+                    const float* injected_noise, float* out, int B, int L, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!desc || !sigmas_host || n_sigmas < 1) return fail(h, "adf_sampler_run: bad arguments");
+    Plan* p;
+    if (get_plan(h, B, L, s, &p)) return 1;
+    const long long n = (long long)B * h->cfg.out_channels * L;
+    if (h->cfg.in_channels != h->cfg.out_channels) return fail(h, "sampler needs in_channels == out_channels");
+    if (hipMemcpyAsync(p->noise_stage, noise, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "noise copy failed");
+    if (injected_noise) {
+        const size_t need = (size_t)desc->num_steps * n;
+        if (p->inj_cap < need) {
+            p->inj_stage = (float*)dalloc(h, need * 4);
+            if (!p->inj_stage) return fail(h, "device allocation failed for injected noise");
+            p->inj_cap = need;
+            for (auto& g : p->graphs) hipGraphExecDestroy(g.second);
+            p->graphs.clear();
+        }
+        if (hipMemcpyAsync(p->inj_stage, injected_noise, need * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "injected-noise copy failed");
+    } else if (desc->kind == ADF_SAMPLER_EDM && desc->s_churn > 0.f) {
+        return fail(h, "EDMSampler with s_churn > 0 needs injected_noise (pre-drawn randn_like tensors)");
+    }
+    SamplerCtx c{h, p, desc, sigmas_host, n_sigmas, s, n};
+    float* result = nullptr;
+    if (!desc->use_graph) {
+        if (run_sampler(c, &result)) return 1;
+        if (hipMemcpyAsync(out, result, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
+        return 0;
+    }
+    std::string key((const char*)desc, sizeof(*desc));
+    key.append((const char*)sigmas_host, (size_t)n_sigmas * 4);
+    key.push_back(injected_noise ? 'i' : 'n');
+    auto it = p->graphs.find(key);
+    if (it == p->graphs.end()) {
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) return fail(h, "hipStreamBeginCapture failed");
+        int rc = run_sampler(c, &result);
+        if (!rc && hipMemcpyAsync(p->out_stage, result, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; h->err = "result copy failed (capture)"; }
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(s, &graph);
+        if (rc) { if (graph) hipGraphDestroy(graph); return 1; }
+        if (ee != hipSuccess || !graph) return fail(h, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(ee));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ie != hipSuccess) return fail(h, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ie));
+        it = p->graphs.emplace(key, exec).first;
+    }
+    if (hipGraphLaunch(it->second, s) != hipSuccess) return fail(h, "hipGraphLaunch failed");
+    if (hipMemcpyAsync(out, p->out_stage, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
+    return 0;
+}
+
+int adf_debug_tap_count(adf_handle* h) { return h->last_plan ? (int)h->last_plan->taps.size() : 0; }
+const char* adf_debug_tap_name(adf_handle* h, int i) {
+    if (!h->last_plan || i < 0 || i >= (int)h->last_plan->taps.size()) return nullptr;
+    return h->last_plan->taps[i].name.c_str();
+}
+int adf_debug_tap_shape(adf_handle* h, const char* name, int* C, int* L) {
+    if (!h->last_plan) return fail(h, "no forward has run yet");
+    for (const auto& t : h->last_plan->taps)
+        if (t.name == name) { *C = t.C; *L = t.L; return 0; }
+    return fail(h, std::string("unknown tap ") + name);
+}
+int adf_debug_tap_copy(adf_handle* h, const char* name, float* out, void* stream) {
+    if (!h->last_plan) return fail(h, "no forward has run yet");
+    for (const auto& t : h->last_plan->taps)
+        if (t.name == name) {
+            const char* e = launch_nlc_to_ncl_f32(t.p, out, h->bf16, h->last_plan->B, t.L, t.C, (hipStream_t)stream);
+            return e ? fail(h, e) : 0;
+        }
+    return fail(h, std::string("unknown tap ") + name);
+}
+
+int64_t adf_device_bytes(const adf_handle* h) { return h->bytes; }
+
+int adf_bench_resblock(adf_handle* h, int B, int L, int level, int iters, float* ms1, float* ms2, double* bytes1, double* bytes2,
+                       double* flops1, double* flops2, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Plan* p;
+    if (get_plan(h, B, L, s, &p)) return 1;
+    if (p->rbs.empty()) return fail(h, "no resblock recorded; run a forward first");
+    if (level < 0 || level >= (int)p->rbs.size()) return fail(h, "resblock index out of range");
+    const RbRec& r = p->rbs[level];
+    GemmArgs g1 = r.g1, g2 = r.g2;
+    g1.stats = nullptr; g2.stats = nullptr;  // timing replay must not disturb the statistics buffers
+    hipEvent_t e0, e1, e2;
+    hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+    for (int i = 0; i < 2; ++i) { launch_conv_gemm(g1, h->bf16, s); launch_conv_gemm(g2, h->bf16, s); }
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) if (const char* e = launch_conv_gemm(g1, h->bf16, s)) return fail(h, e);
+    hipEventRecord(e1, s);
+    for (int i = 0; i < iters; ++i) if (const char* e = launch_conv_gemm(g2, h->bf16, s)) return fail(h, e);
+    hipEventRecord(e2, s);
+    if (hipEventSynchronize(e2) != hipSuccess) return fail(h, "bench_resblock: event sync failed");
+    float a = 0, b = 0;
+    hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&b, e1, e2);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    *ms1 = a / iters; *ms2 = b / iters;
+    const double es = h->esz, BL = (double)B * r.L, ci = r.cin, co = r.cout;
+    // x read for conv1; x read again for the residual; h1 written and re-read; y written; weights once
+    *bytes1 = BL * es * (ci + co) + es * 3.0 * ci * co;
+    *bytes2 = BL * es * (co + ci + co) + es * (3.0 * co * co + (ci != co ? ci * co : 0.0));
+    *flops1 = 2.0 * BL * 3.0 * ci * co;
+    *flops2 = 2.0 * BL * (3.0 * co * co + (ci != co ? ci * co : 0.0));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+// Fused implicit-GEMM kernel for every conv1d / conv_transpose1d / linear on the U-Net path
+// (reference call sites: src/models/backbones/unet1d.py:193-207 ConvBlock1d, :297-316 ResnetBlock1d,
+//  :214-225 Downsample1d, :248-255 Upsample1d, :49-61 FeedForward1d, attention_utils.py:117,157,184).
+//
+// Layout: activations are channels-last  [B][L][C]  ("NLC", the reference's tensors are [B][C][L]);
+// only the network's C=1 waveform input/output cross the boundary, so the internal layout is free.
+// GEMM view:  out[m, n] = sum_seg sum_tap sum_ci  f(A[m*stride + off0 + tap*step, ci]) * W[seg][tap][n][ci]
+//   M = positions of one sample, N = output channels (x phases for transposed conv), K = taps x Cin.
+//   f() = fused prologue: per-(sample, channel) affine (GroupNorm apply + FiLM folded) then SiLU,
+//   applied while the activation tile is staged into LDS; conv zero padding is applied after f().
+//   A second K segment (raw skip-concat input, 1x1) implements ResnetBlock1d.to_out inside the
+//   same accumulators.  The channel concat of the up path is never materialised: a segment reads
+//   two source tensors.  Epilogue: bias, identity residual, GELU, transposed-conv phase scatter,
+//   optional GroupNorm statistics of the produced tensor (fp64 atomics into [B][G][2]).
+//
+// MFMA: 32x32x16 bf16 (throughput mode) or 32x32x2 f32 (parity mode, exact fp32 FMA chain); a wave
+// owns an (MT*32) x (NT*32) accumulator tile; K is walked in 128-byte rows (64 bf16 / 32 fp32).
+// LDS rows are 128 B, 16-byte chunks XOR-swizzled by (row>>1)&7, which makes the ds_read_b128
+// fragment reads (lane = row) conflict-free on gfx950's 64-bank LDS.
+#pragma once
+#include "adf_common.h"
+
+namespace adf {
+
+constexpr int kARows = 136;     // activation rows staged per tile (incl. halo)
+constexpr int kTapGroup = 3;    // taps of weights staged per iteration
+
+struct GemmSeg {
+    const void* src0;
+    const void* src1;   // optional second source, concatenated along channels
+    int c0, c1;
+    const float* ab;    // [B][c0+c1][2] fused affine, or nullptr = raw input
+    float scale1;       // raw input: multiplier of source 1 (skip scale)
+    int act;            // 1 = SiLU after the affine
+    int taps, stride, off0, step;
+    const void* w;      // packed [nchunk][taps][n_pad][row of 128 B]
+    int nchunk;
+};
+
+struct GemmArgs {
+    GemmSeg seg[2];
+    int nseg;
+    int B, lin, mrows, n, n_pad;
+    const float* bias0;
+    const float* bias1;
+    int bias_mod;        // bias index = n % bias_mod
+    const void* res;     // identity residual, same layout as out (plain mode only)
+    int gelu;
+    void* out;
+    int out_rows, out_c;
+    int scatter_f, scatter_pad;  // transposed conv: n = phase*out_c + co -> row m*f + phase - pad
+    double* stats;       // optional [B][stats_groups][2] (sum, sumsq) of the produced tensor
+    int stats_groups;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ int lds_swz(int row, int c16) { return row * kRowBytes + ((c16 ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int MT, int NT, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs a) {
+    constexpr int TM = 32 * MT * WM, TN = 32 * NT * WN, NTHR = 64 * WM * WN;
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int KC = kRowBytes / (int)sizeof(T);
+    constexpr int A_CH = (kARows * 8 + NTHR - 1) / NTHR;
+    constexpr int W_CH = (kTapGroup * TN * 8 + NTHR - 1) / NTHR;
+    constexpr bool kBf16 = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsA = smem;
+    char* ldsW = smem + kARows * kRowBytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (a.n_pad + TN - 1) / TN;
+    const int tiles_m = (a.mrows + TM - 1) / TM;
+    int bid = blockIdx.x;
+    const int tn_i = bid % tiles_n; bid /= tiles_n;
+    const int tm_i = bid % tiles_m;
+    const int b = bid / tiles_m;
+    const int m0 = tm_i * TM, n0 = tn_i * TN;
+    const int c16 = tid & 7;  // this thread's 16-byte column within a 128-byte row (NTHR % 8 == 0)
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int ntg0 = (a.seg[0].taps + kTapGroup - 1) / kTapGroup;
+    const int nit0 = a.seg[0].nchunk * ntg0;
+    const int ntg1 = a.nseg > 1 ? (a.seg[1].taps + kTapGroup - 1) / kTapGroup : 1;
+    const int nit = nit0 + (a.nseg > 1 ? a.seg[1].nchunk * ntg1 : 0);
+
+    uint4 ra[A_CH];
+    uint4 rw[W_CH];
+    float fa[EPC], fb[EPC];
+    unsigned avalid = 0;
+
+    // ---- staging: global -> registers ---------------------------------------------------
+    auto load_regs = [&](int it) {
+        const bool s1 = it >= nit0;
+        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+        const int local = s1 ? it - nit0 : it;
+        const int ntg = s1 ? ntg1 : ntg0;
+        const int chunk = local / ntg, tg = local - chunk * ntg;
+        const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+        if (tg == 0) {
+            const int ctot = sg.c0 + sg.c1;
+            const int cidx = chunk * KC + c16 * EPC;
+            const bool cvalid = cidx < ctot;
+            const bool from1 = cidx >= sg.c0;
+            const char* src = (const char*)(from1 ? sg.src1 : sg.src0);
+            const int csrc = from1 ? sg.c1 : sg.c0;
+            const int cc = from1 ? cidx - sg.c0 : cidx;
+            const int nrows = (TM - 1) * sg.stride + sg.taps;
+            const int p_lo = m0 * sg.stride + off_min;
+            avalid = 0;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int row = (tid + i * NTHR) >> 3;
+                const int p = p_lo + row;
+                const bool ok = cvalid && row < nrows && p >= 0 && p < a.lin;
+                ra[i] = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    ra[i] = *(const uint4*)(src + ((size_t)((size_t)b * a.lin + p) * csrc + cc) * sizeof(T));
+                    avalid |= 1u << i;
+                }
+            }
+            if (sg.ab != nullptr && cvalid) {
+                const float* abp = sg.ab + ((size_t)b * ctot + cidx) * 2;
+#pragma unroll
+                for (int e = 0; e < EPC; e += 2) {
+                    const float4 q = *(const float4*)(abp + e * 2);
+                    fa[e] = q.x; fb[e] = q.y; fa[e + 1] = q.z; fb[e + 1] = q.w;
+                }
+            } else {
+                const float s = from1 ? sg.scale1 : 1.0f;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { fa[e] = s; fb[e] = 0.f; }
+            }
+        }
+        const int tleft = sg.taps - tg * kTapGroup;  // taps in this group (may exceed kTapGroup)
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int row = (tid + i * NTHR) >> 3;
+            const int tap_l = row / TN, n_l = row - tap_l * TN;
+            const bool ok = tap_l < kTapGroup && tap_l < tleft && (n0 + n_l) < a.n_pad;
+            rw[i] = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const size_t wrow = ((size_t)chunk * sg.taps + (tg * kTapGroup + tap_l)) * a.n_pad + (n0 + n_l);
+                rw[i] = *(const uint4*)((const char*)sg.w + wrow * kRowBytes + c16 * 16);
+            }
+        }
+    };
+
+    // ---- staging: registers -> (fused prologue) -> LDS -------------------------------------
+    auto store_lds = [&](int it) {
+        const bool s1 = it >= nit0;
+        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+        const int local = s1 ? it - nit0 : it;
+        const int ntg = s1 ? ntg1 : ntg0;
+        const int tg = local % ntg;
+        if (tg == 0) {
+            const int nrows = (TM - 1) * sg.stride + sg.taps;
+            const bool act = sg.act != 0;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int row = (tid + i * NTHR) >> 3;
+                if (row < nrows) {
+                    uint4 q = make_uint4(0, 0, 0, 0);
+                    if ((avalid >> i) & 1u) {
+                        float f[EPC];
+                        unpack16<T>(ra[i], f);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            float v = fmaf(f[e], fa[e], fb[e]);
+                            f[e] = act ? silu_f(v) : v;
+                        }
+                        q = pack16<T>(f);
+                    }
+                    *(uint4*)(ldsA + lds_swz(row, c16)) = q;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int row = (tid + i * NTHR) >> 3;
+            if (row < kTapGroup * TN) *(uint4*)(ldsW + lds_swz(row, c16)) = rw[i];
+        }
+    };
+
+    // ---- MFMA over one staged (chunk, tap group) ---------------------------------------------
+    auto compute = [&](int it) {
+        const bool s1 = it >= nit0;
+        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+        const int local = s1 ? it - nit0 : it;
+        const int ntg = s1 ? ntg1 : ntg0;
+        const int tg = local % ntg;
+        const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+        int ntap = sg.taps - tg * kTapGroup;
+        ntap = ntap > kTapGroup ? kTapGroup : ntap;
+        for (int tap_l = 0; tap_l < ntap; ++tap_l) {
+            const int aoff = sg.off0 + (tg * kTapGroup + tap_l) * sg.step - off_min;
+            int arow[MT], wrow[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) arow[i] = ((wm * MT + i) * 32 + r) * sg.stride + aoff;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wrow[j] = tap_l * TN + (wn * NT + j) * 32 + r;
+            if constexpr (kBf16) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8_t fa_[MT], fb_[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa_[i] = *(const bf16x8_t*)(ldsA + lds_swz(arow[i], ks * 2 + h));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb_[j] = *(const bf16x8_t*)(ldsW + lds_swz(wrow[j], ks * 2 + h));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float4 fa_[MT][2], fb_[NT][2];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        fa_[i][0] = *(const float4*)(ldsA + lds_swz(arow[i], ks * 4 + 2 * h));
+                        fa_[i][1] = *(const float4*)(ldsA + lds_swz(arow[i], ks * 4 + 2 * h + 1));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        fb_[j][0] = *(const float4*)(ldsW + lds_swz(wrow[j], ks * 4 + 2 * h));
+                        fb_[j][1] = *(const float4*)(ldsW + lds_swz(wrow[j], ks * 4 + 2 * h + 1));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].x, fb_[j][0].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].y, fb_[j][0].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].z, fb_[j][0].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].w, fb_[j][0].w, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].x, fb_[j][1].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].y, fb_[j][1].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].z, fb_[j][1].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].w, fb_[j][1].w, acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    };
+
+    // ---- main loop: loads of iteration it+1 are in flight while iteration it computes --------
+    load_regs(0);
+    for (int it = 0; it < nit; ++it) {
+        if (it > 0) __syncthreads();
+        store_lds(it);
+        __syncthreads();
+        if (it + 1 < nit) load_regs(it + 1);
+        compute(it);
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    T* out = (T*)a.out;
+    const T* res = (const T*)a.res;
+    const bool do_stats = a.stats != nullptr;
+    const int gs = do_stats ? a.out_c / a.stats_groups : 1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + (wn * NT + j) * 32 + r;
+        const bool nok = n < a.n;
+        float bias = 0.f;
+        if (nok) {
+            const int bi = n % a.bias_mod;
+            if (a.bias0) bias += a.bias0[bi];
+            if (a.bias1) bias += a.bias1[bi];
+        }
+        int co = n, phase = 0;
+        if (a.scatter_f) { phase = n / a.out_c; co = n - phase * a.out_c; }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (nok && m < a.mrows) {
+                    float v = acc[i][j][e] + bias;
+                    if (a.scatter_f) {
+                        const int orow = m * a.scatter_f + phase - a.scatter_pad;
+                        if (orow >= 0 && orow < a.out_rows)
+                            Elem<T>::st(out + ((size_t)b * a.out_rows + orow) * a.out_c + co, v);
+                    } else {
+                        const size_t o = ((size_t)b * a.out_rows + m) * a.out_c + n;
+                        if (res) v += Elem<T>::ld(res + o);
+                        if (a.gelu) v = gelu_erf_f(v);
+                        Elem<T>::st(out + o, v);
+                        s1 += v; s2 += v * v;
+                    }
+                }
+            }
+        }
+        if (do_stats) {
+            // lanes r..r+gs-1 (same 32-lane half) hold channels of one group; the two halves hold
+            // different rows of the same channels.
+            const int span = gs < 32 ? gs : 32;
+            for (int o = 1; o < span; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0 && (r & (span - 1)) == 0 && nok) {
+                double* sp = a.stats + ((size_t)b * a.stats_groups + n / gs) * 2;
+                atomicAdd(sp, (double)s1);
+                atomicAdd(sp + 1, (double)s2);
+            }
+        }
+    }
+}
+
+// host-side launcher (adf_gemm.hip)
+const char* launch_conv_gemm(const GemmArgs& a, int dtype_bf16, hipStream_t stream);
+
+}  // namespace adf

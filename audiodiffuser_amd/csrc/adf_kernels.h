@@ -1,0 +1,82 @@
+// Launchers of the non-GEMM kernels of the EDM sampling path (adf_kernels.hip).
+// Every launcher returns nullptr on success or a static error string; none of them allocates,
+// synchronises or copies, so they are safe inside hipGraph capture.
+#pragma once
+#include "adf_common.h"
+
+namespace adf {
+
+// GroupNorm statistics of an NLC tensor: stats[b][g][2] += (sum, sumsq) in fp64 (buffer pre-zeroed).
+const char* launch_gn_stats(const void* x, int bf16, int B, int L, int C, int G, double* stats, hipStream_t s);
+
+// Fold GroupNorm (+ optional FiLM scale/shift) into a per-(sample, channel) affine y = a*x + b
+// for a (possibly concatenated) input [src0 (c0) ; scale1 * src1 (c1)].
+struct GnFinalizeArgs {
+    const double* stats0; const double* stats1;  // [B][G][2] per source tensor
+    int c0, c1, L, G, B;
+    float scale1, eps;
+    const float* gamma; const float* beta;        // [c0+c1]
+    const float* film; int film_bstride;           // film[b*bstride + c] = scale, film[b*bstride + ctot + c] = shift
+    float* ab;                                     // [B][c0+c1][2]
+};
+const char* launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
+
+// Row LayerNorm over the channel (last) dim of an NLC tensor; beta may be null (gain only).
+const char* launch_ln_rows(const void* x, void* y, int bf16, long long rows, int C, const float* gamma,
+                           const float* beta, float eps, hipStream_t s);
+
+// Multi-head self-attention on a fused qkv tensor [B][N][3C] (q | k | v), out [B][N][C].
+const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N, int C, int heads, hipStream_t s);
+
+// Input transform Conv1d(in_ch -> nf, k=wl, stride, pad) on the fp32 waveform x[B][in_ch][L], with the
+// EDM c_in scaling fused: out NLC [B][L/stride][nf].  coef may be null (c_in = 1).
+const char* launch_to_in(const float* x, const float* w, void* out, int bf16, int B, int in_ch, int L, int nf,
+                         int wl, int stride, int pad, const float* coef, int coef_bstride, hipStream_t s);
+
+// Output transform ConvTranspose1d(nf -> out_ch, k=wl, stride, pad) + EDM epilogue
+//   mode 0: out = F;  mode 1: out = clamp(c_skip*x_noisy + c_out*F, -1, 1).   out / x_noisy: fp32 [B][out_ch][L]
+const char* launch_to_out(const void* h, const float* w, float* out, int bf16, int B, int out_ch, int Lh, int nf,
+                          int wl, int stride, int pad, int mode, const float* x_noisy, const float* coef,
+                          int coef_bstride, hipStream_t s);
+
+// coef[b][4] = (c_in, c_noise, c_skip, c_out) from sigma (EluDiffusion.get_scale_weights).
+const char* launch_edm_coef(const float* sigmas_dev, float sigma_scalar, int nb, float sigma_data, float* coef,
+                            hipStream_t s);
+
+// Time embedding MLP: t[b] -> temb[b][4*ch];  t read as t[b*t_stride].
+struct TimeEmbedArgs {
+    const float* t; int t_stride; int nb; int ch;
+    const float* fourier; const float* w1; const float* b1; const float* w2; const float* b2;
+    float* temb;
+};
+const char* launch_time_embed(const TimeEmbedArgs& a, hipStream_t s);
+
+// All resblocks' FiLM projections at once: film[b][j] = bias[j] + sum_i W[j][i] * silu(temb[b][i]).
+const char* launch_film(const float* temb, const float* w, const float* bias, float* film, int nb, int tdim,
+                        int total, hipStream_t s);
+
+// ---- sampler state updates (fp32, flat arrays of n elements) --------------------------------
+const char* launch_scale(float* out, const float* in, float s, long long n, hipStream_t st);
+// x_hat = x + c * s_noise * eps
+const char* launch_churn(float* x_hat, const float* x, const float* eps, float c, float s_noise, long long n, hipStream_t st);
+// d = (x - den) / sigma ; x_next = x + dt * d
+const char* launch_euler(float* x_next, float* d, const float* x, const float* den, float sigma, float dt, long long n, hipStream_t st);
+// d2 = (x_e - den2) / sigma2 ; x_next = x + h * (w1 * d + w2 * d2)
+const char* launch_rk2(float* x_next, const float* x, const float* d, const float* x_e, const float* den2,
+                       float sigma2, float h, float w1, float w2, long long n, hipStream_t st);
+// DPM-Solver++ multistep update (orders 1..3), x0-prediction form.
+struct DpmArgs {
+    int order; float ratio, phi1, phi2, phi3, inv_r0, inv_r1, r0_frac, inv_r01;
+    const float* m0; const float* m1; const float* m2;
+};
+const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st);
+const char* launch_clamp(float* x, long long n, hipStream_t st);
+
+const char* launch_nlc_to_ncl_f32(const void* x, float* y, int bf16, int B, int L, int C, hipStream_t st);
+
+// ---- weight packing (fp32 state-dict tensors -> GEMM operand layout) ---------------------------
+// mode 0: Conv1d / Linear weight (Cout, Cin, K) ; mode 1: ConvTranspose1d weight (Cin, Cout, K=2f) as 2-tap phases
+const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, int cout, int cin, int K, int f,
+                               int n_offset, int n_pad, int nchunk, hipStream_t s);
+
+}  // namespace adf

@@ -1,0 +1,614 @@
+// Non-GEMM kernels of the EDM sampling path: norms, attention, waveform in/out transforms with the
+// EDM preconditioning fused, sigma embedding, sampler state updates, weight packing.
+// All are bandwidth- or latency-bound; they use 16-byte accesses along the contiguous channel axis
+// of the NLC activations (or the sample axis of the fp32 waveform) and 64-lane wave reductions.
+#include "adf_kernels.h"
+
+namespace adf {
+
+#define ADF_LAUNCH_CHECK(name) (hipGetLastError() == hipSuccess ? nullptr : name ": launch failed")
+
+// =====================================================================================================
+// GroupNorm statistics (reference: torch.nn.GroupNorm inside ConvBlock1d, unet1d.py:178-182,198)
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, int L, int C, int G, int rows_per_block,
+                                                       double* __restrict__ stats) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* csum = (float*)smem;       // [C]
+    float* csq = csum + C;            // [C]
+    const int b = blockIdx.y;
+    const int cpr = C / EPC;          // 16-byte chunks per row (power of two, <= 256)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * C; i += 256) csum[i] = 0.f;
+    __syncthreads();
+    const int cc = tid % cpr, rsub = tid / cpr, rstep = 256 / cpr;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(L, r0 + rows_per_block);
+    float s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    const T* base = x + (size_t)b * L * C + (size_t)cc * EPC;
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+        const uint4 v = *(const uint4*)(base + (size_t)r * C);
+        float f[EPC];
+        unpack16<T>(v, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        atomicAdd(&csum[cc * EPC + e], s[e]);
+        atomicAdd(&csq[cc * EPC + e], q[e]);
+    }
+    __syncthreads();
+    const int gs = C / G;
+    if (tid < G) {
+        double a = 0.0, c = 0.0;
+        for (int i = 0; i < gs; ++i) { a += (double)csum[tid * gs + i]; c += (double)csq[tid * gs + i]; }
+        atomicAdd(&stats[((size_t)b * G + tid) * 2], a);
+        atomicAdd(&stats[((size_t)b * G + tid) * 2 + 1], c);
+    }
+}
+
+const char* launch_gn_stats(const void* x, int bf16, int B, int L, int C, int G, double* stats, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (C % epc) return "gn_stats: C must be a multiple of a 16-byte chunk";
+    const int cpr = C / epc;
+    if (cpr > 256 || (cpr & (cpr - 1))) return "gn_stats: C/chunk must be a power of two <= 256";
+    if (C % G || G > 256) return "gn_stats: bad group count";
+    const int rstep = 256 / cpr;
+    int rows_per_block = rstep * 16;
+    while ((long long)ceil_div(L, rows_per_block) * B > 8192) rows_per_block *= 2;
+    dim3 grid(ceil_div(L, rows_per_block), B);
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    if (bf16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, L, C, G, rows_per_block, stats);
+    else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds, s, (const float*)x, L, C, G, rows_per_block, stats);
+    return ADF_LAUNCH_CHECK("gn_stats");
+}
+
+// GroupNorm apply + FiLM (unet1d.py:160-161, 198-200) folded to y = a*x + b per (sample, channel).
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a) {
+    const int b = blockIdx.x;
+    const int ctot = a.c0 + a.c1;
+    const int gs = ctot / a.G;
+    for (int c = threadIdx.x; c < ctot; c += 256) {
+        const int j = c / gs;
+        const int cstart = j * gs;
+        const bool s1 = cstart >= a.c0;
+        const double* st = s1 ? a.stats1 : a.stats0;
+        const int csrc = s1 ? a.c1 : a.c0;
+        const int lc = s1 ? cstart - a.c0 : cstart;
+        const int fg = csrc / a.G;                // channels per stored (fine) group
+        const int g0 = lc / fg, g1 = (lc + gs + fg - 1) / fg;
+        double sum = 0.0, sq = 0.0;
+        for (int g = g0; g < g1; ++g) { sum += st[((size_t)b * a.G + g) * 2]; sq += st[((size_t)b * a.G + g) * 2 + 1]; }
+        const double sc = s1 ? (double)a.scale1 : 1.0;
+        sum *= sc; sq *= sc * sc;
+        const double cnt = (double)a.L * (double)gs;
+        const double mean = sum / cnt;
+        double var = sq / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float meanf = (float)mean;
+        const float gam = a.gamma[c], bet = a.beta[c];
+        float A = rstd * gam;
+        float Bc = bet - meanf * A;
+        if (a.film) {
+            const float fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
+            const float fh = a.film[(size_t)b * a.film_bstride + ctot + c];
+            A *= fs;
+            Bc = fmaf(Bc, fs, fh);
+        }
+        if (s1) A *= a.scale1;
+        float* o = a.ab + ((size_t)b * ctot + c) * 2;
+        o[0] = A; o[1] = Bc;
+    }
+}
+
+const char* launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
+    const int ctot = a.c0 + a.c1;
+    if (ctot % a.G) return "gn_finalize: channels not divisible by groups";
+    const int gs = ctot / a.G;
+    if (a.c0 % gs) return "gn_finalize: a group straddles the two concatenated sources";
+    if (a.c0 % a.G || (a.c1 && a.c1 % a.G)) return "gn_finalize: source channels not divisible by groups";
+    if (gs % (a.c0 / a.G) || (a.c1 && gs % (a.c1 / a.G))) return "gn_finalize: group size not a multiple of the stored group size";
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B), dim3(256), 0, s, a);
+    return ADF_LAUNCH_CHECK("gn_finalize");
+}
+
+// =====================================================================================================
+// Row LayerNorm (nn.LayerNorm in TransformerBlock1d unet1d.py:80,111; LayerNorm1d :31-43 in NLC)
+// =====================================================================================================
+template <typename T, int MAXCH>
+__global__ void __launch_bounds__(256) ln_rows_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int cpr = C / EPC;
+    float f[MAXCH][EPC];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int cc = lane + k * 64;
+        if (cc < cpr) {
+            const uint4 v = *(const uint4*)(x + row * C + (size_t)cc * EPC);
+            unpack16<T>(v, f[k]);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sum += f[k][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int cc = lane + k * 64;
+        if (cc < cpr) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float d = f[k][e] - mean; sq = fmaf(d, d, sq); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int cc = lane + k * 64;
+        if (cc < cpr) {
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = cc * EPC + e;
+                float v = (f[k][e] - mean) * rstd * gamma[c];
+                if (beta) v += beta[c];
+                o[e] = v;
+            }
+            *(uint4*)(y + row * C + (size_t)cc * EPC) = pack16<T>(o);
+        }
+    }
+}
+
+const char* launch_ln_rows(const void* x, void* y, int bf16, long long rows, int C, const float* gamma,
+                           const float* beta, float eps, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (C % epc) return "ln_rows: C must be a multiple of a 16-byte chunk";
+    if (C / epc > 64 * 4) return "ln_rows: C too large";
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (bf16) hipLaunchKernelGGL((ln_rows_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C, gamma, beta, eps);
+    else hipLaunchKernelGGL((ln_rows_kernel<float, 4>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, rows, C, gamma, beta, eps);
+    return ADF_LAUNCH_CHECK("ln_rows");
+}
+
+// =====================================================================================================
+// Self-attention (attention_utils.py:160-182): one query row per lane, online softmax in fp32.
+// K/V rows are wave-broadcast loads.  (Round-1 VALU version; MFMA version is the next step.)
+// =====================================================================================================
+template <typename T, int DH>
+__global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int N, int C,
+                                                        int heads, float scale) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int NCH = DH / EPC;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * heads * N;
+    if (gid >= total) return;
+    const int qi = (int)(gid % N);
+    const int hh = (int)((gid / N) % heads);
+    const int b = (int)(gid / ((long long)N * heads));
+    const size_t rowstride = (size_t)3 * C;
+    const T* base = qkv + (size_t)b * N * rowstride + (size_t)hh * DH;
+    float q[DH], o[DH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint4 v = *(const uint4*)(base + (size_t)qi * rowstride + k * EPC);
+        unpack16<T>(v, q + k * EPC);
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { q[d] *= scale; o[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const T* kr = base + (size_t)j * rowstride + C;
+        float sdot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            float kf[EPC];
+            unpack16<T>(*(const uint4*)(kr + k * EPC), kf);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sdot = fmaf(q[k * EPC + e], kf[e], sdot);
+        }
+        const float mn = fmaxf(m, sdot);
+        const float alpha = __expf(m - mn);
+        const float p = __expf(sdot - mn);
+        l = l * alpha + p;
+        const T* vr = kr + C;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            float vf[EPC];
+            unpack16<T>(*(const uint4*)(vr + k * EPC), vf);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[k * EPC + e] = fmaf(o[k * EPC + e], alpha, p * vf[e]);
+        }
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+    T* orow = out + ((size_t)b * N + qi) * C + (size_t)hh * DH;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        float t[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) t[e] = o[k * EPC + e] * inv;
+        *(uint4*)(orow + k * EPC) = pack16<T>(t);
+    }
+}
+
+template <typename T>
+static const char* attention_dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
+    const int dh = C / heads;
+    const long long total = (long long)B * heads * N;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    const float scale = 1.0f / sqrtf((float)dh);
+#define ADF_ATT(D) hipLaunchKernelGGL((attention_kernel<T, D>), dim3(grid), dim3(256), 0, s, (const T*)qkv, (T*)out, B, N, C, heads, scale)
+    switch (dh) {
+        case 8: ADF_ATT(8); break;
+        case 16: ADF_ATT(16); break;
+        case 32: ADF_ATT(32); break;
+        case 64: ADF_ATT(64); break;
+        default: return "attention: head dim must be 8, 16, 32 or 64";
+    }
+#undef ADF_ATT
+    return ADF_LAUNCH_CHECK("attention");
+}
+
+const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N, int C, int heads, hipStream_t s) {
+    if (C % heads) return "attention: C % heads != 0";
+    return bf16 ? attention_dispatch<bf16_t>(qkv, out, B, N, C, heads, s) : attention_dispatch<float>(qkv, out, B, N, C, heads, s);
+}
+
+// =====================================================================================================
+// Waveform -> features: WAVenc1d (unet1d.py:584-591) with c_in * x fused (diffusion.py:50)
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) to_in_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
+                                                    int in_ch, int L, int nf, int wl, int stride, int pad,
+                                                    const float* __restrict__ coef, int coef_bstride) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl_s = (float*)smem;  // [in_ch][wl][nf]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < nf * in_ch * wl; i += 256) {
+        const int k = i % wl, ci = (i / wl) % in_ch, co = i / (wl * in_ch);
+        wl_s[(ci * wl + k) * nf + co] = w[i];
+    }
+    __syncthreads();
+    const int cpr = nf / EPC;
+    const int Lo = L / stride;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)Lo * cpr) return;
+    const int cc = (int)(idx % cpr);
+    const int m = (int)(idx / cpr);
+    const float cin = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int ci = 0; ci < in_ch; ++ci) {
+        const float* xr = x + ((size_t)b * in_ch + ci) * L;
+        for (int k = 0; k < wl; ++k) {
+            const int p = m * stride + k - pad;
+            if (p < 0 || p >= L) continue;
+            const float xv = cin * xr[p];
+            const float* wr = wl_s + (ci * wl + k) * nf + cc * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = fmaf(wr[e], xv, acc[e]);
+        }
+    }
+    *(uint4*)(out + ((size_t)b * Lo + m) * nf + (size_t)cc * EPC) = pack16<T>(acc);
+}
+
+const char* launch_to_in(const float* x, const float* w, void* out, int bf16, int B, int in_ch, int L, int nf,
+                         int wl, int stride, int pad, const float* coef, int coef_bstride, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (nf % epc) return "to_in: num_filters must be a multiple of a 16-byte chunk";
+    if (L % stride) return "to_in: L % stride != 0";
+    const size_t lds = (size_t)nf * in_ch * wl * sizeof(float);
+    if (lds > 60000) return "to_in: weight tile too large for LDS";
+    const long long work = (long long)(L / stride) * (nf / epc);
+    dim3 grid((unsigned)((work + 255) / 256), B);
+    if (bf16) hipLaunchKernelGGL(to_in_kernel<bf16_t>, grid, dim3(256), lds, s, x, w, (bf16_t*)out, in_ch, L, nf, wl, stride, pad, coef, coef_bstride);
+    else hipLaunchKernelGGL(to_in_kernel<float>, grid, dim3(256), lds, s, x, w, (float*)out, in_ch, L, nf, wl, stride, pad, coef, coef_bstride);
+    return ADF_LAUNCH_CHECK("to_in");
+}
+
+// =====================================================================================================
+// Features -> waveform: WAVdec1d (unet1d.py:611-622) + EDM combine and clamp (diffusion.py:60-63)
+// Each thread turns one feature row into its wl tap products P[row][k]; outputs gather wl/stride of them.
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) to_out_kernel(const T* __restrict__ h, const float* __restrict__ w, float* __restrict__ out,
+                                                     int out_ch, int Lh, int nf, int wl, int stride, int pad, int mode,
+                                                     const float* __restrict__ x_noisy, const float* __restrict__ coef,
+                                                     int coef_bstride) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int R = 256;                 // feature rows owned by a block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = (wl + stride - 1) / stride;
+    float* ws = (float*)smem;              // [nf][wl]   (for this output channel)
+    float* P = ws + nf * wl;               // [R + 2*halo][wl]
+    const int b = blockIdx.y, oc = blockIdx.z;
+    for (int i = threadIdx.x; i < nf * wl; i += 256) {
+        const int k = i % wl, ci = i / wl;
+        ws[i] = w[((size_t)ci * out_ch + oc) * wl + k];
+    }
+    __syncthreads();
+    const int i0 = blockIdx.x * R - halo;
+    const int nrows = R + 2 * halo;
+    for (int rr = threadIdx.x; rr < nrows; rr += 256) {
+        const int i = i0 + rr;
+        float p[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p[k] = 0.f;
+        if (i >= 0 && i < Lh) {
+            const T* row = h + ((size_t)b * Lh + i) * nf;
+            for (int c = 0; c < nf; c += EPC) {
+                float f[EPC];
+                unpack16<T>(*(const uint4*)(row + c), f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float* wr = ws + (c + e) * wl;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) if (k < wl) p[k] = fmaf(f[e], wr[k], p[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < wl) P[rr * wl + k] = p[k];
+    }
+    __syncthreads();
+    const int L = Lh * stride;
+    const int l0 = blockIdx.x * R * stride;
+    float c_skip = 0.f, c_out = 1.f;
+    if (mode == 1) { c_skip = coef[(size_t)b * coef_bstride + 2]; c_out = coef[(size_t)b * coef_bstride + 3]; }
+    for (int t = threadIdx.x; t < R * stride; t += 256) {
+        const int l = l0 + t;
+        if (l >= L) break;
+        float acc = 0.f;
+        // taps k with (l + pad - k) % stride == 0, feature row i = (l + pad - k) / stride
+        const int k0 = (l + pad) % stride;
+        for (int k = k0; k < wl; k += stride) {
+            const int i = (l + pad - k) / stride;
+            if (i >= 0 && i < Lh && (l + pad - k) >= 0) acc += P[(i - i0) * wl + k];
+        }
+        const size_t o = ((size_t)b * out_ch + oc) * L + l;
+        float v = acc;
+        if (mode == 1) {
+            v = fmaf(c_skip, x_noisy[o], c_out * acc);
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+        }
+        out[o] = v;
+    }
+}
+
+const char* launch_to_out(const void* h, const float* w, float* out, int bf16, int B, int out_ch, int Lh, int nf,
+                          int wl, int stride, int pad, int mode, const float* x_noisy, const float* coef,
+                          int coef_bstride, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (nf % epc) return "to_out: num_filters must be a multiple of a 16-byte chunk";
+    if (wl > 16) return "to_out: window_length > 16 unsupported";
+    const int halo = (wl + stride - 1) / stride;
+    const size_t lds = ((size_t)nf * wl + (size_t)(256 + 2 * halo) * wl) * sizeof(float);
+    dim3 grid(ceil_div(Lh, 256), B, out_ch);
+    if (bf16) hipLaunchKernelGGL(to_out_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
+    else hipLaunchKernelGGL(to_out_kernel<float>, grid, dim3(256), lds, s, (const float*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
+    return ADF_LAUNCH_CHECK("to_out");
+}
+
+// =====================================================================================================
+// EDM preconditioning scalars (diffusion.py:232-241): coef[b] = (c_in, c_noise, c_skip, c_out)
+// =====================================================================================================
+__global__ void edm_coef_kernel(const float* __restrict__ sigmas, float sigma_scalar, int nb, float sd, float* __restrict__ coef) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const float s = sigmas ? sigmas[b] : sigma_scalar;
+    const float s2 = s * s, d2 = sd * sd;
+    coef[b * 4 + 0] = 1.0f / sqrtf(s2 + d2);
+    coef[b * 4 + 1] = logf(s) * 0.25f;
+    coef[b * 4 + 2] = d2 / (s2 + d2);
+    coef[b * 4 + 3] = s * sd * (1.0f / sqrtf(d2 + s2));
+}
+
+const char* launch_edm_coef(const float* sigmas_dev, float sigma_scalar, int nb, float sigma_data, float* coef, hipStream_t s) {
+    hipLaunchKernelGGL(edm_coef_kernel, dim3(ceil_div(nb, 64)), dim3(64), 0, s, sigmas_dev, sigma_scalar, nb, sigma_data, coef);
+    return ADF_LAUNCH_CHECK("edm_coef");
+}
+
+// =====================================================================================================
+// sigma embedding: LearnedPositionalEmbedding + MLP (unet1d.py:128-148, 678-684)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) time_embed_kernel(const TimeEmbedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ch = a.ch, td = 4 * ch, half = ch / 2;
+    float* feat = (float*)smem;          // [ch + 1]
+    float* h1 = feat + (ch + 1);         // [td]
+    const int b = blockIdx.x;
+    const float t = a.t[(size_t)b * a.t_stride];
+    for (int i = threadIdx.x; i < ch + 1; i += 256) {
+        float v;
+        if (i == 0) v = t;
+        else if (i <= half) v = sinf(t * a.fourier[i - 1] * 6.28318530717958647692f);
+        else v = cosf(t * a.fourier[i - 1 - half] * 6.28318530717958647692f);
+        feat[i] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < td; j += 256) {
+        float acc = a.b1[j];
+        const float* wr = a.w1 + (size_t)j * (ch + 1);
+        for (int i = 0; i < ch + 1; ++i) acc = fmaf(wr[i], feat[i], acc);
+        h1[j] = silu_f(acc);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < td; j += 256) {
+        float acc = a.b2[j];
+        const float* wr = a.w2 + (size_t)j * td;
+        for (int i = 0; i < td; ++i) acc = fmaf(wr[i], h1[i], acc);
+        a.temb[(size_t)b * td + j] = acc;
+    }
+}
+
+const char* launch_time_embed(const TimeEmbedArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(a.ch + 1 + 4 * a.ch) * sizeof(float);
+    hipLaunchKernelGGL(time_embed_kernel, dim3(a.nb), dim3(256), lds, s, a);
+    return ADF_LAUNCH_CHECK("time_embed");
+}
+
+// FiLM projections of every resblock in one launch (unet1d.py:269-276, 306-310): one wave per output row.
+__global__ void __launch_bounds__(256) film_kernel(const float* __restrict__ temb, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ film, int nb, int tdim, int total) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= total) return;
+    const float* wr = w + (size_t)j * tdim;
+    for (int b = 0; b < nb; ++b) {
+        float acc = 0.f;
+        for (int i = lane; i < tdim; i += 64) acc = fmaf(wr[i], silu_f(temb[(size_t)b * tdim + i]), acc);
+        acc = wave_sum(acc);
+        if (lane == 0) film[(size_t)b * total + j] = acc + bias[j];
+    }
+}
+
+const char* launch_film(const float* temb, const float* w, const float* bias, float* film, int nb, int tdim, int total, hipStream_t s) {
+    hipLaunchKernelGGL(film_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, s, temb, w, bias, film, nb, tdim, total);
+    return ADF_LAUNCH_CHECK("film");
+}
+
+// =====================================================================================================
+// Sampler state updates (sampler_edm.py:333-369 Heun/churn, :251-282 RK2-alpha, :624-690 DPM multistep)
+// Operation order follows the reference expressions so fp32 rounding matches as closely as possible.
+// =====================================================================================================
+static inline unsigned ew_grid(long long n) {
+    long long g = (n + 255) / 256;
+    return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+#define ADF_EW_LOOP for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+
+__global__ void __launch_bounds__(256) scale_kernel(float* o, const float* x, float s, long long n) { ADF_EW_LOOP o[i] = s * x[i]; }
+__global__ void __launch_bounds__(256) churn_kernel(float* o, const float* x, const float* eps, float c, float sn, long long n) {
+    ADF_EW_LOOP o[i] = x[i] + c * (sn * eps[i]);
+}
+__global__ void __launch_bounds__(256) euler_kernel(float* xn, float* d, const float* x, const float* den, float sigma, float dt, long long n) {
+    ADF_EW_LOOP { const float dd = (x[i] - den[i]) / sigma; d[i] = dd; xn[i] = x[i] + dt * dd; }
+}
+__global__ void __launch_bounds__(256) rk2_kernel(float* xn, const float* x, const float* d, const float* xe, const float* den2,
+                                                  float sigma2, float h, float w1, float w2, long long n) {
+    ADF_EW_LOOP { const float d2 = (xe[i] - den2[i]) / sigma2; xn[i] = x[i] + h * (w1 * d[i] + w2 * d2); }
+}
+__global__ void __launch_bounds__(256) dpm_kernel(float* xo, const float* x, const DpmArgs a, int clampit, long long n) {
+    ADF_EW_LOOP {
+        const float m0 = a.m0[i];
+        float v = a.ratio * x[i] - a.phi1 * m0;
+        if (a.order == 2) {
+            const float d10 = a.inv_r0 * (m0 - a.m1[i]);
+            v = v - 0.5f * a.phi1 * d10;
+        } else if (a.order == 3) {
+            const float m1 = a.m1[i];
+            const float d10 = a.inv_r0 * (m0 - m1);
+            const float d11 = a.inv_r1 * (m1 - a.m2[i]);
+            const float d1 = d10 + a.r0_frac * (d10 - d11);
+            const float d2 = a.inv_r01 * (d10 - d11);
+            v = v + a.phi2 * d1 - a.phi3 * d2;
+        }
+        if (clampit) v = fminf(fmaxf(v, -1.0f), 1.0f);
+        xo[i] = v;
+    }
+}
+__global__ void __launch_bounds__(256) clamp_kernel(float* x, long long n) { ADF_EW_LOOP x[i] = fminf(fmaxf(x[i], -1.0f), 1.0f); }
+
+const char* launch_scale(float* out, const float* in, float s, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, st, out, in, s, n);
+    return ADF_LAUNCH_CHECK("scale");
+}
+const char* launch_churn(float* x_hat, const float* x, const float* eps, float c, float s_noise, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(churn_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x_hat, x, eps, c, s_noise, n);
+    return ADF_LAUNCH_CHECK("churn");
+}
+const char* launch_euler(float* x_next, float* d, const float* x, const float* den, float sigma, float dt, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(euler_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x_next, d, x, den, sigma, dt, n);
+    return ADF_LAUNCH_CHECK("euler");
+}
+const char* launch_rk2(float* x_next, const float* x, const float* d, const float* x_e, const float* den2, float sigma2,
+                       float h, float w1, float w2, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(rk2_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x_next, x, d, x_e, den2, sigma2, h, w1, w2, n);
+    return ADF_LAUNCH_CHECK("rk2");
+}
+const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(dpm_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x_out, x, a, clamp, n);
+    return ADF_LAUNCH_CHECK("dpm_update");
+}
+const char* launch_clamp(float* x, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, n);
+    return ADF_LAUNCH_CHECK("clamp");
+}
+
+// =====================================================================================================
+// NLC (T) -> NCL fp32 copy of an internal activation (debug taps used by the parity tests)
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) nlc_to_ncl_kernel(const T* __restrict__ x, float* __restrict__ y, int L, int C, long long n) {
+    ADF_EW_LOOP {
+        const int l = (int)(i % L);
+        const int c = (int)((i / L) % C);
+        const long long b = i / ((long long)L * C);
+        y[i] = Elem<T>::ld(x + ((size_t)b * L + l) * C + c);
+    }
+}
+const char* launch_nlc_to_ncl_f32(const void* x, float* y, int bf16, int B, int L, int C, hipStream_t st) {
+    const long long n = (long long)B * L * C;
+    if (bf16) hipLaunchKernelGGL(nlc_to_ncl_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)x, y, L, C, n);
+    else hipLaunchKernelGGL(nlc_to_ncl_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, st, (const float*)x, y, L, C, n);
+    return ADF_LAUNCH_CHECK("nlc_to_ncl");
+}
+
+// =====================================================================================================
+// Weight packing: dst[chunk][tap][n][kc]  (row of 128 bytes = KC elements of K)
+// =====================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int mode, int cout,
+                                                          int cin, int K, int f, int n_offset, int n_rows, int n_pad, int nchunk,
+                                                          int taps) {
+    constexpr int KC = kRowBytesPack / (int)sizeof(T);
+    const long long total = (long long)nchunk * taps * n_rows * KC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int kc = (int)(i % KC);
+        long long r = i / KC;
+        const int nl = (int)(r % n_rows); r /= n_rows;
+        const int tap = (int)(r % taps);
+        const int chunk = (int)(r / taps);
+        const int ci = chunk * KC + kc;
+        float v = 0.f;
+        if (ci < cin) {
+            if (mode == 0) {
+                v = src[((size_t)nl * cin + ci) * K + tap];
+            } else {
+                const int p = nl / cout, co = nl - p * cout;
+                v = src[((size_t)ci * cout + co) * K + (p + tap * f)];
+            }
+        }
+        const size_t o = (((size_t)chunk * taps + tap) * n_pad + n_offset + nl) * KC + kc;
+        Elem<T>::st(dst + o, v);
+    }
+}
+
+const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, int cout, int cin, int K, int f,
+                               int n_offset, int n_pad, int nchunk, hipStream_t s) {
+    const int taps = mode == 0 ? K : 2;
+    if (mode == 1 && K != 2 * f) return "pack_weight: transposed conv needs K == 2*factor";
+    // only the real rows are written; the destination is zero-initialised at allocation (row / K padding)
+    const int n_rows = mode == 0 ? cout : f * cout;
+    if (n_offset + n_rows > n_pad) return "pack_weight: rows exceed n_pad";
+    const int kc = kRowBytesPack / (bf16 ? 2 : 4);
+    const long long total = (long long)nchunk * taps * n_rows * kc;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (bf16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, mode, cout, cin, K, f, n_offset, n_rows, n_pad, nchunk, taps);
+    else hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, mode, cout, cin, K, f, n_offset, n_rows, n_pad, nchunk, taps);
+    return ADF_LAUNCH_CHECK("pack_weight");
+}
+
+}  // namespace adf

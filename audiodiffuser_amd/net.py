@@ -1,0 +1,202 @@
+"""``model.net`` plugin: HIP-backed drop-in for the reference ``UNet1dBase``.
+
+Contract kept (reference: src/models/backbones/unet1d.py:818-893):
+  * constructor kwargs of ``UNet1dBase`` / ``UNet1d`` (hydra ``_target_`` instantiation),
+  * ``forward(x, t, classes=None, ..., cond_drop_prob=None, **kwargs) -> Tensor`` same shape as ``x``,
+  * ``state_dict()`` keys/shapes identical to the reference, so Lightning strict-loads
+    reference checkpoints (src/eval.py:73),
+  * ``.parameters()`` non-empty (dtype probe, src/models/diffunet_complex_module.py:108).
+
+The parameters are ordinary ``nn.Parameter`` s held in a module tree that reproduces the
+reference key names; the compute happens in ``libadf_hip.so`` on packed copies of them that
+are refreshed whenever a parameter changes.  PyTorch is only the memory container.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import UNet1dConfig
+from .weights import param_specs
+
+_DTYPES = {"fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16}
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class NativeHandle:
+    """Owns one ``adf_handle`` (one device, one compute dtype)."""
+
+    def __init__(self, cfg: UNet1dConfig, dtype: str, flags: int = 0):
+        self.lib = _lib.load_library()
+        self.cfg = cfg
+        self.dtype = dtype
+        c = _lib.make_config(cfg, _DTYPES[dtype], flags)
+        h = C.c_void_p()
+        rc = self.lib.adf_create(C.byref(c), C.byref(h))
+        if rc != 0:
+            raise _lib.AdfError("adf_create: " + self.lib.adf_last_error(None).decode())
+        self.h = h
+        self._loaded: Dict[str, tuple] = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.adf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int, what: str) -> None:
+        _lib.check(self.lib, self.h, rc, what)
+
+    def sync_weights(self, named: Dict[str, torch.Tensor], device: torch.device) -> None:
+        """Upload every tensor whose storage/version changed since the last call."""
+        stream = _stream_ptr(device)
+        for name, t in named.items():
+            sig = (t.data_ptr(), t._version, t.device)
+            if self._loaded.get(name) == sig:
+                continue
+            src = t.detach()
+            if src.device != device or src.dtype != torch.float32 or not src.is_contiguous():
+                src = src.to(device=device, dtype=torch.float32).contiguous()
+            self.check(self.lib.adf_load_weight(self.h, name.encode(), C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(stream)),
+                       f"adf_load_weight({name})")
+            self._loaded[name] = sig
+        missing = self.lib.adf_weights_missing(self.h)
+        if missing:
+            raise _lib.AdfError(f"{missing} state_dict tensors were not provided to the HIP library")
+
+    # ---- compute entry points (all tensors fp32, contiguous, on the handle's device) ----
+    def net_forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((x.shape[0], self.cfg.out_channels, x.shape[-1]), device=x.device, dtype=torch.float32)
+        self.check(self.lib.adf_net_forward(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()),
+                                            x.shape[0], x.shape[-1], C.c_void_p(_stream_ptr(x.device))), "adf_net_forward")
+        return out
+
+    def denoise(self, x: torch.Tensor, sigma_data: float, sigma: Optional[float] = None,
+                sigmas: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = torch.empty_like(x)
+        sp = C.c_void_p(sigmas.data_ptr()) if sigmas is not None else C.c_void_p(0)
+        self.check(self.lib.adf_denoise(self.h, C.c_void_p(x.data_ptr()), sp, float(sigma if sigma is not None else 0.0),
+                                        float(sigma_data), C.c_void_p(out.data_ptr()), x.shape[0], x.shape[-1],
+                                        C.c_void_p(_stream_ptr(x.device))), "adf_denoise")
+        return out
+
+    def sampler_run(self, desc: "_lib.AdfSamplerDesc", sigmas_host: torch.Tensor, noise: torch.Tensor,
+                    injected: Optional[torch.Tensor]) -> torch.Tensor:
+        out = torch.empty_like(noise)
+        sg = sigmas_host.detach().to("cpu", torch.float32).contiguous()
+        arr = (C.c_float * sg.numel())(*sg.tolist())
+        ip = C.c_void_p(injected.data_ptr()) if injected is not None else C.c_void_p(0)
+        self.check(self.lib.adf_sampler_run(self.h, C.byref(desc), arr, sg.numel(), C.c_void_p(noise.data_ptr()), ip,
+                                            C.c_void_p(out.data_ptr()), noise.shape[0], noise.shape[-1],
+                                            C.c_void_p(_stream_ptr(noise.device))), "adf_sampler_run")
+        return out
+
+    def tap_names(self):
+        n = self.lib.adf_debug_tap_count(self.h)
+        return [self.lib.adf_debug_tap_name(self.h, i).decode() for i in range(n)]
+
+    def tap(self, name: str, batch: int, device: torch.device) -> torch.Tensor:
+        c, l = C.c_int(), C.c_int()
+        self.check(self.lib.adf_debug_tap_shape(self.h, name.encode(), C.byref(c), C.byref(l)), "adf_debug_tap_shape")
+        out = torch.empty((batch, c.value, l.value), device=device, dtype=torch.float32)
+        self.check(self.lib.adf_debug_tap_copy(self.h, name.encode(), C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr(device))),
+                   "adf_debug_tap_copy")
+        return out
+
+
+def _init_like_reference(name: str, shape, kind: str) -> torch.Tensor:
+    """Default initialisation equivalent to the reference's torch defaults."""
+    t = torch.empty(shape, dtype=torch.float32)
+    if kind in ("conv_w", "convT_w", "linear_w"):
+        if name == "unet.to_out.to_out.weight":
+            return t.zero_()                      # unet1d.py:619
+        nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+        return t
+    if kind == "bias":
+        # torch default: U(-1/sqrt(fan_in), 1/sqrt(fan_in)); fan_in is not known here, keep it small
+        return t.uniform_(-0.05, 0.05)
+    if kind == "norm_w":
+        return t.fill_(1.0)
+    if kind == "norm_b":
+        return t.zero_()
+    if kind == "fourier":
+        return t.normal_()
+    raise ValueError(kind)
+
+
+class UNet1dBase(nn.Module):
+    """HIP-backed ``UNet1dBase``.  Extra kwarg: ``compute_dtype`` in {"fp32", "bf16"}."""
+
+    def __init__(self, channels: int, cond_drop_prob: float = 0.0, num_classes: Optional[int] = None,
+                 class_embed_dim: Optional[int] = None, class_cond: bool = False, text_cond: bool = False,
+                 max_text_len: Optional[int] = None, text_embed_dim: int = 768, text_cond_multiplier: Optional[int] = None,
+                 use_self_text_cond: bool = False, use_condition_block: bool = False,
+                 compute_dtype: str = "fp32", native_flags: int = 0, **kwargs):
+        super().__init__()
+        if class_cond or text_cond or use_condition_block:
+            raise NotImplementedError("class/text/channel conditioning is outside the round-1 hot path (SURVEY.md 8f)")
+        if compute_dtype not in _DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
+        out_channels = kwargs.pop("out_channels", None)
+        self.cond_drop_prob = cond_drop_prob
+        self.compute_dtype = compute_dtype
+        self.native_flags = native_flags
+        self.cfg = UNet1dConfig(channels=channels, cond_drop_prob=cond_drop_prob, **kwargs)
+        self.cfg.out_channels = out_channels if out_channels is not None else self.cfg.in_channels  # unet1d.py:607
+        self.cfg.validate()
+        self._specs = param_specs(self.cfg)
+        for name, (shape, kind) in self._specs.items():
+            self._register(name, nn.Parameter(_init_like_reference(name, shape, kind)))
+        self._handles: Dict[tuple, NativeHandle] = {}
+
+    # -- parameter tree with reference key names ------------------------------------
+    def _register(self, dotted: str, p: nn.Parameter) -> None:
+        mod = self
+        parts = dotted.split(".")
+        for part in parts[:-1]:
+            if part not in mod._modules:
+                mod.add_module(part, nn.Module())
+            mod = mod._modules[part]
+        mod.register_parameter(parts[-1], p)
+
+    @classmethod
+    def from_config(cls, cfg: UNet1dConfig, compute_dtype: str = "fp32", native_flags: int = 0) -> "UNet1dBase":
+        kw = cfg.to_kwargs()
+        return cls(compute_dtype=compute_dtype, native_flags=native_flags, **kw)
+
+    # -- native handle ---------------------------------------------------------------
+    def native(self, device: torch.device) -> NativeHandle:
+        if device.type != "cuda":
+            raise RuntimeError("the HIP UNet1dBase only runs on a ROCm device ('cuda'); there is no CPU fallback")
+        key = (device.index if device.index is not None else torch.cuda.current_device(), self.compute_dtype)
+        hd = self._handles.get(key)
+        if hd is None:
+            with torch.cuda.device(device):
+                hd = NativeHandle(self.cfg, self.compute_dtype, self.native_flags)
+            self._handles[key] = hd
+        hd.sync_weights(dict(self.named_parameters()), device)
+        return hd
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, classes=None, text_embeds=None, text_mask=None,
+                inj_embeddings=None, inj_channels=None, cond_drop_prob=None, **kwargs) -> torch.Tensor:
+        if classes is not None or text_embeds is not None or inj_embeddings is not None or inj_channels is not None:
+            raise NotImplementedError("conditioning inputs are outside the round-1 hot path (SURVEY.md 8f)")
+        hd = self.native(x.device)
+        xin = x.detach().to(torch.float32).contiguous()
+        tin = t.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if tin.numel() != xin.shape[0]:
+            raise ValueError("t must have one entry per batch element")
+        return hd.net_forward(xin, tin).to(x.dtype)

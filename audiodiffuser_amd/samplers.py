@@ -1,0 +1,192 @@
+"""``model.sampler`` plugins: EDM-family sampling loops
+(reference: src/models/components/sampler_edm.py:229-300 ``EDMAlphaSampler``, :302-397 ``EDMSampler``,
+:495-805 ``DPMSampler``).
+
+Constructor kwargs and ``forward(noise, fn, net, sigmas, **kwargs)`` follow the reference.  When ``fn``
+is ``EluDiffusion.denoise_fn`` of this package and ``net`` is the HIP ``UNet1dBase``, the whole step
+loop runs inside ``libadf_hip.so`` (one ``adf_sampler_run`` call, optionally one hipGraph replay): all
+branch conditions of the reference loop (``gamma > 0``, ``sigma_next != 0``, warm-up orders) depend only
+on the sigma schedule, so they are resolved on the host before anything is enqueued.  For any other
+callable the same recurrences are expressed with tensor ops around ``fn`` (interface compatibility).
+"""
+from __future__ import annotations
+
+from math import sqrt
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+from .diffusion import EluDiffusion
+from .net import UNet1dBase
+
+
+def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict) -> Optional[EluDiffusion]:
+    owner = getattr(fn, "__self__", None)
+    if (isinstance(owner, EluDiffusion) and getattr(fn, "__func__", None) is EluDiffusion.denoise_fn
+            and isinstance(net, UNet1dBase) and cond_scale == 1.0 and owner.dynamic_threshold == 0.0
+            and all(v is None for v in kwargs.values())):
+        return owner
+    return None
+
+
+def _prep(noise: Tensor) -> Tensor:
+    if noise.ndim != 3:
+        raise ValueError("the HIP sampler expects waveforms shaped [B, C, L]")
+    return noise.detach().to(torch.float32).contiguous()
+
+
+class EDMSampler(nn.Module):
+    """EDM stochastic sampler (Heun, optional churn); ``s_churn=0`` is the deterministic Heun ODE solver."""
+
+    def __init__(self, s_tmin: float = 0, s_tmax: float = float("inf"), s_churn: float = 150.0, s_noise: float = 1.04,
+                 num_steps: int = 200, cond_scale: float = 1.0, use_heun: bool = True, use_graph: bool = True):
+        super().__init__()
+        self.s_tmin, self.s_tmax, self.s_noise, self.s_churn = s_tmin, s_tmax, s_noise, s_churn
+        self.num_steps, self.cond_scale, self.use_heun, self.use_graph = num_steps, cond_scale, use_heun, use_graph
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_EDM, self.num_steps
+        d.s_tmin, d.s_tmax, d.s_churn, d.s_noise = self.s_tmin, min(self.s_tmax, 3.0e38), self.s_churn, self.s_noise
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = int(self.use_heun), 1.0, 0, sigma_data, int(self.use_graph)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
+                **kwargs) -> Tensor:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            hd = net.native(x.device)
+            inj = injected_noise
+            if inj is None and self.s_churn > 0:
+                # same draw order as the reference's per-step randn_like (sampler_edm.py:346)
+                inj = torch.stack([torch.randn_like(x) for _ in range(self.num_steps)])
+            if inj is not None:
+                inj = inj.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
+        # ---- interface-compatibility branch (sampler_edm.py:333-397) -----------------------------
+        sig = torch.cat([sigmas, torch.zeros_like(sigmas[:1])])
+        x = sig[0] * noise
+        gam = torch.where((sig >= self.s_tmin) & (sig <= self.s_tmax), min(self.s_churn / self.num_steps, sqrt(2) - 1), 0.0)
+        for i in range(self.num_steps):
+            s, s_next, g = sig[i], sig[i + 1], gam[i]
+            eps = injected_noise[i] if injected_noise is not None else torch.randn_like(x)
+            eps = self.s_noise * eps
+            if g > 0:
+                s_hat = s + g * s
+                x_hat = x + (s_hat ** 2 - s ** 2) ** 0.5 * eps
+            else:
+                s_hat, x_hat = s, x
+            d = (x_hat - fn(x_hat, net=net, sigma=s_hat, inference=True, cond_scale=self.cond_scale, **kwargs)) / s_hat
+            x = x_hat + (s_next - s_hat) * d
+            if s_next != 0 and self.use_heun:
+                d2 = (x - fn(x, net=net, sigma=s_next, inference=True, cond_scale=self.cond_scale, **kwargs)) / s_next
+                x = x_hat + 0.5 * (s_next - s_hat) * (d + d2)
+        return x
+
+
+class EDMAlphaSampler(nn.Module):
+    """EDM algorithm 3, generalised second-order Runge-Kutta; ``alpha=1`` is Heun."""
+
+    def __init__(self, alpha: float = 1.0, num_steps: int = 50, cond_scale: float = 1.0, use_heun: bool = True,
+                 use_graph: bool = True):
+        super().__init__()
+        self.alpha, self.num_steps, self.cond_scale, self.use_heun, self.use_graph = alpha, num_steps, cond_scale, use_heun, use_graph
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_EDM_ALPHA, self.num_steps
+        d.s_tmin = d.s_tmax = d.s_churn = 0.0
+        d.s_noise = 1.0
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = int(self.use_heun), self.alpha, 0, sigma_data, int(self.use_graph)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            return net.native(x.device).sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
+        x = sigmas[0] * noise                                            # sampler_edm.py:284-300
+        for i in range(self.num_steps - 1):
+            s, s_next = sigmas[i], sigmas[i + 1]
+            h = s_next - s
+            d = (x - fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)) / s
+            s_p = s + self.alpha * h
+            if s_p != 0 and self.use_heun:
+                x_p = x + self.alpha * h * d
+                d_p = (x_p - fn(x_p, net=net, sigma=s_p, inference=True, cond_scale=self.cond_scale, **kwargs)) / s_p
+                x = x + h * ((1 - 0.5 / self.alpha) * d + 0.5 / self.alpha * d_p)
+            else:
+                x = x + h * d
+        return x
+
+
+class DPMSampler(nn.Module):
+    """DPM-Solver.  The accelerated configuration is the shipped one
+    (configs/experiment/sc09_inference/diffunet_complex_sc09_eval_dpm.yaml:57-64):
+    ``multisteps=True, x0_pred=True, log_time_spacing=False``; other settings raise."""
+
+    def __init__(self, cond_scale, order=1, num_steps=10, multisteps=False, x0_pred: bool = True,
+                 log_time_spacing: bool = True, use_graph: bool = True):
+        super().__init__()
+        self.order, self.cond_scale, self.multisteps = order, cond_scale, multisteps
+        self.x0_pred, self.log_time_spacing, self.use_graph = x0_pred, log_time_spacing, use_graph
+        self.ctor_num_steps = num_steps
+        self.num_steps = num_steps if log_time_spacing else num_steps - 1      # sampler_edm.py:526
+
+    def _check_supported(self) -> None:
+        if not (self.multisteps and self.x0_pred and not self.log_time_spacing):
+            raise NotImplementedError("only DPMSampler(multisteps=True, x0_pred=True, log_time_spacing=False) is on the "
+                                      "hot path (SURVEY.md 8a16); single-step / eps-pred / log-spaced variants are next-round work")
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_DPM_MULTISTEP, self.ctor_num_steps
+        d.s_tmin = d.s_tmax = d.s_churn = 0.0
+        d.s_noise = 1.0
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, int(self.order), sigma_data, int(self.use_graph)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
+        self._check_supported()
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            return net.native(x.device).sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
+        # ---- interface-compatibility branch (sampler_edm.py:710-768, :624-690) --------------------
+        steps, order = self.num_steps, self.order
+        assert steps >= order
+        lam = lambda s: -s.log()
+        call = lambda x, s: fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)
+        x = sigmas[0] * noise
+        s_hist, m_hist = [sigmas[0]], [call(x, sigmas[0])]
+        for step in range(1, steps + 1):
+            o = step if step < order else min(order, steps + 1 - step)
+            s_cur, s0 = sigmas[step], s_hist[-1]
+            h = lam(s_cur) - lam(s0)
+            phi1 = torch.expm1(-h)
+            new = s_cur / s0 * x - phi1 * m_hist[-1]
+            if o == 2:
+                r0 = (lam(s0) - lam(s_hist[-2])) / h
+                new = new - 0.5 * phi1 * ((1.0 / r0) * (m_hist[-1] - m_hist[-2]))
+            elif o == 3:
+                r0 = (lam(s0) - lam(s_hist[-2])) / h
+                r1 = (lam(s_hist[-2]) - lam(s_hist[-3])) / h
+                d10 = (1.0 / r0) * (m_hist[-1] - m_hist[-2])
+                d11 = (1.0 / r1) * (m_hist[-2] - m_hist[-3])
+                d1 = d10 + (r0 / (r0 + r1)) * (d10 - d11)
+                d2 = (1.0 / (r0 + r1)) * (d10 - d11)
+                phi2 = phi1 / h + 1.0
+                phi3 = phi2 / h - 0.5
+                new = new + phi2 * d1 - phi3 * d2
+            x = new
+            s_hist = (s_hist + [s_cur])[-order:]
+            if step < steps:
+                m_hist = (m_hist + [call(x, s_cur)])[-order:]
+        return x.clamp(-1.0, 1.0)

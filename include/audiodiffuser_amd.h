@@ -1,0 +1,115 @@
+/* C ABI of libadf_hip.so -- the MI355X (gfx950) implementation of AudioDiffuser's EDM sampling hot path.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *   adf_create / adf_load_weight   <- UNet1dBase.__init__ + Lightning strict state_dict load
+ *                                     (src/models/backbones/unet1d.py:818-862, src/eval.py:73)
+ *   adf_net_forward                <- UNet1dBase.forward            (src/models/backbones/unet1d.py:864-893, :771-816)
+ *   adf_denoise                    <- Diffusion.denoise_fn + EluDiffusion.get_scale_weights + clip
+ *                                     (src/models/components/diffusion.py:32-63, :232-241; components/utils.py:20-22)
+ *   adf_sampler_run                <- EDMSampler.forward / EDMAlphaSampler.forward / DPMSampler.forward (multistep)
+ *                                     (src/models/components/sampler_edm.py:371-397, :284-300, :710-768)
+ *   the call site all of them sit behind: src/models/diffunet_complex_module.py:86-89
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; adf_last_error() gives the message.
+ *     No C++ exception crosses this boundary.
+ *   - tensors are caller-owned DEVICE buffers (fp32, contiguous, reference layout [B][C][L]); the library
+ *     never frees them and only owns its weights / workspace / graphs.
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream); all work
+ *     is enqueued there, nothing synchronises the device except adf_load_weight's final packing, which is
+ *     also stream-ordered.
+ *   - one handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef AUDIODIFFUSER_AMD_H
+#define AUDIODIFFUSER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADF_MAX_LAYERS 12
+
+#define ADF_DTYPE_F32 0  /* parity mode: fp32 storage, exact-fp32 MFMA */
+#define ADF_DTYPE_BF16 1 /* throughput mode: bf16 storage, fp32 accumulate */
+
+/* Hyper-parameters of UNet1dBase (unconditional path); same meaning as the reference kwargs. */
+typedef struct adf_net_config {
+    int32_t channels, num_filters, window_length, stride, in_channels, out_channels;
+    int32_t resnet_groups, kernel_multiplier_downsample;
+    int32_t num_layers;                     /* len(multipliers) - 1 */
+    int32_t multipliers[ADF_MAX_LAYERS + 1];
+    int32_t factors[ADF_MAX_LAYERS];
+    int32_t num_blocks[ADF_MAX_LAYERS];
+    int32_t attentions[ADF_MAX_LAYERS];
+    int32_t attention_heads, attention_multiplier;
+    int32_t use_skip_scale, use_attention_bottleneck;
+    int32_t dtype;                          /* ADF_DTYPE_* */
+    int32_t flags;                          /* ADF_FLAG_* */
+} adf_net_config;
+
+#define ADF_FLAG_SEPARATE_GN_STATS 1 /* compute GroupNorm statistics in a separate pass instead of the GEMM epilogue */
+
+#define ADF_SAMPLER_EDM 0       /* EDMSampler: Heun + optional churn      */
+#define ADF_SAMPLER_EDM_ALPHA 1 /* EDMAlphaSampler: generalised RK2        */
+#define ADF_SAMPLER_DPM_MULTISTEP 2 /* DPMSampler(multisteps=True, x0_pred=True, log_time_spacing=False) */
+
+typedef struct adf_sampler_desc {
+    int32_t kind;
+    int32_t num_steps;   /* the reference constructor's num_steps */
+    float s_tmin, s_tmax, s_churn, s_noise;  /* EDM */
+    int32_t use_heun;    /* EDM, EDM_ALPHA */
+    float alpha;         /* EDM_ALPHA */
+    int32_t order;       /* DPM: 1..3 */
+    float sigma_data;    /* EluDiffusion.sigma_data */
+    int32_t use_graph;   /* capture the whole step loop into one hipGraph and replay it */
+} adf_sampler_desc;
+
+typedef struct adf_handle adf_handle;
+
+int adf_create(const adf_net_config* cfg, adf_handle** out);
+void adf_destroy(adf_handle* h);
+const char* adf_last_error(const adf_handle* h);   /* h may be NULL: error of the last failed adf_create */
+
+/* state_dict interface: names/shapes are exactly the reference UNet1dBase.state_dict() keys */
+int adf_num_weights(const adf_handle* h);
+const char* adf_weight_name(const adf_handle* h, int index);
+int64_t adf_weight_numel(const adf_handle* h, int index);
+int adf_load_weight(adf_handle* h, const char* name, const float* dev_fp32, int64_t numel, void* stream);
+int adf_weights_missing(const adf_handle* h);      /* number of tensors not loaded yet */
+
+/* out = net(x, t):  x [B][in_channels][L], t [B], out [B][out_channels][L] */
+int adf_net_forward(adf_handle* h, const float* x, const float* t, float* out, int B, int L, void* stream);
+
+/* out = clamp(c_skip*x + c_out*net(c_in*x, c_noise), -1, 1); sigmas_dev [B] or NULL (then `sigma` for all) */
+int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, float sigma, float sigma_data,
+                float* out, int B, int L, void* stream);
+
+/* Full sampling loop.  sigmas_host: the schedule tensor (host, n_sigmas entries) the reference passes as
+ * `sigmas`; noise: unit-variance [B][C][L]; injected_noise: [num_steps][B][C][L] draws replacing
+ * randn_like (required when the EDM sampler churns, may be NULL otherwise). */
+int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas,
+                    const float* noise, const float* injected_noise, float* out, int B, int L, void* stream);
+int adf_sampler_nfe(const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas);
+
+/* Parity-test support: copy an internal activation of the LAST adf_net_forward/adf_denoise call, converted to
+ * fp32 [B][C][L].  Names follow oracle/unet1d.py taps ("to_in", "down0.conv", "down0.block1", "mid.attn", ...). */
+int adf_debug_tap_shape(adf_handle* h, const char* name, int* C, int* L);
+int adf_debug_tap_copy(adf_handle* h, const char* name, float* out_fp32, void* stream);
+int adf_debug_tap_count(adf_handle* h);
+const char* adf_debug_tap_name(adf_handle* h, int index);
+
+/* Bytes of device memory held by the handle (weights + workspaces). */
+int64_t adf_device_bytes(const adf_handle* h);
+
+/* Instrumentation for bench.py: time launches [first, last) of the last eager forward is not exposed;
+ * instead a single fused-resblock pair can be replayed in isolation with HIP events on `stream`. */
+int adf_bench_resblock(adf_handle* h, int B, int L, int level, int iters, float* ms_block1, float* ms_block2,
+                       double* algo_bytes_block1, double* algo_bytes_block2, double* flops_block1,
+                       double* flops_block2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
