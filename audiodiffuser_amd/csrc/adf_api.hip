@@ -90,6 +90,10 @@ struct adf_handle {
     std::vector<UpW> ups;
     std::map<std::pair<int, int>, Plan*> plans;
     Plan* last_plan = nullptr;
+    // graphs are captured and replayed on a library-owned stream (the caller's stream may be the legacy
+    // default stream, which cannot be captured); it is fenced against the caller's stream with events
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 
 namespace {
@@ -100,7 +104,7 @@ void* dalloc(adf_handle* h, size_t bytes) {
     void* p = nullptr;
     bytes = (bytes + 255) & ~(size_t)255;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    hipMemset(p, 0, bytes);
+    (void)hipMemset(p, 0, bytes);
     h->allocs.push_back(p);
     h->bytes += (int64_t)bytes;
     return p;
@@ -678,10 +682,13 @@ int adf_create(const adf_net_config* cfg, adf_handle** out) {
 void adf_destroy(adf_handle* h) {
     if (!h) return;
     for (auto& kv : h->plans) {
-        for (auto& g : kv.second->graphs) hipGraphExecDestroy(g.second);
+        for (auto& g : kv.second->graphs) (void)hipGraphExecDestroy(g.second);
         delete kv.second;
     }
-    for (void* p : h->allocs) hipFree(p);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
     delete h;
 }
 
@@ -761,7 +768,7 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
             p->inj_stage = (float*)dalloc(h, need * 4);
             if (!p->inj_stage) return fail(h, "device allocation failed for injected noise");
             p->inj_cap = need;
-            for (auto& g : p->graphs) hipGraphExecDestroy(g.second);
+            for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.second);
             p->graphs.clear();
         }
         if (hipMemcpyAsync(p->inj_stage, injected_noise, need * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "injected-noise copy failed");
@@ -775,25 +782,39 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
         if (hipMemcpyAsync(out, result, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
         return 0;
     }
+    if (!h->gstream) {
+        if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess)
+            return fail(h, "could not create the graph stream / events");
+    }
+    hipStream_t gs = h->gstream;
+    c.s = gs;
+    // inputs staged on the caller's stream must be visible to the graph stream
+    if (hipEventRecord(h->ev_in, s) != hipSuccess || hipStreamWaitEvent(gs, h->ev_in, 0) != hipSuccess)
+        return fail(h, "stream fence (in) failed");
     std::string key((const char*)desc, sizeof(*desc));
     key.append((const char*)sigmas_host, (size_t)n_sigmas * 4);
     key.push_back(injected_noise ? 'i' : 'n');
     auto it = p->graphs.find(key);
     if (it == p->graphs.end()) {
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) return fail(h, "hipStreamBeginCapture failed");
+        const hipError_t be = hipStreamBeginCapture(gs, hipStreamCaptureModeRelaxed);
+        if (be != hipSuccess) return fail(h, std::string("hipStreamBeginCapture failed: ") + hipGetErrorString(be));
         int rc = run_sampler(c, &result);
-        if (!rc && hipMemcpyAsync(p->out_stage, result, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; h->err = "result copy failed (capture)"; }
+        if (!rc && hipMemcpyAsync(p->out_stage, result, (size_t)n * 4, hipMemcpyDeviceToDevice, gs) != hipSuccess) { rc = 1; h->err = "result copy failed (capture)"; }
         hipGraph_t graph = nullptr;
-        const hipError_t ee = hipStreamEndCapture(s, &graph);
-        if (rc) { if (graph) hipGraphDestroy(graph); return 1; }
+        const hipError_t ee = hipStreamEndCapture(gs, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
         if (ee != hipSuccess || !graph) return fail(h, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(ee));
         hipGraphExec_t exec = nullptr;
         const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         if (ie != hipSuccess) return fail(h, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ie));
         it = p->graphs.emplace(key, exec).first;
     }
-    if (hipGraphLaunch(it->second, s) != hipSuccess) return fail(h, "hipGraphLaunch failed");
+    if (hipGraphLaunch(it->second, gs) != hipSuccess) return fail(h, "hipGraphLaunch failed");
+    if (hipEventRecord(h->ev_out, gs) != hipSuccess || hipStreamWaitEvent(s, h->ev_out, 0) != hipSuccess)
+        return fail(h, "stream fence (out) failed");
     if (hipMemcpyAsync(out, p->out_stage, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
     return 0;
 }
@@ -832,17 +853,17 @@ int adf_bench_resblock(adf_handle* h, int B, int L, int level, int iters, float*
     GemmArgs g1 = r.g1, g2 = r.g2;
     g1.stats = nullptr; g2.stats = nullptr;  // timing replay must not disturb the statistics buffers
     hipEvent_t e0, e1, e2;
-    hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2);
     for (int i = 0; i < 2; ++i) { launch_conv_gemm(g1, h->bf16, s); launch_conv_gemm(g2, h->bf16, s); }
-    hipEventRecord(e0, s);
+    (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters; ++i) if (const char* e = launch_conv_gemm(g1, h->bf16, s)) return fail(h, e);
-    hipEventRecord(e1, s);
+    (void)hipEventRecord(e1, s);
     for (int i = 0; i < iters; ++i) if (const char* e = launch_conv_gemm(g2, h->bf16, s)) return fail(h, e);
-    hipEventRecord(e2, s);
+    (void)hipEventRecord(e2, s);
     if (hipEventSynchronize(e2) != hipSuccess) return fail(h, "bench_resblock: event sync failed");
     float a = 0, b = 0;
-    hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&b, e1, e2);
-    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    (void)hipEventElapsedTime(&a, e0, e1); (void)hipEventElapsedTime(&b, e1, e2);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     *ms1 = a / iters; *ms2 = b / iters;
     const double es = h->esz, BL = (double)B * r.L, ci = r.cin, co = r.cout;
     // x read for conv1; x read again for the residual; h1 written and re-read; y written; weights once
