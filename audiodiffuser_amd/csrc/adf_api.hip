@@ -297,11 +297,15 @@ struct Walker {
     }
 
     Act linear(const Act& x, const ConvW& w, const void* res, int gelu, bool want_stats) {
+        // a 1x1 op has no halo: run it over the flattened [B*L] rows as one long sample
         Act out = new_act(w.n, x.L);
-        GemmArgs g = gemm_base(out, x.L, x.L, w);
+        const int rows = p->B * x.L;
+        GemmArgs g = gemm_base(out, rows, rows, w);
+        g.B = 1; g.out_rows = rows;
         g.seg[0] = seg_of(x, nullptr, nullptr, 1.f, 0, 1, 1, 0, 1, w);
         g.res = res; g.gelu = gelu;
-        run_gemm(g, out, want_stats);
+        run_gemm(g, out, false);
+        (void)want_stats;   // per-sample statistics come from the separate pass (ensure_stats) when needed
         return out;
     }
 
@@ -320,9 +324,16 @@ struct Walker {
             f.scale1 = sscale; f.eps = 1e-5f; f.gamma = r.g1w; f.beta = r.g1b; f.film = nullptr; f.ab = ab1;
             check(launch_gn_finalize(f, s));
         }
+        const bool short_level = x.L <= 64 && (x.L & (x.L - 1)) == 0;
         Act h1 = new_act(r.cout, x.L);
         GemmArgs g1 = gemm_base(h1, x.L, x.L, r.c1);
-        g1.seg[0] = seg_of(x, skip, ab1, sscale, 1, 3, 1, -1, 1, r.c1);
+        if (short_level) {
+            Act a1 = new_act(ctot, x.L);
+            if (live()) check(launch_gn_apply(x.p, skip ? skip->p : nullptr, x.C, skip ? skip->C : 0, x.L, B, ab1, 1, a1.p, h->bf16, s));
+            g1.seg[0] = seg_of(a1, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, r.c1);
+        } else {
+            g1.seg[0] = seg_of(x, skip, ab1, sscale, 1, 3, 1, -1, 1, r.c1);
+        }
         run_gemm(g1, h1, true);
         double* sh = ensure_stats(h1);
         float* ab2 = (float*)alloc((size_t)B * r.cout * 2 * 4);
@@ -336,7 +347,13 @@ struct Walker {
         }
         Act y = new_act(r.cout, x.L);
         GemmArgs g2 = gemm_base(y, x.L, x.L, r.c2);
-        g2.seg[0] = seg_of(h1, nullptr, ab2, 1.f, 1, 3, 1, -1, 1, r.c2);
+        if (short_level) {
+            Act a2 = new_act(r.cout, x.L);
+            if (live()) check(launch_gn_apply(h1.p, nullptr, r.cout, 0, x.L, B, ab2, 1, a2.p, h->bf16, s));
+            g2.seg[0] = seg_of(a2, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, r.c2);
+        } else {
+            g2.seg[0] = seg_of(h1, nullptr, ab2, 1.f, 1, 3, 1, -1, 1, r.c2);
+        }
         if (r.has_res) {
             g2.nseg = 2;
             g2.seg[1] = seg_of(x, skip, nullptr, sscale, 0, 1, 1, 0, 1, r.cr);

@@ -46,16 +46,26 @@ template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
+// two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN kept)
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    f32x2_hw_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
+}
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
     uint4 q;
-    q.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-    q.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-    q.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-    q.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    q.x = pack_bf16x2(f[0], f[1]);
+    q.y = pack_bf16x2(f[2], f[3]);
+    q.z = pack_bf16x2(f[4], f[5]);
+    q.w = pack_bf16x2(f[6], f[7]);
     return q;
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// SiLU = v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): 5 VALU ops, 2 of them transcendental
+__device__ __forceinline__ float silu_f(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 __device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -10,8 +10,14 @@
 //   applied while the activation tile is staged into LDS; conv zero padding is applied after f().
 //   A second K segment (raw skip-concat input, 1x1) implements ResnetBlock1d.to_out inside the
 //   same accumulators.  The channel concat of the up path is never materialised: a segment reads
-//   two source tensors.  Epilogue: bias, identity residual, GELU, transposed-conv phase scatter,
-//   optional GroupNorm statistics of the produced tensor (fp64 atomics into [B][G][2]).
+//   two source tensors.
+// Tiling: an M tile either lies inside one sample ("per-sample" mode) or, for short sequences with raw
+//   inputs, covers several whole samples ("flat" mode: the LDS image keeps one zero-padded segment per
+//   sample so taps never leak across sample boundaries).
+// Epilogue: accumulators (+bias) are staged through LDS as fp32, then written with 16-byte stores along
+//   the contiguous channel axis (identity residual, GELU and the transposed-conv phase scatter applied
+//   there), and the GroupNorm statistics of the produced tensor are reduced from the same LDS image
+//   (fp64 atomics into [B][G][2]).
 //
 // MFMA: 32x32x16 bf16 (throughput mode) or 32x32x2 f32 (parity mode, exact fp32 FMA chain); a wave
 // owns an (MT*32) x (NT*32) accumulator tile; K is walked in 128-byte rows (64 bf16 / 32 fp32).
@@ -22,7 +28,7 @@
 
 namespace adf {
 
-constexpr int kARows = 136;     // activation rows staged per tile (incl. halo)
+constexpr int kARows = 144;     // activation rows staged per tile (incl. halo / per-sample padding)
 constexpr int kTapGroup = 3;    // taps of weights staged per iteration
 
 struct GemmSeg {
@@ -41,6 +47,8 @@ struct GemmArgs {
     GemmSeg seg[2];
     int nseg;
     int B, lin, mrows, n, n_pad;
+    int flat;            // set by the launcher: tiles run over the flattened B*mrows rows
+    int seg_rows;        // set by the launcher: rows of one sample inside a tile (flat mode)
     const float* bias0;
     const float* bias1;
     int bias_mod;        // bias index = n % bias_mod
@@ -58,6 +66,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ int lds_swz(int row, int c16) { return row * kRowBytes + ((c16 ^ ((row >> 1) & 7)) << 4); }
 
+template <int TM, int TN>
+constexpr int gemm_lds_bytes() {
+    constexpr int main_b = kARows * kRowBytes + kTapGroup * TN * kRowBytes;
+    constexpr int epi_b = TM * TN * 4;
+    return main_b > epi_b ? main_b : epi_b;
+}
+
 template <typename T, int MT, int NT, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs a) {
     constexpr int TM = 32 * MT * WM, TN = 32 * NT * WN, NTHR = 64 * WM * WN;
@@ -74,12 +89,25 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (a.n_pad + TN - 1) / TN;
-    const int tiles_m = (a.mrows + TM - 1) / TM;
     int bid = blockIdx.x;
     const int tn_i = bid % tiles_n; bid /= tiles_n;
-    const int tm_i = bid % tiles_m;
-    const int b = bid / tiles_m;
-    const int m0 = tm_i * TM, n0 = tn_i * TN;
+    // per-sample mode: bid = b * tiles_m + tm_i ; flat mode: bid = tile over the flattened rows
+    const int seg = a.flat ? a.seg_rows : TM;   // rows of one sample inside the tile
+    const int nsegs = TM / seg;
+    int b0, m0;                                  // first sample of the tile, first row inside that sample
+    long long R0;                                // first flattened output row (b * mrows + m)
+    if (a.flat) {
+        R0 = (long long)bid * TM;
+        b0 = (int)(R0 / a.mrows);
+        m0 = 0;
+    } else {
+        const int tiles_m = (a.mrows + TM - 1) / TM;
+        const int tm_i = bid % tiles_m;
+        b0 = bid / tiles_m;
+        m0 = tm_i * TM;
+        R0 = (long long)b0 * a.mrows + m0;
+    }
+    const int n0 = tn_i * TN;
     const int c16 = tid & 7;  // this thread's 16-byte column within a 128-byte row (NTHR % 8 == 0)
 
     f32x16_t acc[MT][NT];
@@ -116,22 +144,25 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
             const char* src = (const char*)(from1 ? sg.src1 : sg.src0);
             const int csrc = from1 ? sg.c1 : sg.c0;
             const int cc = from1 ? cidx - sg.c0 : cidx;
-            const int nrows = (TM - 1) * sg.stride + sg.taps;
+            const int segrows = (seg - 1) * sg.stride + sg.taps;   // staged rows per sample segment
+            const int nrows = nsegs * segrows;
             const int p_lo = m0 * sg.stride + off_min;
             avalid = 0;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 const int row = (tid + i * NTHR) >> 3;
-                const int p = p_lo + row;
-                const bool ok = cvalid && row < nrows && p >= 0 && p < a.lin;
+                const int j = row / segrows;
+                const int p = p_lo + (row - j * segrows);
+                const int bb = b0 + j;
+                const bool ok = cvalid && row < nrows && p >= 0 && p < a.lin && bb < a.B;
                 ra[i] = make_uint4(0, 0, 0, 0);
                 if (ok) {
-                    ra[i] = *(const uint4*)(src + ((size_t)((size_t)b * a.lin + p) * csrc + cc) * sizeof(T));
+                    ra[i] = *(const uint4*)(src + ((size_t)((size_t)bb * a.lin + p) * csrc + cc) * sizeof(T));
                     avalid |= 1u << i;
                 }
             }
             if (sg.ab != nullptr && cvalid) {
-                const float* abp = sg.ab + ((size_t)b * ctot + cidx) * 2;
+                const float* abp = sg.ab + ((size_t)b0 * ctot + cidx) * 2;
 #pragma unroll
                 for (int e = 0; e < EPC; e += 2) {
                     const float4 q = *(const float4*)(abp + e * 2);
@@ -165,7 +196,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         const int ntg = s1 ? ntg1 : ntg0;
         const int tg = local % ntg;
         if (tg == 0) {
-            const int nrows = (TM - 1) * sg.stride + sg.taps;
+            const int nrows = nsegs * ((seg - 1) * sg.stride + sg.taps);
             const bool act = sg.act != 0;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
@@ -201,13 +232,21 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         const int ntg = s1 ? ntg1 : ntg0;
         const int tg = local % ntg;
         const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+        const int segrows = (seg - 1) * sg.stride + sg.taps;
         int ntap = sg.taps - tg * kTapGroup;
         ntap = ntap > kTapGroup ? kTapGroup : ntap;
+        int abase[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int ti = (wm * MT + i) * 32 + r;   // tile row
+            const int j = ti / seg;
+            abase[i] = j * segrows + (ti - j * seg) * sg.stride;
+        }
         for (int tap_l = 0; tap_l < ntap; ++tap_l) {
             const int aoff = sg.off0 + (tg * kTapGroup + tap_l) * sg.step - off_min;
             int arow[MT], wrow[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) arow[i] = ((wm * MT + i) * 32 + r) * sg.stride + aoff;
+            for (int i = 0; i < MT; ++i) arow[i] = abase[i] + aoff;
 #pragma unroll
             for (int j = 0; j < NT; ++j) wrow[j] = tap_l * TN + (wn * NT + j) * 32 + r;
             if constexpr (kBf16) {
@@ -266,55 +305,113 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         compute(it);
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------
-    T* out = (T*)a.out;
-    const T* res = (const T*)a.res;
-    const bool do_stats = a.stats != nullptr;
-    const int gs = do_stats ? a.out_c / a.stats_groups : 1;
+    // ---- epilogue phase 1: accumulators (+bias) -> LDS fp32 image [TM][TN] -----------------------
+    __syncthreads();
+    float* tile = (float*)smem;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int n = n0 + (wn * NT + j) * 32 + r;
-        const bool nok = n < a.n;
+        const int col = (wn * NT + j) * 32 + r;
+        const int n = n0 + col;
         float bias = 0.f;
-        if (nok) {
+        if (n < a.n) {
             const int bi = n % a.bias_mod;
             if (a.bias0) bias += a.bias0[bi];
             if (a.bias1) bias += a.bias1[bi];
         }
-        int co = n, phase = 0;
-        if (a.scatter_f) { phase = n / a.out_c; co = n - phase * a.out_c; }
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (nok && m < a.mrows) {
-                    float v = acc[i][j][e] + bias;
-                    if (a.scatter_f) {
-                        const int orow = m * a.scatter_f + phase - a.scatter_pad;
-                        if (orow >= 0 && orow < a.out_rows)
-                            Elem<T>::st(out + ((size_t)b * a.out_rows + orow) * a.out_c + co, v);
-                    } else {
-                        const size_t o = ((size_t)b * a.out_rows + m) * a.out_c + n;
-                        if (res) v += Elem<T>::ld(res + o);
-                        if (a.gelu) v = gelu_erf_f(v);
-                        Elem<T>::st(out + o, v);
-                        s1 += v; s2 += v * v;
-                    }
-                }
+                const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                tile[row * TN + col] = acc[i][j][e] + bias;
+            }
+    }
+    __syncthreads();
+
+    // ---- phase 2: 16-byte stores along the channel axis (+ residual / GELU / phase scatter) ------
+    T* out = (T*)a.out;
+    const T* res = (const T*)a.res;
+    const bool do_stats = a.stats != nullptr;
+    const long long rows_total = (long long)a.B * a.mrows;
+    constexpr int CPR = TN / EPC;   // 16-byte chunks per tile row
+    for (int idx = tid; idx < TM * CPR; idx += NTHR) {
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const int n = n0 + cc * EPC;
+        int bb, m;
+        bool ok;
+        if (a.flat) {
+            const long long R = R0 + row;
+            ok = R < rows_total;
+            bb = (int)(R / a.mrows);
+            m = (int)(R - (long long)bb * a.mrows);
+        } else {
+            bb = b0; m = m0 + row;
+            ok = m < a.mrows;
+        }
+        if (!(ok && n < a.n)) continue;
+        float v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+            const float4 q = *(const float4*)(tile + row * TN + cc * EPC + e);
+            v[e] = q.x; v[e + 1] = q.y; v[e + 2] = q.z; v[e + 3] = q.w;
+        }
+        if (a.scatter_f) {
+            const int phase = n / a.out_c, co = n - phase * a.out_c;
+            const int orow = m * a.scatter_f + phase - a.scatter_pad;
+            if (orow >= 0 && orow < a.out_rows)
+                *(uint4*)(out + ((size_t)bb * a.out_rows + orow) * a.out_c + co) = pack16<T>(v);
+        } else {
+            const size_t o = ((size_t)bb * a.out_rows + m) * a.out_c + n;
+            if (res) {
+                float rr[EPC];
+                unpack16<T>(*(const uint4*)(res + o), rr);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+            }
+            if (a.gelu) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
+            }
+            *(uint4*)(out + o) = pack16<T>(v);
+            if (do_stats && (res || a.gelu)) {
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4)
+                    *(float4*)(tile + row * TN + cc * EPC + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
             }
         }
-        if (do_stats) {
-            // lanes r..r+gs-1 (same 32-lane half) hold channels of one group; the two halves hold
-            // different rows of the same channels.
-            const int span = gs < 32 ? gs : 32;
-            for (int o = 1; o < span; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (h == 0 && (r & (span - 1)) == 0 && nok) {
-                double* sp = a.stats + ((size_t)b * a.stats_groups + n / gs) * 2;
-                atomicAdd(sp, (double)s1);
-                atomicAdd(sp + 1, (double)s2);
+    }
+
+    // ---- phase 3: GroupNorm statistics of the produced tile, column-wise from the LDS image ---------
+    if (do_stats) {
+        __syncthreads();
+        constexpr int PARTS = NTHR / TN;
+        constexpr int RPP = TM / PARTS;     // rows per part
+        const int col = tid % TN, part = tid / TN;
+        const int n = n0 + col;
+        const bool nok = n < a.n;
+        const int gs = a.out_c / a.stats_groups;
+        const int span = gs < 32 ? gs : 32;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < RPP; ++i) {
+            const int row = part * RPP + i;
+            bool ok;
+            if (a.flat) ok = (R0 + row) < rows_total;
+            else ok = (m0 + row) < a.mrows;
+            if (ok && nok) {
+                const float v = tile[row * TN + col];
+                s1 += v; s2 = fmaf(v, v, s2);
+            }
+            if (((row + 1) % seg) == 0 || i == RPP - 1) {   // wave-uniform (seg, RPP are powers of two)
+                for (int o = 1; o < span; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (nok && (col & (span - 1)) == 0) {
+                    const int bb = a.flat ? (int)((R0 + row) / a.mrows) : b0;
+                    if (bb < a.B) {
+                        double* sp = a.stats + ((size_t)bb * a.stats_groups + n / gs) * 2;
+                        atomicAdd(sp, (double)s1);
+                        atomicAdd(sp + 1, (double)s2);
+                    }
+                }
+                s1 = 0.f; s2 = 0.f;
             }
         }
     }

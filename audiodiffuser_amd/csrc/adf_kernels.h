@@ -21,6 +21,10 @@ struct GnFinalizeArgs {
 };
 const char* launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
 
+// out[b][l][c0+c1] = act(a*x + b) of the concatenated input [src0 ; src1] (affine from launch_gn_finalize).
+const char* launch_gn_apply(const void* s0, const void* s1, int c0, int c1, int L, int B, const float* ab, int act, void* out,
+                            int bf16, hipStream_t s);
+
 // Row LayerNorm over the channel (last) dim of an NLC tensor; beta may be null (gain only).
 const char* launch_ln_rows(const void* x, void* y, int bf16, long long rows, int C, const float* gamma,
                            const float* beta, float eps, hipStream_t s);

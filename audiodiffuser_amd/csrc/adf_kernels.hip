@@ -118,6 +118,42 @@ const char* launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
     return ADF_LAUNCH_CHECK("gn_finalize");
 }
 
+// Materialise silu(a*x + b) of a (possibly concatenated) input as one NLC tensor.  Used for the short
+// (L <= 64) levels, where the GEMM runs on flat multi-sample tiles that take raw inputs only.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ s0, const T* __restrict__ s1, int c0, int c1, int L,
+                                                       const float* __restrict__ ab, int act, T* __restrict__ out) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    const int b = blockIdx.y;
+    const int ctot = c0 + c1, cpr = ctot / EPC;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)L * cpr) return;
+    const int cc = (int)(idx % cpr);
+    const int l = (int)(idx / cpr);
+    const int c = cc * EPC;
+    const T* src = c < c0 ? s0 + ((size_t)b * L + l) * c0 + c : s1 + ((size_t)b * L + l) * c1 + (c - c0);
+    float f[EPC];
+    unpack16<T>(*(const uint4*)src, f);
+    const float* abp = ab + ((size_t)b * ctot + c) * 2;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const float v = fmaf(f[e], abp[2 * e], abp[2 * e + 1]);
+        f[e] = act ? silu_f(v) : v;
+    }
+    *(uint4*)(out + ((size_t)b * L + l) * ctot + c) = pack16<T>(f);
+}
+
+const char* launch_gn_apply(const void* s0, const void* s1, int c0, int c1, int L, int B, const float* ab, int act, void* out,
+                            int bf16, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (c0 % epc || c1 % epc) return "gn_apply: channel counts must be multiples of a 16-byte chunk";
+    const long long work = (long long)L * ((c0 + c1) / epc);
+    dim3 grid((unsigned)((work + 255) / 256), B);
+    if (bf16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)s0, (const bf16_t*)s1, c0, c1, L, ab, act, (bf16_t*)out);
+    else hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)s0, (const float*)s1, c0, c1, L, ab, act, (float*)out);
+    return ADF_LAUNCH_CHECK("gn_apply");
+}
+
 // =====================================================================================================
 // Row LayerNorm (nn.LayerNorm in TransformerBlock1d unet1d.py:80,111; LayerNorm1d :31-43 in NLC)
 // =====================================================================================================

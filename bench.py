@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio samples / second for full EDM sampler runs on MI355X.
+
+A "step" is ONE complete sampler run (KarrasSchedule N=50, Heun, 99 denoiser evaluations) over one
+batch of synthetic noise that is already resident in HBM: BASELINE.json configs[1]
+(UNet1d 64 ch, 16384-sample waveforms, batch 64 per GPU, bf16 storage / fp32 accumulate).
+With N > 1 GPUs the batch is sharded (64 waveforms per rank, weak scaling) and the only exchange
+is one all-gather of the finished waveforms (audiodiffuser_amd/distributed.py).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement); extra objects:
+  roofline     -- the dominant kernel (fused resblock implicit-GEMM): algorithmic bytes / flops per launch
+                  (SURVEY.md 8d definition) over its HIP-event-timed launch duration
+  cpu_baseline -- the CPU oracle (a port of the reference PyTorch path) timed on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "tiny"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64, help="waveforms per GPU")
+    ap.add_argument("--length", type=int, default=16384)
+    ap.add_argument("--num-steps", type=int, default=50, help="sigma schedule length N (Heun => 2N-1 NFE)")
+    ap.add_argument("--sampler", default="heun", choices=["heun", "dpm"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-iters", type=int, default=50)
+    ap.add_argument("--roofline-only", action="store_true", help="only replay the dominant kernel (for rocprofv3)")
+    return ap.parse_args()
+
+
+def roofline(net, hd, batch, length, dtype, iters, device):
+    """Replay each recorded resblock kernel pair with HIP events on the launch stream and report the
+    one that dominates the NFE (largest total time)."""
+    lib = hd.lib
+    stream = torch.cuda.current_stream(device).cuda_stream
+    best, total_ms, rows = None, 0.0, []
+    idx = 0
+    while True:
+        ms1, ms2 = C.c_float(), C.c_float()
+        b1, b2, f1, f2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        rc = lib.adf_bench_resblock(hd.h, batch, length, idx, iters, C.byref(ms1), C.byref(ms2), C.byref(b1), C.byref(b2),
+                                    C.byref(f1), C.byref(f2), C.c_void_p(stream))
+        if rc != 0:
+            break
+        for k, (ms, by, fl) in enumerate(((ms1.value, b1.value, f1.value), (ms2.value, b2.value, f2.value))):
+            rows.append({"resblock": idx, "kernel": k + 1, "ms": ms, "bytes": by, "flops": fl})
+            total_ms += ms
+        idx += 1
+    if not rows:
+        return None
+    dom = max(rows, key=lambda r: r["ms"])
+    ai = dom["flops"] / dom["bytes"]
+    ridge = MFMA_PEAK_TFLOPS[dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+    gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    tfs = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    all_bytes = sum(r["bytes"] for r in rows)
+    all_flops = sum(r["flops"] for r in rows)
+    out = {
+        "bound": "hbm" if ai < ridge else "mfma",
+        "kernel": f"conv_gemm (resblock {dom['resblock']} conv{dom['kernel']})",
+        "ms_per_launch": dom["ms"],
+        "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"],
+        "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+        "mfma_TFLOPs": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS[dtype],
+        "all_resblocks": {"ms": total_ms, "hbm_GBps": all_bytes / (total_ms * 1e-3) / 1e9,
+                          "hbm_frac": all_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "mfma_TFLOPs": all_flops / (total_ms * 1e-3) / 1e12},
+        "traffic": None,
+    }
+    if os.environ.get("ADF_BENCH_VERBOSE"):
+        out["rows"] = rows
+    if out["bound"] == "hbm":
+        out.update({"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    else:
+        out.update({"achieved": tfs, "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS[dtype]})
+    return out
+
+
+def cpu_baseline(cfg, length, nfe_per_waveform):
+    """Time the CPU oracle (port of the reference PyTorch path) on a bounded sample of the same workload."""
+    from audiodiffuser_amd.weights import generate_weights, generate_noise
+    from oracle import edm as E
+    w = generate_weights(cfg, seed=0)
+    fn = E.make_denoiser(w, cfg, 0.2)
+    b = 2
+    x = generate_noise(0, b, length) * 3.0
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        fn(x, sigma=torch.tensor(3.0))           # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 20):
+            fn(x, sigma=torch.tensor(3.0 / (n + 1)))
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+    wps = b / (dt * nfe_per_waveform)
+    return {"value": wps * length, "unit": "audio-samples/s", "waveforms_per_s": wps, "cores": cores, "kind": "port",
+            "sample": f"oracle denoiser on the same net, batch {b}, {n} NFEs timed ({dt:.3f} s/NFE), scaled to {nfe_per_waveform} NFE per waveform"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"# note: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import audiodiffuser_amd as A
+    from audiodiffuser_amd.weights import generate_weights
+    from audiodiffuser_amd.distributed import rank_noise, gather_samples
+
+    cfg = A.PRESETS[a.config]()
+    net = A.UNet1dBase.from_config(cfg, compute_dtype=a.dtype)
+    net.load_state_dict(generate_weights(cfg, seed=0))     # every rank regenerates the same weights
+    net = net.to(device)
+    diff = A.EluDiffusion(sigma_data=0.2)
+    sigmas = A.KarrasSchedule(0.002, 80.0, 7.0, a.num_steps)()
+    if a.sampler == "heun":
+        sampler = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=a.num_steps, use_heun=True, use_graph=not a.no_graph)
+        nfe = 2 * a.num_steps - 1
+    else:
+        sampler = A.DPMSampler(1.0, order=3, num_steps=a.num_steps, multisteps=True, x0_pred=True, log_time_spacing=False,
+                               use_graph=not a.no_graph)
+        nfe = a.num_steps - 1
+    global_batch = a.batch * world
+    noise = rank_noise(global_batch, a.length, rank, world).to(device)
+
+    def step():
+        y = sampler(noise, fn=diff.denoise_fn, net=net, sigmas=sigmas)
+        return gather_samples(y, global_batch)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    hd = net.native(device)
+    if a.roofline_only:
+        net(noise[:a.batch], torch.zeros(a.batch, device=device))
+        r = roofline(net, hd, a.batch, a.length, a.dtype, max(a.roofline_iters, 200), device)
+        print(json.dumps({"roofline": r}))
+        return
+
+    for _ in range(a.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max()) <= 1.0 + 1e-6 if a.sampler == "heun" else True
+    waveforms = global_batch * a.steps
+    value = waveforms * a.length / dt
+    res = {
+        "metric": "audio samples/sec (16384-sample waveform, 50-step Heun)", "value": value, "unit": "audio-samples/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "waveforms_per_s": waveforms / dt, "nfe_per_waveform": nfe, "finite_and_clamped": ok,
+        "config": {"workload": f"BASELINE configs[1]: UNet1d {cfg.channels} ch ({a.config}), {a.length}-sample waveforms, "
+                               f"KarrasSchedule N={a.num_steps} {a.sampler}, batch {a.batch}/GPU, random-init weights",
+                   "global_batch": global_batch, "sampler": a.sampler, "num_steps": a.num_steps, "nfe": nfe,
+                   "hipgraph": not a.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
+    }
+    if rank == 0:
+        res["roofline"] = roofline(net, hd, a.batch, a.length, a.dtype, a.roofline_iters, device)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, a.length, nfe)
+            res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
