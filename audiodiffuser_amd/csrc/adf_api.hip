@@ -129,7 +129,8 @@ struct Registrar {
             w.taps = transposed ? 2 : K;
             w.n = n_total; w.n_pad = round_up(n_total, 32);
             w.nchunk = ceil_div(cin, h->kc);
-            w.w = dalloc(h, (size_t)w.nchunk * w.taps * w.n_pad * kRowBytes);
+            // + kTapGroup slabs of 128 rows: the kernel's weight staging loads are unguarded (adf_gemm.h)
+            w.w = dalloc(h, ((size_t)w.nchunk * w.taps * w.n_pad + (size_t)kTapGroup * (w.n_pad + 128)) * kRowBytes);
             if (!w.w) { ok = false; return; }
         }
         w.cout = cout;

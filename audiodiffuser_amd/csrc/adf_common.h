@@ -10,6 +10,8 @@ namespace adf {
 // Activations / GEMM weights are stored either as fp32 ("parity" mode) or bf16 ("throughput"
 // mode); all accumulation, norms, softmax and sampler state are fp32 (stats in fp64).
 struct bf16_t { uint16_t v; };
+// native 16-byte vector (HIP's uint4 struct defeats SROA in unrolled staging arrays -> scratch)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
@@ -32,19 +34,19 @@ template <> struct Elem<bf16_t> {
 };
 
 // unpack one 16-byte chunk into floats / pack floats into a chunk
-template <typename T> __device__ __forceinline__ void unpack16(const uint4& q, float* f);
-template <> __device__ __forceinline__ void unpack16<float>(const uint4& q, float* f) {
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& q, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& q, float* f) {
     f[0] = __uint_as_float(q.x); f[1] = __uint_as_float(q.y); f[2] = __uint_as_float(q.z); f[3] = __uint_as_float(q.w);
 }
-template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& q, float* f) {
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& q, float* f) {
     f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
     f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
     f[4] = __uint_as_float(q.z << 16); f[5] = __uint_as_float(q.z & 0xffff0000u);
     f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
 }
-template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
-template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
-    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* f);
+template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {
+    return u32x4_t{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
 // two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN kept)
 typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
@@ -53,8 +55,8 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     f32x2_hw_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
-template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
-    uint4 q;
+template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
+    u32x4_t q;
     q.x = pack_bf16x2(f[0], f[1]);
     q.y = pack_bf16x2(f[2], f[3]);
     q.z = pack_bf16x2(f[4], f[5]);

@@ -59,10 +59,16 @@ struct GemmArgs {
     int scatter_f, scatter_pad;  // transposed conv: n = phase*out_c + co -> row m*f + phase - pad
     double* stats;       // optional [B][stats_groups][2] (sum, sumsq) of the produced tensor
     int stats_groups;
+    int dbg;             // timing experiments only (ADF_GEMM_DBG): 1 skip stores, 2 skip prologue math, 4 skip MFMA, 8 skip stats
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// Staging loads are UNCONDITIONAL: lanes with nothing to load read offset 0 of the same (global) buffer and
+// the value is discarded / zeroed afterwards.  A branch around a load makes hipcc serialise the loads behind
+// vmcnt(0) waits, and a select between pointers of different address spaces turns them into flat loads.
 
 __device__ __forceinline__ int lds_swz(int row, int c16) { return row * kRowBytes + ((c16 ^ ((row >> 1) & 7)) << 4); }
 
@@ -123,27 +129,33 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     const int ntg1 = a.nseg > 1 ? (a.seg[1].taps + kTapGroup - 1) / kTapGroup : 1;
     const int nit = nit0 + (a.nseg > 1 ? a.seg[1].nchunk * ntg1 : 0);
 
-    uint4 ra[A_CH];
-    uint4 rw[W_CH];
-    float fa[EPC], fb[EPC];
+    u32x4_t ra[A_CH];
+    u32x4_t rw[W_CH];
+    f32x4_t abq[EPC / 2];    // (a, b) pairs of this thread's EPC channels, as loaded
+    float raw_scale = 1.0f;
     unsigned avalid = 0;
 
     // ---- staging: global -> registers ---------------------------------------------------
+    // All offsets are 32-bit (every tensor / packed weight is < 4 GB, checked by the launcher) and every
+    // load is unconditional: a lane with nothing to load re-reads offset 0 and the value is dropped.
+    // Weight buffers are over-allocated by kTapGroup tap slabs, so the weight loads need no guard at all.
+    // weight slab row of this thread for i = 0: the others are a compile-time number of rows further on
+    const int wrow0 = tid >> 3;                           // tap_l * TN + n_l for i = 0 (NTHR/8 rows per step)
     auto load_regs = [&](int it) {
         const bool s1 = it >= nit0;
         const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
         const int local = s1 ? it - nit0 : it;
         const int ntg = s1 ? ntg1 : ntg0;
         const int chunk = local / ntg, tg = local - chunk * ntg;
-        const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
         if (tg == 0) {
+            const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
             const int ctot = sg.c0 + sg.c1;
             const int cidx = chunk * KC + c16 * EPC;
             const bool cvalid = cidx < ctot;
-            const bool from1 = cidx >= sg.c0;
+            const bool from1 = sg.c1 > 0 && cidx >= sg.c0;   // K-padding lanes of a single-source segment stay on src0
             const char* src = (const char*)(from1 ? sg.src1 : sg.src0);
-            const int csrc = from1 ? sg.c1 : sg.c0;
-            const int cc = from1 ? cidx - sg.c0 : cidx;
+            const unsigned rowbytes = (unsigned)(from1 ? sg.c1 : sg.c0) * (unsigned)sizeof(T);
+            const unsigned colbytes = (unsigned)(from1 ? cidx - sg.c0 : cidx) * (unsigned)sizeof(T);
             const int segrows = (seg - 1) * sg.stride + sg.taps;   // staged rows per sample segment
             const int nrows = nsegs * segrows;
             const int p_lo = m0 * sg.stride + off_min;
@@ -151,40 +163,28 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 const int row = (tid + i * NTHR) >> 3;
-                const int j = row / segrows;
+                const int j = a.flat ? row / segrows : 0;
                 const int p = p_lo + (row - j * segrows);
                 const int bb = b0 + j;
                 const bool ok = cvalid && row < nrows && p >= 0 && p < a.lin && bb < a.B;
-                ra[i] = make_uint4(0, 0, 0, 0);
-                if (ok) {
-                    ra[i] = *(const uint4*)(src + ((size_t)((size_t)bb * a.lin + p) * csrc + cc) * sizeof(T));
-                    avalid |= 1u << i;
-                }
+                const unsigned off = ok ? (unsigned)(bb * a.lin + p) * rowbytes + colbytes : 0u;
+                ra[i] = *(const u32x4_t*)(src + off);
+                avalid |= (ok ? 1u : 0u) << i;
             }
-            if (sg.ab != nullptr && cvalid) {
-                const float* abp = sg.ab + ((size_t)b0 * ctot + cidx) * 2;
+            // affine table (or, for raw inputs, any valid global address: the values are then ignored in
+            // store_lds).  No branch and no use of the loaded values here, so nothing waits on these loads.
+            const float* abp = sg.ab ? sg.ab + (cvalid ? (unsigned)(b0 * ctot + cidx) * 2u : 0u) : (const float*)sg.w;
 #pragma unroll
-                for (int e = 0; e < EPC; e += 2) {
-                    const float4 q = *(const float4*)(abp + e * 2);
-                    fa[e] = q.x; fb[e] = q.y; fa[e + 1] = q.z; fb[e + 1] = q.w;
-                }
-            } else {
-                const float s = from1 ? sg.scale1 : 1.0f;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) { fa[e] = s; fb[e] = 0.f; }
-            }
+            for (int e = 0; e < EPC / 2; ++e) abq[e] = *(const f32x4_t*)(abp + e * 4);
+            raw_scale = from1 ? sg.scale1 : 1.0f;
         }
-        const int tleft = sg.taps - tg * kTapGroup;  // taps in this group (may exceed kTapGroup)
+        const char* wp = (const char*)sg.w + (size_t)(chunk * sg.taps + tg * kTapGroup) * a.n_pad * kRowBytes;
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) {
-            const int row = (tid + i * NTHR) >> 3;
-            const int tap_l = row / TN, n_l = row - tap_l * TN;
-            const bool ok = tap_l < kTapGroup && tap_l < tleft && (n0 + n_l) < a.n_pad;
-            rw[i] = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const size_t wrow = ((size_t)chunk * sg.taps + (tg * kTapGroup + tap_l)) * a.n_pad + (n0 + n_l);
-                rw[i] = *(const uint4*)((const char*)sg.w + wrow * kRowBytes + c16 * 16);
-            }
+            const int row = wrow0 + i * (NTHR / 8);
+            const int tap_l = row / TN, n_l = row - tap_l * TN;     // TN is a power of two: shifts
+            const unsigned woff = (unsigned)((tap_l * a.n_pad + n0 + n_l) * kRowBytes + c16 * 16);
+            rw[i] = *(const u32x4_t*)(wp + woff);
         }
     };
 
@@ -198,29 +198,36 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         if (tg == 0) {
             const int nrows = nsegs * ((seg - 1) * sg.stride + sg.taps);
             const bool act = sg.act != 0;
+            const bool use_ab = sg.ab != nullptr;
+            float fa[EPC], fb[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC / 2; ++e) {
+                fa[2 * e] = use_ab ? abq[e].x : raw_scale; fb[2 * e] = use_ab ? abq[e].y : 0.f;
+                fa[2 * e + 1] = use_ab ? abq[e].z : raw_scale; fb[2 * e + 1] = use_ab ? abq[e].w : 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 const int row = (tid + i * NTHR) >> 3;
                 if (row < nrows) {
-                    uint4 q = make_uint4(0, 0, 0, 0);
+                    u32x4_t q = u32x4_t{0u, 0u, 0u, 0u};
                     if ((avalid >> i) & 1u) {
                         float f[EPC];
                         unpack16<T>(ra[i], f);
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
                             float v = fmaf(f[e], fa[e], fb[e]);
-                            f[e] = act ? silu_f(v) : v;
+                            f[e] = (act && !(a.dbg & 2)) ? silu_f(v) : v;
                         }
                         q = pack16<T>(f);
                     }
-                    *(uint4*)(ldsA + lds_swz(row, c16)) = q;
+                    *(u32x4_t*)(ldsA + lds_swz(row, c16)) = q;
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) {
             const int row = (tid + i * NTHR) >> 3;
-            if (row < kTapGroup * TN) *(uint4*)(ldsW + lds_swz(row, c16)) = rw[i];
+            if (row < kTapGroup * TN) *(u32x4_t*)(ldsW + lds_swz(row, c16)) = rw[i];
         }
     };
 
@@ -239,9 +246,10 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int ti = (wm * MT + i) * 32 + r;   // tile row
-            const int j = ti / seg;
+            const int j = a.flat ? ti / seg : 0;
             abase[i] = j * segrows + (ti - j * seg) * sg.stride;
         }
+        if (a.dbg & 4) ntap = 0;
         for (int tap_l = 0; tap_l < ntap; ++tap_l) {
             const int aoff = sg.off0 + (tg * kTapGroup + tap_l) * sg.step - off_min;
             int arow[MT], wrow[NT];
@@ -334,45 +342,65 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     const bool do_stats = a.stats != nullptr;
     const long long rows_total = (long long)a.B * a.mrows;
     constexpr int CPR = TN / EPC;   // 16-byte chunks per tile row
-    for (int idx = tid; idx < TM * CPR; idx += NTHR) {
-        const int row = idx / CPR, cc = idx - row * CPR;
-        const int n = n0 + cc * EPC;
-        int bb, m;
-        bool ok;
-        if (a.flat) {
-            const long long R = R0 + row;
-            ok = R < rows_total;
-            bb = (int)(R / a.mrows);
-            m = (int)(R - (long long)bb * a.mrows);
-        } else {
-            bb = b0; m = m0 + row;
-            ok = m < a.mrows;
-        }
-        if (!(ok && n < a.n)) continue;
-        float v[EPC];
+    constexpr int P2 = (TM * CPR) / NTHR;   // chunks per thread (exact: TM*CPR is a multiple of NTHR)
+    static_assert((TM * CPR) % NTHR == 0, "tile chunks must divide evenly over the block");
+    if (!(a.dbg & 1)) {
+        unsigned off[P2];
+        bool okv[P2];
+        u32x4_t rres[P2];
 #pragma unroll
-        for (int e = 0; e < EPC; e += 4) {
-            const float4 q = *(const float4*)(tile + row * TN + cc * EPC + e);
-            v[e] = q.x; v[e + 1] = q.y; v[e + 2] = q.z; v[e + 3] = q.w;
-        }
-        if (a.scatter_f) {
-            const int phase = n / a.out_c, co = n - phase * a.out_c;
-            const int orow = m * a.scatter_f + phase - a.scatter_pad;
-            if (orow >= 0 && orow < a.out_rows)
-                *(uint4*)(out + ((size_t)bb * a.out_rows + orow) * a.out_c + co) = pack16<T>(v);
-        } else {
-            const size_t o = ((size_t)bb * a.out_rows + m) * a.out_c + n;
-            if (res) {
-                float rr[EPC];
-                unpack16<T>(*(const uint4*)(res + o), rr);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+        for (int k = 0; k < P2; ++k) {
+            const int idx = tid + k * NTHR;
+            const int row = idx / CPR, cc = idx - row * CPR;
+            const int n = n0 + cc * EPC;
+            int bb, m;
+            bool ok;
+            if (a.flat) {
+                const long long R = R0 + row;
+                ok = R < rows_total;
+                bb = (int)(R / a.mrows);
+                m = (int)(R - (long long)bb * a.mrows);
+            } else {
+                bb = b0; m = m0 + row;
+                ok = m < a.mrows;
             }
+            ok = ok && n < a.n;
+            if (a.scatter_f) {
+                const int phase = n / a.out_c, co = n - phase * a.out_c;
+                const int orow = m * a.scatter_f + phase - a.scatter_pad;
+                ok = ok && orow >= 0 && orow < a.out_rows;
+                off[k] = (unsigned)((bb * a.out_rows + orow) * a.out_c + co);
+            } else {
+                off[k] = (unsigned)((bb * a.out_rows + m) * a.out_c + n);
+            }
+            okv[k] = ok;
+            if (!ok) off[k] = 0;
+        }
+        if (res) {   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < P2; ++k) rres[k] = *(const u32x4_t*)(res + off[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < P2; ++k) rres[k] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < P2; ++k) {
+            const int idx = tid + k * NTHR;
+            const int row = idx / CPR, cc = idx - row * CPR;
+            float v[EPC], rr[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+                const float4 q = *(const float4*)(tile + row * TN + cc * EPC + e);
+                v[e] = q.x; v[e + 1] = q.y; v[e + 2] = q.z; v[e + 3] = q.w;
+            }
+            unpack16<T>(rres[k], rr);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] += rr[e];
             if (a.gelu) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
             }
-            *(uint4*)(out + o) = pack16<T>(v);
+            if (okv[k]) *(u32x4_t*)(out + off[k]) = pack16<T>(v);
             if (do_stats && (res || a.gelu)) {
 #pragma unroll
                 for (int e = 0; e < EPC; e += 4)
@@ -382,7 +410,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     }
 
     // ---- phase 3: GroupNorm statistics of the produced tile, column-wise from the LDS image ---------
-    if (do_stats) {
+    if (do_stats && !(a.dbg & 8)) {
         __syncthreads();
         constexpr int PARTS = NTHR / TN;
         constexpr int RPP = TM / PARTS;     // rows per part

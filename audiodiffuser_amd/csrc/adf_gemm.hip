@@ -1,5 +1,6 @@
 // Tile-shape dispatch for the fused implicit-GEMM kernel (see adf_gemm.h).
 #include "adf_gemm.h"
+#include <cstdlib>
 
 namespace adf {
 
@@ -41,10 +42,13 @@ const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
 
 const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t stream) {
     GemmArgs a = a_in;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ADF_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     if (a.nseg < 1 || a.nseg > 2) return "conv_gemm: nseg must be 1 or 2";
     if (a.n_pad % 32) return "conv_gemm: n_pad must be a multiple of 32";
     const int epc = dtype_bf16 ? 8 : 4;
     if (a.n % epc || a.out_c % epc) return "conv_gemm: output channels must be a multiple of a 16-byte chunk";
+    const long long esz = dtype_bf16 ? 2 : 4;
+    if ((long long)a.B * a.out_rows * a.out_c * esz >= (1LL << 32)) return "conv_gemm: output tensor must be < 4 GiB";
     bool raw = true;
     for (int s = 0; s < a.nseg; ++s) {
         const GemmSeg& g = a.seg[s];
@@ -52,6 +56,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         if (g.step != 1 && g.step != -1) return "conv_gemm: step must be +-1";
         if (g.taps < 1 || g.stride < 1) return "conv_gemm: bad taps/stride";
         if (g.ab) raw = false;
+        if ((long long)a.B * a.lin * (g.c0 > g.c1 ? g.c0 : g.c1) * esz >= (1LL << 32)) return "conv_gemm: input tensor must be < 4 GiB";
     }
     if (a.stats) {
         if (a.scatter_f) return "conv_gemm: fused stats unsupported with phase scatter";

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
     for (int e = 0; e < EPC; ++e) { s[e] = 0.f; q[e] = 0.f; }
     const T* base = x + (size_t)b * L * C + (size_t)cc * EPC;
     for (int r = r0 + rsub; r < r1; r += rstep) {
-        const uint4 v = *(const uint4*)(base + (size_t)r * C);
+        const u32x4_t v = *(const u32x4_t*)(base + (size_t)r * C);
         float f[EPC];
         unpack16<T>(v, f);
 #pragma unroll
@@ -133,14 +133,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ s0,
     const int c = cc * EPC;
     const T* src = c < c0 ? s0 + ((size_t)b * L + l) * c0 + c : s1 + ((size_t)b * L + l) * c1 + (c - c0);
     float f[EPC];
-    unpack16<T>(*(const uint4*)src, f);
+    unpack16<T>(*(const u32x4_t*)src, f);
     const float* abp = ab + ((size_t)b * ctot + c) * 2;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const float v = fmaf(f[e], abp[2 * e], abp[2 * e + 1]);
         f[e] = act ? silu_f(v) : v;
     }
-    *(uint4*)(out + ((size_t)b * L + l) * ctot + c) = pack16<T>(f);
+    *(u32x4_t*)(out + ((size_t)b * L + l) * ctot + c) = pack16<T>(f);
 }
 
 const char* launch_gn_apply(const void* s0, const void* s1, int c0, int c1, int L, int B, const float* ab, int act, void* out,
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const T* __restrict__ x, T
     for (int k = 0; k < MAXCH; ++k) {
         const int cc = lane + k * 64;
         if (cc < cpr) {
-            const uint4 v = *(const uint4*)(x + row * C + (size_t)cc * EPC);
+            const u32x4_t v = *(const u32x4_t*)(x + row * C + (size_t)cc * EPC);
             unpack16<T>(v, f[k]);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) sum += f[k][e];
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const T* __restrict__ x, T
                 if (beta) v += beta[c];
                 o[e] = v;
             }
-            *(uint4*)(y + row * C + (size_t)cc * EPC) = pack16<T>(o);
+            *(u32x4_t*)(y + row * C + (size_t)cc * EPC) = pack16<T>(o);
         }
     }
 }
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
     float q[DH], o[DH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        const uint4 v = *(const uint4*)(base + (size_t)qi * rowstride + k * EPC);
+        const u32x4_t v = *(const u32x4_t*)(base + (size_t)qi * rowstride + k * EPC);
         unpack16<T>(v, q + k * EPC);
     }
 #pragma unroll
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             float kf[EPC];
-            unpack16<T>(*(const uint4*)(kr + k * EPC), kf);
+            unpack16<T>(*(const u32x4_t*)(kr + k * EPC), kf);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) sdot = fmaf(q[k * EPC + e], kf[e], sdot);
         }
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             float vf[EPC];
-            unpack16<T>(*(const uint4*)(vr + k * EPC), vf);
+            unpack16<T>(*(const u32x4_t*)(vr + k * EPC), vf);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o[k * EPC + e] = fmaf(o[k * EPC + e], alpha, p * vf[e]);
         }
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
         float t[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) t[e] = o[k * EPC + e] * inv;
-        *(uint4*)(orow + k * EPC) = pack16<T>(t);
+        *(u32x4_t*)(orow + k * EPC) = pack16<T>(t);
     }
 }
 
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256) to_in_kernel(const float* __restrict__ x,
             for (int e = 0; e < EPC; ++e) acc[e] = fmaf(wr[e], xv, acc[e]);
         }
     }
-    *(uint4*)(out + ((size_t)b * Lo + m) * nf + (size_t)cc * EPC) = pack16<T>(acc);
+    *(u32x4_t*)(out + ((size_t)b * Lo + m) * nf + (size_t)cc * EPC) = pack16<T>(acc);
 }
 
 const char* launch_to_in(const float* x, const float* w, void* out, int bf16, int B, int in_ch, int L, int nf,
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) to_out_kernel(const T* __restrict__ h, co
             const T* row = h + ((size_t)b * Lh + i) * nf;
             for (int c = 0; c < nf; c += EPC) {
                 float f[EPC];
-                unpack16<T>(*(const uint4*)(row + c), f);
+                unpack16<T>(*(const u32x4_t*)(row + c), f);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float* wr = ws + (c + e) * wl;
