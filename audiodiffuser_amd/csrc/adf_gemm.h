@@ -21,8 +21,9 @@
 //
 // MFMA: 32x32x16 bf16 (throughput mode) or 32x32x2 f32 (parity mode, exact fp32 FMA chain); a wave
 // owns an (MT*32) x (NT*32) accumulator tile; K is walked in 128-byte rows (64 bf16 / 32 fp32).
-// LDS rows are 128 B, 16-byte chunks XOR-swizzled by (row>>1)&7, which makes the ds_read_b128
-// fragment reads (lane = row) conflict-free on gfx950's 64-bank LDS.
+// LDS rows hold 128 B of K padded to a 144-byte pitch: with that pitch the ds_read_b128 fragment reads
+// (lane = row, 16 lanes per LDS cycle) hit 16 distinct 4-bank slots, i.e. they are conflict-free on gfx950's
+// 64-bank LDS, and every fragment / staging address is "per-thread base + compile-time immediate".
 #pragma once
 #include "adf_common.h"
 
@@ -65,16 +66,18 @@ struct GemmArgs {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 // Staging loads are UNCONDITIONAL: lanes with nothing to load read offset 0 of the same (global) buffer and
 // the value is discarded / zeroed afterwards.  A branch around a load makes hipcc serialise the loads behind
 // vmcnt(0) waits, and a select between pointers of different address spaces turns them into flat loads.
 
-__device__ __forceinline__ int lds_swz(int row, int c16) { return row * kRowBytes + ((c16 ^ ((row >> 1) & 7)) << 4); }
+constexpr int kLdsPitch = 144;   // bytes between LDS rows (128 B of K + 16 B pad)
+__device__ __forceinline__ int lds_swz(int row, int c16) { return row * kLdsPitch + (c16 << 4); }
 
 template <int TM, int TN>
 constexpr int gemm_lds_bytes() {
-    constexpr int main_b = kARows * kRowBytes + kTapGroup * TN * kRowBytes;
+    constexpr int main_b = kARows * kLdsPitch + kTapGroup * TN * kLdsPitch;
     constexpr int epi_b = TM * TN * 4;
     return main_b > epi_b ? main_b : epi_b;
 }
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     constexpr bool kBf16 = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsA = smem;
-    char* ldsW = smem + kARows * kRowBytes;
+    char* ldsW = smem + kARows * kLdsPitch;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -141,14 +144,30 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     // Weight buffers are over-allocated by kTapGroup tap slabs, so the weight loads need no guard at all.
     // weight slab row of this thread for i = 0: the others are a compile-time number of rows further on
     const int wrow0 = tid >> 3;                           // tap_l * TN + n_l for i = 0 (NTHR/8 rows per step)
+    int arow_idx[A_CH];          // flattened input row (bb*lin + p) of each staged chunk, or -1
+    auto setup_segment = [&](const GemmSeg& sg) {
+        const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+        const int segrows = (seg - 1) * sg.stride + sg.taps;   // staged rows per sample segment
+        const int nrows = nsegs * segrows;
+        const int p_lo = m0 * sg.stride + off_min;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int row = (tid + i * NTHR) >> 3;
+            const int j = a.flat ? row / segrows : 0;
+            const int p = p_lo + (row - j * segrows);
+            const int bb = b0 + j;
+            const bool ok = row < nrows && p >= 0 && p < a.lin && bb < a.B;
+            arow_idx[i] = ok ? bb * a.lin + p : -1;
+        }
+    };
     auto load_regs = [&](int it) {
         const bool s1 = it >= nit0;
         const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
         const int local = s1 ? it - nit0 : it;
         const int ntg = s1 ? ntg1 : ntg0;
         const int chunk = local / ntg, tg = local - chunk * ntg;
+        if (local == 0) setup_segment(sg);
         if (tg == 0) {
-            const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
             const int ctot = sg.c0 + sg.c1;
             const int cidx = chunk * KC + c16 * EPC;
             const bool cvalid = cidx < ctot;
@@ -156,18 +175,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
             const char* src = (const char*)(from1 ? sg.src1 : sg.src0);
             const unsigned rowbytes = (unsigned)(from1 ? sg.c1 : sg.c0) * (unsigned)sizeof(T);
             const unsigned colbytes = (unsigned)(from1 ? cidx - sg.c0 : cidx) * (unsigned)sizeof(T);
-            const int segrows = (seg - 1) * sg.stride + sg.taps;   // staged rows per sample segment
-            const int nrows = nsegs * segrows;
-            const int p_lo = m0 * sg.stride + off_min;
             avalid = 0;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                const int row = (tid + i * NTHR) >> 3;
-                const int j = a.flat ? row / segrows : 0;
-                const int p = p_lo + (row - j * segrows);
-                const int bb = b0 + j;
-                const bool ok = cvalid && row < nrows && p >= 0 && p < a.lin && bb < a.B;
-                const unsigned off = ok ? (unsigned)(bb * a.lin + p) * rowbytes + colbytes : 0u;
+                const bool ok = cvalid && arow_idx[i] >= 0;
+                const unsigned off = ok ? (unsigned)arow_idx[i] * rowbytes + colbytes : 0u;
                 ra[i] = *(const u32x4_t*)(src + off);
                 avalid |= (ok ? 1u : 0u) << i;
             }
@@ -189,6 +201,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     };
 
     // ---- staging: registers -> (fused prologue) -> LDS -------------------------------------
+    // SiLU(v) = v / (1 + 2^(-log2e * v)), v = a*x + b: the exp2 argument is a second affine of x, so the
+    // per-element cost is 2 packed FMAs + exp2 + packed add + rcp + packed mul.
+    const int lds_row0 = tid >> 3;
     auto store_lds = [&](int it) {
         const bool s1 = it >= nit0;
         const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
@@ -197,26 +212,43 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         const int tg = local % ntg;
         if (tg == 0) {
             const int nrows = nsegs * ((seg - 1) * sg.stride + sg.taps);
-            const bool act = sg.act != 0;
+            const bool act = sg.act != 0 && !(a.dbg & 2);
             const bool use_ab = sg.ab != nullptr;
-            float fa[EPC], fb[EPC];
+            f32x2_t fa2[EPC / 2], fb2[EPC / 2], za2[EPC / 2], zb2[EPC / 2];
 #pragma unroll
             for (int e = 0; e < EPC / 2; ++e) {
-                fa[2 * e] = use_ab ? abq[e].x : raw_scale; fb[2 * e] = use_ab ? abq[e].y : 0.f;
-                fa[2 * e + 1] = use_ab ? abq[e].z : raw_scale; fb[2 * e + 1] = use_ab ? abq[e].w : 0.f;
+                fa2[e] = use_ab ? f32x2_t{abq[e].x, abq[e].z} : f32x2_t{raw_scale, raw_scale};
+                fb2[e] = use_ab ? f32x2_t{abq[e].y, abq[e].w} : f32x2_t{0.f, 0.f};
+                za2[e] = fa2[e] * -1.4426950408889634f;
+                zb2[e] = fb2[e] * -1.4426950408889634f;
             }
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                const int row = (tid + i * NTHR) >> 3;
+                const int row = lds_row0 + i * (NTHR / 8);
                 if (row < nrows) {
                     u32x4_t q = u32x4_t{0u, 0u, 0u, 0u};
                     if ((avalid >> i) & 1u) {
                         float f[EPC];
                         unpack16<T>(ra[i], f);
+                        if (act) {
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) {
-                            float v = fmaf(f[e], fa[e], fb[e]);
-                            f[e] = (act && !(a.dbg & 2)) ? silu_f(v) : v;
+                            for (int e = 0; e < EPC / 2; ++e) {
+                                const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
+                                const f32x2_t v2 = x2 * fa2[e] + fb2[e];
+                                const f32x2_t z2 = x2 * za2[e] + zb2[e];
+                                f32x2_t d2 = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+                                d2 = d2 + 1.0f;
+                                const f32x2_t r2 = {__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
+                                const f32x2_t y2 = v2 * r2;
+                                f[2 * e] = y2.x; f[2 * e + 1] = y2.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < EPC / 2; ++e) {
+                                const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
+                                const f32x2_t v2 = x2 * fa2[e] + fb2[e];
+                                f[2 * e] = v2.x; f[2 * e + 1] = v2.y;
+                            }
                         }
                         q = pack16<T>(f);
                     }
@@ -226,7 +258,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) {
-            const int row = (tid + i * NTHR) >> 3;
+            const int row = lds_row0 + i * (NTHR / 8);
             if (row < kTapGroup * TN) *(u32x4_t*)(ldsW + lds_swz(row, c16)) = rw[i];
         }
     };

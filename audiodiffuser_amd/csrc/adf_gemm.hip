@@ -82,8 +82,6 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         tm = cand;
     }
     if (!tm) return "conv_gemm: no tile shape fits (stride/taps too large)";
-    a.flat = flat;
-    a.seg_rows = flat ? a.mrows : tm;
     int tn = a.n_pad >= 128 ? 128 : (a.n_pad >= 64 ? 64 : 32);
     if (a.n_pad % tn && a.n_pad % 64 == 0) tn = 64;
     // keep the 256 CUs busy when the problem is small: prefer narrower N tiles, then shorter M tiles
@@ -96,6 +94,8 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         tm >>= 1;
         if (flat && a.mrows >= tm) flat = 0;   // a tile now lies inside one sample again
     }
+    { static int ftn = -1, ftm = -1; if (ftn < 0) { const char* e = getenv("ADF_GEMM_TN"); ftn = e ? atoi(e) : 0; e = getenv("ADF_GEMM_TM"); ftm = e ? atoi(e) : 0; }
+      if (ftn && a.n_pad >= 128 && a.mrows >= 1024) tn = ftn; if (ftm && a.mrows >= 1024 && !flat) { bool fits = true; for (int s = 0; s < a.nseg; ++s) if ((ftm - 1) * a.seg[s].stride + a.seg[s].taps > kARows) fits = false; if (fits) tm = ftm; } }
     a.flat = flat;
     a.seg_rows = flat ? a.mrows : tm;
     return dtype_bf16 ? dispatch<bf16_t>(a, tm, tn, stream) : dispatch<float>(a, tm, tn, stream);
