@@ -39,9 +39,13 @@ def gather_samples(local: torch.Tensor, global_batch: int, group: Optional[dist.
         out = torch.empty((global_batch,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
-    bufs = [torch.empty((hi - lo,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) for lo, hi in sizes]
-    dist.all_gather(bufs, local.contiguous(), group=group)
-    return torch.cat(bufs, dim=0)
+    # ragged split: pad every slice to the largest one (collectives need equal shapes), gather once, trim
+    nmax = max(hi - lo for lo, hi in sizes)
+    padded = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
 def sample_sharded(run_local: Callable[[torch.Tensor], torch.Tensor], global_batch: int, length: int, device: torch.device,

@@ -1,0 +1,151 @@
+"""CPU: the oracle (oracle/*.py) reproduces the golden fixtures, which are outputs of the reference itself
+(imported on CPU by oracle/gen_golden.py in the build container).  The reference's own test-suite holds no
+vectors for this path, so these fixtures are what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiodiffuser_amd.config import config_c1, config_c2, config_c3, config_tiny
+from audiodiffuser_amd.weights import generate_weights, generate_noise, param_specs, count_parameters
+from oracle import edm as E, samplers as S, unet1d as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = torch.from_numpy
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("n", [18, 35, 50])
+def test_karras_schedule_bit_exact(golden, n):
+    assert torch.equal(E.karras_sigmas(0.002, 80.0, 7.0, n), T(golden[f"karras_{n}"]))
+
+
+def test_karras_known_values(golden):
+    s = golden["karras_18"]          # SURVEY.md 8(a1) probe values
+    assert abs(s[1] - 57.586) < 1e-3 and abs(s[2] - 40.786) < 1e-3 and abs(s[17] - 0.002) < 1e-7
+
+
+def test_scale_weights_bit_exact(golden):
+    sig = T(golden["scale_sigmas"])
+    c_skip, c_out, c_in, c_noise = E.edm_scale_weights(sig, 0.2, 3)
+    for name, v in (("c_skip", c_skip), ("c_out", c_out), ("c_in", c_in), ("c_noise", c_noise)):
+        assert torch.equal(v.reshape(-1), T(golden[f"scale_{name}"])), name
+
+
+def test_state_dict_layout_matches_reference():
+    lay = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))
+    for tag, cfg in (("c1", config_c1()), ("c2", config_c2()), ("c3", config_c3()), ("tiny", config_tiny())):
+        assert count_parameters(cfg) == lay[tag]["num_params"]
+        assert len(param_specs(cfg)) == lay[tag]["num_tensors"]
+    for tag, cfg in (("c1", config_c1()), ("tiny", config_tiny())):
+        specs = param_specs(cfg)
+        assert list(specs.keys()) == list(lay[tag]["keys"].keys())
+        for k, shp in lay[tag]["keys"].items():
+            assert list(specs[k][0]) == shp, k
+    assert lay["c1"]["num_params"] == 1510040 and lay["c2"]["num_params"] == 23937632
+
+
+@pytest.mark.parametrize("tag", ["tiny", "c1"])
+def test_unet_forward_and_taps(golden, tag):
+    cfg = config_tiny() if tag == "tiny" else config_c1()
+    w = generate_weights(cfg, seed=0)
+    x, t = T(golden[f"net_{tag}_x"]), T(golden[f"net_{tag}_t"])
+    taps = {}
+    with torch.no_grad():
+        y = O.unet1d_forward(w, cfg, x, t, taps=taps)
+    assert rel(y, T(golden[f"net_{tag}_y"])) < 1e-5
+    stride = 7 if tag == "tiny" else 61
+    for name, v in taps.items():
+        ref = T(golden[f"net_{tag}_tap_{name}"])
+        got = v.reshape(v.shape[0], -1)[:, ::stride]
+        assert rel(got, ref) < 1e-5, name
+
+
+def test_inputs_regenerate_identically(golden):
+    assert torch.equal(generate_noise(0, 2, 256) * 0.7, T(golden["net_tiny_x"]))
+
+
+def test_unet_c1_full_length(golden):
+    cfg = config_c1()
+    w = generate_weights(cfg, seed=0)
+    x = generate_noise(100, 1, 16384) * 0.5
+    with torch.no_grad():
+        y = O.unet1d_forward(w, cfg, x, T(golden["net_c1_16k_t"]))
+    assert rel(y.reshape(1, -1)[:, ::64], T(golden["net_c1_16k_y_sub"])) < 1e-5
+    assert abs(float(y.norm()) - float(golden["net_c1_16k_y_l2"][0])) < 1e-3 * float(golden["net_c1_16k_y_l2"][0])
+
+
+@pytest.mark.parametrize("tag", ["tiny", "c1"])
+def test_denoise(golden, tag):
+    cfg = config_tiny() if tag == "tiny" else config_c1()
+    B, L = (2, 256) if tag == "tiny" else (2, 2048)
+    fn = E.make_denoiser(generate_weights(cfg, seed=0), cfg, 0.2)
+    xn = generate_noise(7, B, L)
+    with torch.no_grad():
+        for si, sg in enumerate((20.0, 1.5, 0.05)):
+            y = fn(xn * sg, sigma=torch.tensor(sg))
+            assert rel(y, T(golden[f"denoise_{tag}_{si}"])) < 1e-5
+            assert float(y.abs().max()) <= 1.0
+        sv = torch.tensor([3.0, 0.3])
+        assert rel(fn(xn * sv[:, None, None], sigmas=sv), T(golden[f"denoise_{tag}_vec"])) < 1e-5
+
+
+def test_denoise_needs_exactly_one_sigma():
+    cfg = config_tiny()
+    fn = E.make_denoiser(generate_weights(cfg, seed=0), cfg, 0.2)
+    with pytest.raises(AssertionError):
+        fn(torch.zeros(1, 1, 64))                     # reference: components/utils.py:47
+
+
+def test_samplers_mock_fn(golden):
+    """Sampler arithmetic isolated from the net: fn = 0.5 * x."""
+    noise = generate_noise(40, 2, 256)
+    mock = lambda x, sigma=None: 0.5 * x
+    s18, s50 = T(golden["karras_18"]), T(golden["karras_50"])
+    tr = []
+    y = S.edm_sampler(noise, mock, s18, 18, s_churn=0.0, s_noise=1.0, trace=tr)
+    assert rel(y, T(golden["smp_heun18_tiny_mock_final"])) < 1e-6
+    traj = T(golden["smp_heun18_tiny_mock_traj"])
+    assert len(tr) == 18 and traj.shape[0] == 18
+    for a, b in zip(tr, traj):
+        assert rel(a.reshape(2, -1)[:, ::16], b) < 1e-6
+    assert rel(S.edm_alpha_sampler(noise, mock, s18, 18, alpha=1.0), T(golden["smp_alpha18_tiny_mock_final"])) < 1e-6
+    assert rel(S.dpm_multistep_sampler(noise, mock, s50, 50, order=3), T(golden["smp_dpm50_tiny_mock_final"])) < 1e-6
+
+
+def test_sampler_nfe_counts():
+    """Heun 2N-1, alpha 2(N-1), DPM multistep N-1."""
+    cnt = [0]
+    def fn(x, sigma=None):
+        cnt[0] += 1
+        return 0.5 * x
+    z = torch.zeros(1, 1, 8)
+    for n, want in ((18, 35), (50, 99), (35, 69)):
+        cnt[0] = 0
+        S.edm_sampler(z, fn, E.karras_sigmas(0.002, 80.0, 7.0, n), n, s_churn=0.0)
+        assert cnt[0] == want
+    cnt[0] = 0
+    S.edm_alpha_sampler(z, fn, E.karras_sigmas(0.002, 80.0, 7.0, 18), 18)
+    assert cnt[0] == 34
+    cnt[0] = 0
+    S.dpm_multistep_sampler(z, fn, E.karras_sigmas(0.002, 80.0, 7.0, 50), 50, order=3)
+    assert cnt[0] == 49
+
+
+def test_samplers_with_tiny_net(golden):
+    cfg = config_tiny()
+    fn = E.make_denoiser(generate_weights(cfg, seed=0), cfg, 0.2)
+    noise = generate_noise(40, 2, 256)
+    s18, s50, s12 = T(golden["karras_18"]), T(golden["karras_50"]), E.karras_sigmas(0.002, 80.0, 7.0, 12)
+    with torch.no_grad():
+        assert rel(S.edm_sampler(noise, fn, s18, 18, s_churn=0.0, s_noise=1.0), T(golden["smp_heun18_tiny_net_final"])) < 1e-5
+        assert rel(S.edm_alpha_sampler(noise, fn, s18, 18), T(golden["smp_alpha18_tiny_net_final"])) < 1e-5
+        assert rel(S.dpm_multistep_sampler(noise, fn, s50, 50, order=3), T(golden["smp_dpm50_tiny_net_final"])) < 1e-5
+        inj = torch.stack([torch.randn((2, 1, 256), generator=torch.Generator().manual_seed(9000 + i)) for i in range(12)])
+        y = S.edm_sampler(noise, fn, s12, 12, s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, injected_noise=inj)
+        assert rel(y, T(golden["smp_churn12_tiny_net_final"])) < 1e-5
