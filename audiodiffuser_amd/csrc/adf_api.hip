@@ -290,11 +290,17 @@ struct Walker {
         return sg;
     }
     void run_gemm(GemmArgs& g, Act& out, bool want_stats) {
-        if (want_stats && can_fuse_stats(out.C) && !g.scatter_f) {
+        const bool ask = want_stats && can_fuse_stats(out.C) && !g.scatter_f;
+        if (ask) {
             out.stats = alloc_stats();
             g.stats = out.stats; g.stats_groups = h->cfg.resnet_groups;
         }
-        if (live()) check(launch_conv_gemm(g, h->bf16, s));
+        if (live()) {
+            bool fused = false;
+            check(launch_conv_gemm(g, h->bf16, s, &fused));
+            // the launcher may decline (tile shape / group size): fill the same buffer with the separate pass
+            if (ask && !fused) check(launch_gn_stats(out.p, h->bf16, p->B, out.L, out.C, h->cfg.resnet_groups, out.stats, s));
+        }
     }
 
     Act linear(const Act& x, const ConvW& w, const void* res, int gelu, bool want_stats) {

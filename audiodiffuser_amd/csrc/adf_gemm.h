@@ -415,6 +415,15 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
 #pragma unroll
             for (int k = 0; k < P2; ++k) rres[k] = u32x4_t{0u, 0u, 0u, 0u};
         }
+        // statistics: this thread's chunks all cover the same EPC channels (cc = tid % CPR) and rows
+        // tid/CPR + k*RPK, so per-channel sums accumulate in registers and are flushed once per sample
+        // segment: reduce over the channels of a group inside the thread, over the threads of a group and over
+        // the row-lanes of the wave with shuffles, then one fp64 atomic pair per (wave, group).
+        constexpr int RPK = NTHR / CPR;                 // tile rows covered by one k step
+        const bool stats_here = do_stats && !(a.dbg & 8);
+        const int gs = stats_here ? a.out_c / a.stats_groups : EPC;   // channels per group (>= EPC, power of two)
+        const int tpg = gs / EPC;                       // threads (adjacent cc) per group
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < P2; ++k) {
             const int idx = tid + k * NTHR;
@@ -432,39 +441,18 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
             }
-            if (okv[k]) *(u32x4_t*)(out + off[k]) = pack16<T>(v);
-            if (do_stats && (res || a.gelu)) {
+            if (okv[k]) {
+                *(u32x4_t*)(out + off[k]) = pack16<T>(v);
 #pragma unroll
-                for (int e = 0; e < EPC; e += 4)
-                    *(float4*)(tile + row * TN + cc * EPC + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+                for (int e = 0; e < EPC; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
             }
-        }
-    }
-
-    // ---- phase 3: GroupNorm statistics of the produced tile, column-wise from the LDS image ---------
-    if (do_stats && !(a.dbg & 8)) {
-        __syncthreads();
-        constexpr int PARTS = NTHR / TN;
-        constexpr int RPP = TM / PARTS;     // rows per part
-        const int col = tid % TN, part = tid / TN;
-        const int n = n0 + col;
-        const bool nok = n < a.n;
-        const int gs = a.out_c / a.stats_groups;
-        const int span = gs < 32 ? gs : 32;
-        float s1 = 0.f, s2 = 0.f;
-        for (int i = 0; i < RPP; ++i) {
-            const int row = part * RPP + i;
-            bool ok;
-            if (a.flat) ok = (R0 + row) < rows_total;
-            else ok = (m0 + row) < a.mrows;
-            if (ok && nok) {
-                const float v = tile[row * TN + col];
-                s1 += v; s2 = fmaf(v, v, s2);
-            }
-            if (((row + 1) % seg) == 0 || i == RPP - 1) {   // wave-uniform (seg, RPP are powers of two)
-                for (int o = 1; o < span; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                if (nok && (col & (span - 1)) == 0) {
-                    const int bb = a.flat ? (int)((R0 + row) / a.mrows) : b0;
+            if (stats_here && ((((k + 1) * RPK) % seg) == 0 || k == P2 - 1)) {   // wave-uniform
+                for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                for (int o = CPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                const int n = n0 + cc * EPC;
+                if (lane < CPR && (cc & (tpg - 1)) == 0 && n < a.n) {
+                    const int trow = k * RPK;                       // any row of the segment just finished
+                    const int bb = a.flat ? (int)((R0 + trow) / a.mrows) : b0;
                     if (bb < a.B) {
                         double* sp = a.stats + ((size_t)bb * a.stats_groups + n / gs) * 2;
                         atomicAdd(sp, (double)s1);
@@ -477,7 +465,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     }
 }
 
-// host-side launcher (adf_gemm.hip)
-const char* launch_conv_gemm(const GemmArgs& a, int dtype_bf16, hipStream_t stream);
+// host-side launcher (adf_gemm.hip); *stats_fused tells whether the requested statistics were produced
+const char* launch_conv_gemm(const GemmArgs& a, int dtype_bf16, hipStream_t stream, bool* stats_fused = nullptr);
 
 }  // namespace adf

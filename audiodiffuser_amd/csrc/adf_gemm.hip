@@ -40,8 +40,9 @@ const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
 
 }  // namespace
 
-const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t stream) {
+const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t stream, bool* stats_fused) {
     GemmArgs a = a_in;
+    if (stats_fused) *stats_fused = false;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ADF_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     if (a.nseg < 1 || a.nseg > 2) return "conv_gemm: nseg must be 1 or 2";
     if (a.n_pad % 32) return "conv_gemm: n_pad must be a multiple of 32";
@@ -57,11 +58,6 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         if (g.taps < 1 || g.stride < 1) return "conv_gemm: bad taps/stride";
         if (g.ab) raw = false;
         if ((long long)a.B * a.lin * (g.c0 > g.c1 ? g.c0 : g.c1) * esz >= (1LL << 32)) return "conv_gemm: input tensor must be < 4 GiB";
-    }
-    if (a.stats) {
-        if (a.scatter_f) return "conv_gemm: fused stats unsupported with phase scatter";
-        const int gs = a.out_c / a.stats_groups;
-        if (gs * a.stats_groups != a.out_c || (gs & (gs - 1))) return "conv_gemm: fused stats need power-of-two group size";
     }
     // Tile selection.  Per-sample tiles need (TM-1)*stride + taps staged rows; flat tiles (several whole
     // samples per tile, raw inputs only) need (TM/mrows) * ((mrows-1)*stride + taps).
@@ -98,6 +94,16 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
       if (ftn && a.n_pad >= 128 && a.mrows >= 1024) tn = ftn; if (ftm && a.mrows >= 1024 && !flat) { bool fits = true; for (int s = 0; s < a.nseg; ++s) if ((ftm - 1) * a.seg[s].stride + a.seg[s].taps > kARows) fits = false; if (fits) tm = ftm; } }
     a.flat = flat;
     a.seg_rows = flat ? a.mrows : tm;
+    if (a.stats) {
+        // the epilogue reduces statistics per thread-column and wave: see adf_gemm.h phase 2
+        const int nthr = (tm == 64 && tn == 32) || (tm == 32 && tn == 64) ? 128 : ((tm == 32 && tn == 32) ? 64 : 256);
+        const int rpk = nthr * epc / tn;
+        const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
+        const bool ok = !a.scatter_f && gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= tn &&
+                        (!flat || a.mrows % rpk == 0);
+        if (!ok) a.stats = nullptr;
+        else if (stats_fused) *stats_fused = true;
+    }
     return dtype_bf16 ? dispatch<bf16_t>(a, tm, tn, stream) : dispatch<float>(a, tm, tn, stream);
 }
 
