@@ -277,6 +277,120 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
     }
 }
 
+// MFMA self-attention for bf16, head dim 32 (attention_utils.py:160-182).  One wave = 32 queries of one
+// (batch, head) pair.  S^T = K Q^T is computed (keys on the accumulator rows, the query on the lane), so the
+// softmax over keys is lane-local: 16 registers + one xor-32 exchange.  The P^T accumulator tile is converted
+// to bf16 in place and used directly as the B operand of O^T += V^T P^T (the k order inside a step is
+// 16s + 8(j>>2) + 4h + (j&3), and the V^T fragment is gathered from an LDS copy of V in exactly that order).
+typedef __attribute__((ext_vector_type(8))) __bf16 att_bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float att_f32x16_t;
+
+__global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
+                                                                int C, int heads, float scale) {
+    constexpr int D = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qtiles = (N + 31) >> 5;
+    const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);   // waves that share one (b, head) pair
+    const int ppb = 4 / wpp;                                    // pairs per block
+    const int qgroups = (qtiles + wpp - 1) / wpp;
+    const int qg = blockIdx.x % qgroups, pg = blockIdx.x / qgroups;
+    const int pair = pg * ppb + wave / wpp;
+    const int qt = qg * wpp + wave % wpp;
+    const bool pair_ok = pair < B * heads;
+    const int pc = pair_ok ? pair : 0;
+    const int b = pc / heads, hd = pc - b * heads;
+    const size_t rowstride = (size_t)3 * C;
+    const bf16_t* base = qkv + (size_t)b * N * rowstride + (size_t)hd * D;
+    // ---- V of this pair -> LDS [N][32] bf16, staged by the wpp waves of the pair -----------------------
+    char* vl = smem + (size_t)(wave / wpp) * N * 64;
+    {
+        const int tl = (wave % wpp) * 64 + lane, nthr = wpp * 64;
+        const bf16_t* vb = base + 2 * C;
+        for (int idx = tl; idx < N * 4; idx += nthr) {
+            const int key = idx >> 2, c = idx & 3;
+            *(u32x4_t*)(vl + key * 64 + c * 16) = *(const u32x4_t*)(vb + (size_t)key * rowstride + c * 8);
+        }
+    }
+    __syncthreads();
+    if (!pair_ok || qt >= qtiles) return;
+    // ---- Q^T fragments (B operand), query = qt*32 + r ----------------------------------------------------
+    const int query = qt * 32 + r;
+    const int qrow = query < N ? query : N - 1;
+    att_bf16x8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        qf[ks] = __builtin_bit_cast(att_bf16x8_t, *(const u32x4_t*)(base + (size_t)qrow * rowstride + ks * 16 + hh * 8));
+    att_f32x16_t o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const bf16_t* kb = base + C;
+    for (int kt = 0; kt < qtiles; ++kt) {
+        const int key_r = kt * 32 + r;
+        const int krow = key_r < N ? key_r : N - 1;
+        att_f32x16_t st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const att_bf16x8_t kf = __builtin_bit_cast(att_bf16x8_t, *(const u32x4_t*)(kb + (size_t)krow * rowstride + ks * 16 + hh * 8));
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            const float sv = key < N ? st[e] * scale : -INFINITY;
+            st[e] = sv;
+            mt = fmaxf(mt, sv);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m, mt);
+        const float alpha = __expf(m - mn);
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float pv = __expf(st[e] - mn); st[e] = pv; psum += pv; }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] *= alpha;
+        m = mn;
+#pragma unroll
+        for (int sgrp = 0; sgrp < 2; ++sgrp) {
+            u32x4_t pw, vw;
+            pw.x = pack_bf16x2(st[8 * sgrp + 0], st[8 * sgrp + 1]);
+            pw.y = pack_bf16x2(st[8 * sgrp + 2], st[8 * sgrp + 3]);
+            pw.z = pack_bf16x2(st[8 * sgrp + 4], st[8 * sgrp + 5]);
+            pw.w = pack_bf16x2(st[8 * sgrp + 6], st[8 * sgrp + 7]);
+            unsigned short ve[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int key = kt * 32 + 16 * sgrp + 8 * (j >> 2) + 4 * hh + (j & 3);
+                key = key < N ? key : N - 1;             // its probability is 0; keep the value finite
+                ve[j] = *(const unsigned short*)(vl + key * 64 + r * 2);
+            }
+            vw.x = (unsigned)ve[0] | ((unsigned)ve[1] << 16);
+            vw.y = (unsigned)ve[2] | ((unsigned)ve[3] << 16);
+            vw.z = (unsigned)ve[4] | ((unsigned)ve[5] << 16);
+            vw.w = (unsigned)ve[6] | ((unsigned)ve[7] << 16);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8_t, vw), __builtin_bit_cast(att_bf16x8_t, pw), o, 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (query < N) {
+        bf16_t* orow = out + ((size_t)b * N + query) * C + (size_t)hd * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {    // registers 4g..4g+3 = head dims 8g + 4hh .. +3
+            uint2 w;
+            w.x = pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv);
+            w.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *(uint2*)(orow + 8 * g + 4 * hh) = w;
+        }
+    }
+}
+
 template <typename T>
 static const char* attention_dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
     const int dh = C / heads;
@@ -297,6 +411,17 @@ static const char* attention_dispatch(const void* qkv, void* out, int B, int N, 
 
 const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N, int C, int heads, hipStream_t s) {
     if (C % heads) return "attention: C % heads != 0";
+    if (bf16 && C / heads == 32 && N <= 1024 && N >= 1) {
+        const int qtiles = (N + 31) / 32;
+        const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);
+        const int ppb = 4 / wpp;
+        const int qgroups = (qtiles + wpp - 1) / wpp;
+        const long long blocks = (long long)((B * heads + ppb - 1) / ppb) * qgroups;
+        const size_t lds = (size_t)ppb * N * 64;
+        hipLaunchKernelGGL(attention_mfma32_kernel, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C,
+                           heads, 1.0f / sqrtf(32.0f));
+        return ADF_LAUNCH_CHECK("attention_mfma");
+    }
     return bf16 ? attention_dispatch<bf16_t>(qkv, out, B, N, C, heads, s) : attention_dispatch<float>(qkv, out, B, N, C, heads, s);
 }
 

@@ -179,6 +179,17 @@ def test_config2_batch_independence_and_range(dtype):
         assert rel_err(yb, y32) < BF16_TOL
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
+def test_config3_every_layer_short(dtype, tol):
+    """64-channel net with attention at N = 256 / 64 / 16 / 4 tokens (head dim 32: the MFMA attention kernel in
+    bf16, including partial query/key tiles), every recorded layer against the oracle."""
+    x = generate_noise(0, 2, 4096) * 0.7
+    errs, y, yo = tap_errors(A.config_c3(), x, torch.tensor([-0.9, 0.35]), dtype, 0)
+    assert sum("attn" in k for k in errs) == 9
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, bad
+
+
 def test_config3_attention_at_1024_tokens_vs_oracle():
     """BASELINE config 3 (attention from the 16x level, N = 1024 tokens) on one waveform vs the CPU oracle."""
     from oracle import unet1d as O
