@@ -75,6 +75,20 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 constexpr int kLdsPitch = 144;   // bytes between LDS rows (128 B of K + 16 B pad)
 __device__ __forceinline__ int lds_swz(int row, int c16) { return row * kLdsPitch + (c16 << 4); }
 
+// Asynchronous 16-byte global load that hipcc does not track: no compiler-inserted s_waitcnt, the data is
+// only valid after the matching hand-counted wait (ADF_VMWAIT_*), which also names the destination registers so
+// that no consumer can be scheduled above it (cdna_hip_programming.md 5.7, form (ii)).
+#define ADF_GLOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+
+// A kernarg pointer as a guaranteed scalar: a per-lane select between two struct fields otherwise becomes a
+// per-lane select of the fields' ADDRESSES followed by a global_load of the pointer (plus its vmcnt(0) wait).
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int TM, int TN>
 constexpr int gemm_lds_bytes() {
     constexpr int main_b = kARows * kLdsPitch + kTapGroup * TN * kLdsPitch;
@@ -172,9 +186,12 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
             const int cidx = chunk * KC + c16 * EPC;
             const bool cvalid = cidx < ctot;
             const bool from1 = sg.c1 > 0 && cidx >= sg.c0;   // K-padding lanes of a single-source segment stay on src0
-            const char* src = (const char*)(from1 ? sg.src1 : sg.src0);
-            const unsigned rowbytes = (unsigned)(from1 ? sg.c1 : sg.c0) * (unsigned)sizeof(T);
-            const unsigned colbytes = (unsigned)(from1 ? cidx - sg.c0 : cidx) * (unsigned)sizeof(T);
+            const char* src0u = uniform_ptr(sg.src0);
+            const char* src1u = uniform_ptr(sg.src1);
+            const char* src = from1 ? src1u : src0u;
+            const int c0u = __builtin_amdgcn_readfirstlane(sg.c0), c1u = __builtin_amdgcn_readfirstlane(sg.c1);
+            const unsigned rowbytes = (unsigned)(from1 ? c1u : c0u) * (unsigned)sizeof(T);
+            const unsigned colbytes = (unsigned)(from1 ? cidx - c0u : cidx) * (unsigned)sizeof(T);
             avalid = 0;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
@@ -462,6 +479,437 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
                 s1 = 0.f; s2 = 0.f;
             }
         }
+    }
+}
+
+// =====================================================================================================
+// Weight-stationary, warp-specialised persistent variant for the large layers (per-sample tiling, TM = 128).
+//   * The whole weight operand of the block's N tile (every K chunk x tap of both segments) is copied into LDS
+//     ONCE; the block then walks its M tiles, so the steady state streams only activations from HBM.  In the
+//     plain kernel every 128-row tile re-reads the weights from L2, 3-4x the HBM bytes of the layer.
+//   * block = 8 waves: waves 0-3 "consumers" (MFMA + epilogue), waves 4-7 "producers" (activation loads two K
+//     steps ahead in registers, fused GroupNorm/FiLM/SiLU prologue, LDS stores).  Each SIMD hosts one wave of
+//     each role, so the prologue's VALU/transcendental work overlaps the matrix pipe.
+//   * LDS = weights (<= ~110 KB) + 2 activation stages (2 x 18.7 KB) + 4 x 2 KB wave-private epilogue scratch.
+//   * step g: producers fill stage g&1 with K iteration g, consumers compute iteration g-1 from stage (g-1)&1;
+//     ONE workgroup barrier per step.  The epilogue is wave-local (each consumer wave transposes its own 64-row
+//     slice through its private scratch, 8 rows at a time), so it needs no workgroup barrier at all.
+// =====================================================================================================
+constexpr int kWsARows = 136;                       // (128-1)*1 + 9 taps max for stride 1
+constexpr int kWsScratch = 4 * 2048;                // 4 consumer waves x (8 rows x 64 cols x fp32)
+
+template <typename T, int NT, int WN>   // consumer wave tile = 64 x (NT*32); consumer waves = (4/WN) x WN; TN = NT*WN*32
+__global__ void __launch_bounds__(512) conv_gemm_ws_kernel(const GemmArgs a, int tiles_m_total, int blocks_per_n) {
+    constexpr int WM = 4 / WN;
+    constexpr int MT = 4 / WM;                              // TM = 128 = WM * MT * 32
+    constexpr int TM = 128, TN = NT * WN * 32, NTHR = 256;  // NTHR = threads of ONE role
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int KC = kRowBytes / (int)sizeof(T);
+    constexpr int A_CH = (kWsARows * 8 + NTHR - 1) / NTHR;
+    constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr int ASTAGE = kWsARows * kLdsPitch;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NTHR;   // scalar role branch
+    const int tid = threadIdx.x & (NTHR - 1), lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (a.n_pad + TN - 1) / TN;
+    const int tiles_m = (a.mrows + TM - 1) / TM;
+    const int nit0 = a.seg[0].nchunk;                       // one K iteration = one chunk with ALL its taps
+    const int nit = nit0 + (a.nseg > 1 ? a.seg[1].nchunk : 0);
+    const int tn_i = (int)blockIdx.x % tiles_n;
+    const int slot = (int)blockIdx.x / tiles_n;
+    const int n0 = tn_i * TN;
+    const int my_tiles = slot < tiles_m_total ? (tiles_m_total - 1 - slot) / blocks_per_n + 1 : 0;
+    const int G = my_tiles * nit;
+    // LDS carve-up: [weights][A stage 0][A stage 1][scratch]
+    const int wrows0 = a.seg[0].nchunk * a.seg[0].taps * TN;
+    const int wrows = wrows0 + (a.nseg > 1 ? a.seg[1].nchunk * a.seg[1].taps * TN : 0);
+    char* ldsWall = smem;
+    char* ldsA0 = smem + (size_t)wrows * kLdsPitch;
+    char* scratch = ldsA0 + 2 * ASTAGE;
+    auto tile_geom = [&](int tseq, int& b0, int& m0) {
+        const int t = slot + tseq * blocks_per_n;
+        b0 = t / tiles_m;
+        m0 = (t - b0 * tiles_m) * TM;
+    };
+
+    // ---- one-time weight fill: rows [seg][chunk][tap][n_l] -> LDS (all 512 threads, 8 loads in flight each) ----
+    {
+        const int t512 = (int)threadIdx.x;
+        const int c16w = t512 & 7;
+        for (int base = t512 >> 3; base < wrows; base += 64 * 8) {
+            u32x4_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int row = base + 64 * k;
+                row = row < wrows ? row : wrows - 1;              // clamped: the store below is guarded
+                const bool s1 = row >= wrows0;
+                const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+                const int rl = s1 ? row - wrows0 : row;
+                const int ct = rl / TN, n_l = rl - ct * TN;       // ct = chunk * taps + tap
+                // rows beyond n_pad re-read row n_pad-1 (their columns are masked in the epilogue)
+                const int nn = (n0 + n_l) < a.n_pad ? (n0 + n_l) : a.n_pad - 1;
+                v[k] = *(const u32x4_t*)((const char*)sg.w + ((size_t)ct * a.n_pad + nn) * kRowBytes + c16w * 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = base + 64 * k;
+                if (row < wrows) *(u32x4_t*)(ldsWall + lds_swz(row, c16w)) = v[k];
+            }
+        }
+    }
+    __syncthreads();
+    // both roles execute the same, even number of steps: 2 * ceil((G + 1) / 2)
+    const int npairs = (G + 2) / 2;
+
+    if (producer) {
+        // ================================ producers ==================================================
+        const int c16 = tid & 7;
+        const int lds_row0 = tid >> 3;
+        struct Regs { u32x4_t ra[A_CH]; f32x4_t abq[EPC / 2]; float raw_scale; unsigned avalid; };
+        Regs R0s, R1s;
+        int arow_idx[A_CH];
+        int abq_b0 = 0;
+        auto load_a = [&](int q, Regs& R) {
+            const int tseq = q / nit, it = q - tseq * nit;
+            const bool s1 = it >= nit0;
+            const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+            const int chunk = s1 ? it - nit0 : it;
+            if (chunk == 0) {
+                int b0, m0;
+                tile_geom(tseq, b0, m0);
+                const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+                const int nrows = (TM - 1) * sg.stride + sg.taps;
+                const int p_lo = m0 * sg.stride + off_min;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    const int row = (tid + i * NTHR) >> 3;
+                    const int p = p_lo + row;
+                    const bool ok = row < nrows && p >= 0 && p < a.lin;
+                    arow_idx[i] = ok ? b0 * a.lin + p : -1;
+                }
+                abq_b0 = b0;
+            }
+            const int ctot = sg.c0 + sg.c1;
+            const int cidx = chunk * KC + c16 * EPC;
+            const bool cvalid = cidx < ctot;
+            const bool from1 = sg.c1 > 0 && cidx >= sg.c0;
+            const char* src0u = uniform_ptr(sg.src0);
+            const char* src1u = uniform_ptr(sg.src1);
+            const char* src = from1 ? src1u : src0u;
+            const int c0u = __builtin_amdgcn_readfirstlane(sg.c0), c1u = __builtin_amdgcn_readfirstlane(sg.c1);
+            const unsigned rowbytes = (unsigned)(from1 ? c1u : c0u) * (unsigned)sizeof(T);
+            const unsigned colbytes = (unsigned)(from1 ? cidx - c0u : cidx) * (unsigned)sizeof(T);
+            R.avalid = 0;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const bool ok = cvalid && arow_idx[i] >= 0;
+                const unsigned off = (ok ? (unsigned)arow_idx[i] : 0u) * rowbytes + (ok ? colbytes : 0u);
+                const char* ptr = src + off;
+                ADF_GLOAD16(R.ra[i], ptr);
+                R.avalid |= (ok ? 1u : 0u) << i;
+            }
+            const float* abp = sg.ab ? sg.ab + (cvalid ? (unsigned)(abq_b0 * ctot + cidx) * 2u : 0u) : (const float*)sg.w;
+#pragma unroll
+            for (int e = 0; e < EPC / 2; ++e) { const float* pe = abp + e * 4; ADF_GLOAD16(R.abq[e], pe); }
+            R.raw_scale = from1 ? sg.scale1 : 1.0f;
+        };
+        // wait until only the OTHER register set's loads (issued later) are still in flight
+        auto wait_set = [&](Regs& R) {
+            static_assert(A_CH == 5, "wait_set is written for 5 activation chunks per producer thread");
+            if constexpr (EPC == 8)
+                asm volatile("s_waitcnt vmcnt(9)" : "+v"(R.ra[0]), "+v"(R.ra[1]), "+v"(R.ra[2]), "+v"(R.ra[3]), "+v"(R.ra[4]),
+                             "+v"(R.abq[0]), "+v"(R.abq[1]), "+v"(R.abq[2]), "+v"(R.abq[3]) : : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(7)" : "+v"(R.ra[0]), "+v"(R.ra[1]), "+v"(R.ra[2]), "+v"(R.ra[3]), "+v"(R.ra[4]),
+                             "+v"(R.abq[0]), "+v"(R.abq[1]) : : "memory");
+        };
+        auto store_a = [&](int q, Regs& R, char* ldsA) {
+            const int it = q % nit;
+            const bool s1 = it >= nit0;
+            const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+            const int nrows = (TM - 1) * sg.stride + sg.taps;
+            const bool act = sg.act != 0;
+            const bool use_ab = sg.ab != nullptr;
+            f32x2_t fa2[EPC / 2], fb2[EPC / 2], za2[EPC / 2], zb2[EPC / 2];
+#pragma unroll
+            for (int e = 0; e < EPC / 2; ++e) {
+                fa2[e] = use_ab ? f32x2_t{R.abq[e].x, R.abq[e].z} : f32x2_t{R.raw_scale, R.raw_scale};
+                fb2[e] = use_ab ? f32x2_t{R.abq[e].y, R.abq[e].w} : f32x2_t{0.f, 0.f};
+                za2[e] = fa2[e] * -1.4426950408889634f;
+                zb2[e] = fb2[e] * -1.4426950408889634f;
+            }
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int row = lds_row0 + i * (NTHR / 8);
+                if (row < nrows) {
+                    u32x4_t qv = u32x4_t{0u, 0u, 0u, 0u};
+                    if ((R.avalid >> i) & 1u) {
+                        float f[EPC];
+                        unpack16<T>(R.ra[i], f);
+                        if (act) {
+#pragma unroll
+                            for (int e = 0; e < EPC / 2; ++e) {
+                                const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
+                                const f32x2_t v2 = x2 * fa2[e] + fb2[e];
+                                const f32x2_t z2 = x2 * za2[e] + zb2[e];
+                                f32x2_t d2 = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+                                d2 = d2 + 1.0f;
+                                const f32x2_t r2 = {__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
+                                const f32x2_t y2 = v2 * r2;
+                                f[2 * e] = y2.x; f[2 * e + 1] = y2.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < EPC / 2; ++e) {
+                                const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
+                                const f32x2_t v2 = x2 * fa2[e] + fb2[e];
+                                f[2 * e] = v2.x; f[2 * e + 1] = v2.y;
+                            }
+                        }
+                        qv = pack16<T>(f);
+                    }
+                    *(u32x4_t*)(ldsA + lds_swz(row, c16)) = qv;
+                }
+            }
+        };
+        // Straight-line even/odd step pairs with unconditional loads (iteration index clamped to G-1): the
+        // compiler then knows exactly which loads are outstanding and keeps two K steps in flight (a runtime
+        // even/odd branch or conditional loads make it drain vmcnt(0) every step).
+        if (G > 0) {
+            const int qmax = G - 1;
+            load_a(0, R0s);
+            load_a(qmax < 1 ? qmax : 1, R1s);
+            for (int pr = 0; pr < npairs; ++pr) {
+                const int g = 2 * pr;
+                wait_set(R0s);
+                store_a(g < qmax ? g : qmax, R0s, ldsA0);            // a step >= G writes a stage nobody reads again
+                load_a(g + 2 < qmax ? g + 2 : qmax, R0s);
+                __syncthreads();
+                wait_set(R1s);
+                store_a(g + 1 < qmax ? g + 1 : qmax, R1s, ldsA0 + ASTAGE);
+                load_a(g + 3 < qmax ? g + 3 : qmax, R1s);
+                __syncthreads();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours may be in flight when the wave ends
+        } else {
+            for (int pr = 0; pr < npairs; ++pr) { __syncthreads(); __syncthreads(); }
+        }
+        return;
+    }
+
+    // ==================================== consumers ====================================================
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    float bias_r[NT];        // bias of this lane's output column(s): the block's N tile never changes
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nb = n0 + (wn * NT + j) * 32 + r;
+        bias_r[j] = 0.f;
+        if (nb < a.n) {
+            const int bi = nb % a.bias_mod;
+            if (a.bias0) bias_r[j] += a.bias0[bi];
+            if (a.bias1) bias_r[j] += a.bias1[bi];
+        }
+    }
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_r[j];
+
+    for (int g = 0; g < 2 * npairs; ++g) {
+        if (g >= 1 && g <= G) {
+            const int q = g - 1;
+            const int tseq = q / nit, it = q - tseq * nit;
+            const char* ldsA = ldsA0 + ((q & 1) ? ASTAGE : 0);
+            // geometry of the wave-local epilogue (see below) -- needed here to prefetch the identity residual
+            constexpr int WCOLS = NT * 32;                       // columns owned by the wave
+            constexpr int CPW = WCOLS / EPC;                     // 16-byte chunks per row
+            constexpr int RPP = 64 / CPW;                        // rows handled by the 64 lanes at once
+            constexpr int NSUB = RPP >= 8 ? 1 : 8 / RPP;         // sub-steps per 8-row pass
+            constexpr int NRES = MT * 4 * NSUB;
+            u32x4_t rres[NRES];
+            const int cc = lane % CPW, rsub = lane / CPW;        // this lane's chunk column / row inside a sub-step
+            const int ncol0 = n0 + wn * WCOLS;
+            if (it == nit - 1 && a.res != nullptr) {             // wave-uniform
+                int b0, m0;
+                tile_geom(tseq, b0, m0);
+                const T* res = (const T*)a.res;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4)
+#pragma unroll
+                        for (int sb = 0; sb < NSUB; ++sb) {
+                            const int prow = sb * RPP + rsub;
+                            const int m = m0 + (wm * MT + i) * 32 + 8 * p4 + prow;
+                            const int n = ncol0 + cc * EPC;
+                            const bool ok = prow < 8 && m < a.mrows && n < a.n;
+                            const unsigned off = ok ? (unsigned)((b0 * a.out_rows + m) * a.out_c + n) : 0u;
+                            rres[(i * 4 + p4) * NSUB + sb] = *(const u32x4_t*)(res + off);
+                        }
+            }
+            {
+                const bool s1 = it >= nit0;
+                const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+                const int chunk = s1 ? it - nit0 : it;
+                const char* ldsW = ldsWall + (size_t)((s1 ? wrows0 : 0) + chunk * sg.taps * TN) * kLdsPitch;
+                const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+                int abase[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) abase[i] = ((wm * MT + i) * 32 + r) * sg.stride;
+                for (int tap = 0; tap < sg.taps; ++tap) {
+                    const int aoff = sg.off0 + tap * sg.step - off_min;
+                    int arow[MT], wrow[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) arow[i] = abase[i] + aoff;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) wrow[j] = tap * TN + (wn * NT + j) * 32 + r;
+                    if constexpr (kBf16) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            bf16x8_t fa_[MT], fb_[NT];
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) fa_[i] = *(const bf16x8_t*)(ldsA + lds_swz(arow[i], ks * 2 + h));
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) fb_[j] = *(const bf16x8_t*)(ldsW + lds_swz(wrow[j], ks * 2 + h));
+#pragma unroll
+                            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                                for (int j = 0; j < NT; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            float4 fa_[MT][2], fb_[NT][2];
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) {
+                                fa_[i][0] = *(const float4*)(ldsA + lds_swz(arow[i], ks * 4 + 2 * h));
+                                fa_[i][1] = *(const float4*)(ldsA + lds_swz(arow[i], ks * 4 + 2 * h + 1));
+                            }
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) {
+                                fb_[j][0] = *(const float4*)(ldsW + lds_swz(wrow[j], ks * 4 + 2 * h));
+                                fb_[j][1] = *(const float4*)(ldsW + lds_swz(wrow[j], ks * 4 + 2 * h + 1));
+                            }
+#pragma unroll
+                            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                                for (int j = 0; j < NT; ++j) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].x, fb_[j][0].x, acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].y, fb_[j][0].y, acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].z, fb_[j][0].z, acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].w, fb_[j][0].w, acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].x, fb_[j][1].x, acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].y, fb_[j][1].y, acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].z, fb_[j][1].z, acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].w, fb_[j][1].w, acc[i][j], 0, 0, 0);
+                                }
+                        }
+                    }
+                }
+            }
+            if (it == nit - 1) {
+                // ---------------- wave-local epilogue of this tile (no workgroup barrier) ----------------
+                // The wave owns rows [wm*MT*32, +MT*32) x cols [wn*NT*32, +NT*32) of the tile.  Pass (i, p4):
+                // accumulator registers 4*p4..4*p4+3 of both lane halves are rows 8*p4 .. 8*p4+7 of m-tile i;
+                // they go through the wave's private scratch and leave as 16-byte channel chunks.  The bias is
+                // already in the accumulators (they are re-initialised with it), offsets advance incrementally.
+                int b0, m0;
+                tile_geom(tseq, b0, m0);
+                float* sc = (float*)(scratch + wave * 2048);         // [8][WCOLS<=64] fp32
+                float* scw = sc + (4 * h) * WCOLS + r;               // this lane's write base
+                const float* scr = sc + (rsub < 8 ? rsub : 7) * WCOLS + cc * EPC;   // and read base (sub-step 0)
+                T* out = (T*)a.out;
+                const bool has_res = a.res != nullptr;
+                const bool stats_here = a.stats != nullptr;
+                const int gs = stats_here ? a.out_c / a.stats_groups : EPC;
+                const int tpg = gs / EPC;
+                const int n = ncol0 + cc * EPC;
+                const int mw0 = m0 + wm * MT * 32;                   // first row owned by the wave
+                const bool full = !a.scatter_f && (mw0 + MT * 32 <= a.mrows) && (ncol0 + WCOLS <= a.n) && (RPP <= 8 || rsub < 8);
+                f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const int e = 4 * p4 + e4;
+                                scw[e4 * WCOLS + j * 32] = acc[i][j][e];
+                                acc[i][j][e] = bias_r[j];
+                            }
+                        // same-wave LDS traffic is processed in order; only the compiler must not reorder it
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int sb = 0; sb < NSUB; ++sb) {
+                            const int prow = sb * RPP + rsub;        // row inside the 8-row pass
+                            const int m = mw0 + i * 32 + 8 * p4 + prow;
+                            bool ok = true;
+                            unsigned off;
+                            if (full) {
+                                off = (unsigned)((b0 * a.out_rows + m) * a.out_c + n);
+                            } else {
+                                ok = prow < 8 && m < a.mrows && n < a.n;
+                                if (a.scatter_f) {
+                                    const int phase = n / a.out_c, co = n - phase * a.out_c;
+                                    const int orow = m * a.scatter_f + phase - a.scatter_pad;
+                                    ok = ok && orow >= 0 && orow < a.out_rows;
+                                    off = (unsigned)((b0 * a.out_rows + orow) * a.out_c + co);
+                                } else {
+                                    off = (unsigned)((b0 * a.out_rows + m) * a.out_c + n);
+                                }
+                            }
+                            float v[EPC];
+#pragma unroll
+                            for (int e = 0; e < EPC; e += 4) {
+                                const float4 qv = *(const float4*)(scr + sb * RPP * WCOLS + e);
+                                v[e] = qv.x; v[e + 1] = qv.y; v[e + 2] = qv.z; v[e + 3] = qv.w;
+                            }
+                            if (has_res) {
+                                float rr[EPC];
+                                unpack16<T>(rres[(i * 4 + p4) * NSUB + sb], rr);
+#pragma unroll
+                                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+                            }
+                            if (a.gelu) {
+#pragma unroll
+                                for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
+                            }
+                            if (ok) {
+                                *(u32x4_t*)(out + off) = pack16<T>(v);
+#pragma unroll
+                                for (int e = 0; e < EPC; e += 2) {
+                                    const f32x2_t v2 = {v[e], v[e + 1]};
+                                    s1v += v2;
+                                    s2v += v2 * v2;
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                if (stats_here) {
+                    float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
+                    for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                    for (int o = CPW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                    if (lane < CPW && (cc & (tpg - 1)) == 0 && n < a.n) {
+                        double* sp = a.stats + ((size_t)b0 * a.stats_groups + n / gs) * 2;
+                        atomicAdd(sp, (double)s1);
+                        atomicAdd(sp + 1, (double)s2);
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

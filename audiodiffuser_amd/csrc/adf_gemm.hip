@@ -25,6 +25,38 @@ const char* launch_variant(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 
+// Weight-stationary warp-specialised kernel (adf_gemm.h): persistent 512-thread blocks, one per CU.
+int ws_lds_bytes(const GemmArgs& a, int tn) {
+    long long wrows = 0;
+    for (int s = 0; s < a.nseg; ++s) wrows += (long long)a.seg[s].nchunk * a.seg[s].taps * tn;
+    const long long b = wrows * kLdsPitch + 2LL * kWsARows * kLdsPitch + kWsScratch;
+    return b > 0x7fffffff ? 0x7fffffff : (int)b;
+}
+
+template <typename T, int NT, int WN>
+const char* launch_ws_variant(const GemmArgs& a, hipStream_t stream) {
+    constexpr int TN = NT * WN * 32;
+    static bool attr_set = false;
+    static int num_cu = 0;
+    auto kern = conv_gemm_ws_kernel<T, NT, WN>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, ws) failed";
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu < 1)
+            num_cu = 256;
+        attr_set = true;
+    }
+    const int tiles_n = (a.n_pad + TN - 1) / TN;
+    const long long tiles_m_total = (long long)((a.mrows + 127) / 128) * a.B;
+    if (tiles_m_total <= 0 || tiles_m_total > 0x7fffffffLL) return "conv_gemm_ws: bad tile count";
+    long long bpn = num_cu / tiles_n;
+    if (bpn < 1) bpn = 1;
+    if (bpn > tiles_m_total) bpn = tiles_m_total;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(bpn * tiles_n)), dim3(512), (size_t)ws_lds_bytes(a, TN), stream, a, (int)tiles_m_total, (int)bpn);
+    return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_ws: launch failed";
+}
+
 template <typename T>
 const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
     if (tm == 128 && tn == 128) return launch_variant<T, 2, 2, 2, 2>(a, s);
@@ -103,6 +135,33 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                         (!flat || a.mrows % rpk == 0);
         if (!ok) a.stats = nullptr;
         else if (stats_fused) *stats_fused = true;
+    }
+    {
+        // large stride-1 layers: weight-stationary persistent kernel when the weights of an N tile fit in LDS
+        static int use_ws = -1;
+        if (use_ws < 0) { const char* e = getenv("ADF_GEMM_WS"); use_ws = e ? atoi(e) : 1; }
+        bool ws_ok = use_ws && !flat && tm == 128 && a.n_pad >= 64;
+        for (int s = 0; s < a.nseg; ++s)
+            if (a.seg[s].stride != 1 || 127 + a.seg[s].taps > kWsARows) ws_ok = false;
+        const long long tiles_m_total = (long long)((a.mrows + 127) / 128) * a.B;
+        if (ws_ok && tiles_m_total >= 256) {
+            // measured on MI355X: the weight-stationary kernel wins with 128-wide N tiles (Cin = Cout = 128 layers);
+            // with 64-wide tiles (ADF_GEMM_WS=64 to force) the doubled activation staging loses to the plain kernel
+            int wtn = 0;
+            if (a.n_pad >= 128 && ws_lds_bytes(a, 128) <= 160 * 1024) wtn = 128;
+            else if (use_ws == 64 && ws_lds_bytes(a, 64) <= 160 * 1024) wtn = 64;
+            if (wtn) {
+                if (a_in.stats) {
+                    const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
+                    const int wcols = wtn / 2;    // columns owned by one consumer wave
+                    const bool ok = !a.scatter_f && gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= wcols;
+                    a.stats = ok ? a_in.stats : nullptr;
+                    if (stats_fused) *stats_fused = ok;
+                }
+                if (wtn == 128) return dtype_bf16 ? launch_ws_variant<bf16_t, 2, 2>(a, stream) : launch_ws_variant<float, 2, 2>(a, stream);
+                return dtype_bf16 ? launch_ws_variant<bf16_t, 1, 2>(a, stream) : launch_ws_variant<float, 1, 2>(a, stream);
+            }
+        }
     }
     return dtype_bf16 ? dispatch<bf16_t>(a, tm, tn, stream) : dispatch<float>(a, tm, tn, stream);
 }
