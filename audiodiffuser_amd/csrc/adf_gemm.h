@@ -913,6 +913,296 @@ __global__ void __launch_bounds__(512) conv_gemm_ws_kernel(const GemmArgs a, int
     }
 }
 
+// =====================================================================================================
+// Intra-block split-K variant for the short levels (L <= 64: few rows, long K, latency-bound).
+//   One block = one 32 x 32 output tile; its 4 waves each walk a quarter of the K iterations with a PRIVATE
+//   staging region and only wave-level synchronisation (a wave's LDS traffic is processed in order), then
+//   the four partial accumulators are summed through LDS.  Cuts the serial K-loop length by 4.
+//   Restricted to stride-1 segments with <= 3 taps (3-tap convs and 1x1 ops); flat or per-sample tiles.
+// =====================================================================================================
+constexpr int kKsARows = 40;
+constexpr int kKsWaveLds = (kKsARows + kTapGroup * 32) * kLdsPitch;     // 19.6 KB per wave
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a) {
+    constexpr int TM = 32, TN = 32, NW = 64;             // NW = threads of one staging group (a wave)
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int KC = kRowBytes / (int)sizeof(T);
+    constexpr int A_CH = (kKsARows * 8) / NW;              // 5
+    constexpr int W_CH = (kTapGroup * TN * 8) / NW;        // 12
+    constexpr bool kBf16 = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    char* ldsA = smem + wave * kKsWaveLds;
+    char* ldsW = ldsA + kKsARows * kLdsPitch;
+
+    const int tiles_n = (a.n_pad + TN - 1) / TN;
+    int bid = blockIdx.x;
+    const int tn_i = bid % tiles_n; bid /= tiles_n;
+    const int seg = a.flat ? a.seg_rows : TM;
+    const int nsegs = TM / seg;
+    int b0, m0;
+    long long R0;
+    if (a.flat) {
+        R0 = (long long)bid * TM; b0 = (int)(R0 / a.mrows); m0 = 0;
+    } else {
+        const int tiles_m = (a.mrows + TM - 1) / TM;
+        const int tm_i = bid % tiles_m;
+        b0 = bid / tiles_m; m0 = tm_i * TM;
+        R0 = (long long)b0 * a.mrows + m0;
+    }
+    const int n0 = tn_i * TN;
+    const int c16 = lane & 7;
+    const int lds_row0 = lane >> 3;
+
+    const int nit0 = a.seg[0].nchunk;                      // taps <= kTapGroup: one iteration per chunk
+    const int nit = nit0 + (a.nseg > 1 ? a.seg[1].nchunk : 0);
+    const int it_begin = (nit * wave) / 4, it_end = (nit * (wave + 1)) / 4;
+
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    u32x4_t ra[A_CH], rw[W_CH];
+    f32x4_t abq[EPC / 2];
+    float raw_scale = 1.0f;
+    unsigned avalid = 0;
+    int arow_idx[A_CH];
+
+    auto load_regs = [&](int it) {
+        const bool s1 = it >= nit0;
+        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+        const int chunk = s1 ? it - nit0 : it;
+        if (chunk == 0 || it == it_begin) {
+            const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+            const int segrows = (seg - 1) * sg.stride + sg.taps;
+            const int nrows = nsegs * segrows;
+            const int p_lo = m0 * sg.stride + off_min;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int row = lds_row0 + i * (NW / 8);
+                const int j = a.flat ? row / segrows : 0;
+                const int p = p_lo + (row - j * segrows);
+                const int bb = b0 + j;
+                const bool ok = row < nrows && p >= 0 && p < a.lin && bb < a.B;
+                arow_idx[i] = ok ? bb * a.lin + p : -1;
+            }
+        }
+        const int ctot = sg.c0 + sg.c1;
+        const int cidx = chunk * KC + c16 * EPC;
+        const bool cvalid = cidx < ctot;
+        const int c0u = __builtin_amdgcn_readfirstlane(sg.c0), c1u = __builtin_amdgcn_readfirstlane(sg.c1);
+        const bool from1 = c1u > 0 && cidx >= c0u;
+        const char* src0u = uniform_ptr(sg.src0);
+        const char* src1u = uniform_ptr(sg.src1);
+        const char* src = from1 ? src1u : src0u;
+        const unsigned rowbytes = (unsigned)(from1 ? c1u : c0u) * (unsigned)sizeof(T);
+        const unsigned colbytes = (unsigned)(from1 ? cidx - c0u : cidx) * (unsigned)sizeof(T);
+        avalid = 0;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const bool ok = cvalid && arow_idx[i] >= 0;
+            const unsigned off = (ok ? (unsigned)arow_idx[i] : 0u) * rowbytes + (ok ? colbytes : 0u);
+            ra[i] = *(const u32x4_t*)(src + off);
+            avalid |= (ok ? 1u : 0u) << i;
+        }
+        const float* abp = sg.ab ? sg.ab + (cvalid ? (unsigned)(b0 * ctot + cidx) * 2u : 0u) : (const float*)sg.w;
+#pragma unroll
+        for (int e = 0; e < EPC / 2; ++e) abq[e] = *(const f32x4_t*)(abp + e * 4);
+        raw_scale = from1 ? sg.scale1 : 1.0f;
+        const char* wp = uniform_ptr(sg.w) + (size_t)(chunk * sg.taps) * a.n_pad * kRowBytes;
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int row = lds_row0 + i * (NW / 8);
+            const int tap_l = row / TN, n_l = row - tap_l * TN;
+            const unsigned woff = (unsigned)((tap_l * a.n_pad + n0 + n_l) * kRowBytes + c16 * 16);
+            rw[i] = *(const u32x4_t*)(wp + woff);
+        }
+    };
+    auto store_lds = [&](int it) {
+        const bool s1 = it >= nit0;
+        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+        const int nrows = nsegs * ((seg - 1) * sg.stride + sg.taps);
+        const bool act = sg.act != 0;
+        const bool use_ab = sg.ab != nullptr;
+        f32x2_t fa2[EPC / 2], fb2[EPC / 2], za2[EPC / 2], zb2[EPC / 2];
+#pragma unroll
+        for (int e = 0; e < EPC / 2; ++e) {
+            fa2[e] = use_ab ? f32x2_t{abq[e].x, abq[e].z} : f32x2_t{raw_scale, raw_scale};
+            fb2[e] = use_ab ? f32x2_t{abq[e].y, abq[e].w} : f32x2_t{0.f, 0.f};
+            za2[e] = fa2[e] * -1.4426950408889634f;
+            zb2[e] = fb2[e] * -1.4426950408889634f;
+        }
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int row = lds_row0 + i * (NW / 8);
+            if (row < nrows) {
+                u32x4_t qv = u32x4_t{0u, 0u, 0u, 0u};
+                if ((avalid >> i) & 1u) {
+                    float f[EPC];
+                    unpack16<T>(ra[i], f);
+#pragma unroll
+                    for (int e = 0; e < EPC / 2; ++e) {
+                        const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
+                        f32x2_t y2 = x2 * fa2[e] + fb2[e];
+                        if (act) {
+                            const f32x2_t z2 = x2 * za2[e] + zb2[e];
+                            f32x2_t d2 = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
+                            d2 = d2 + 1.0f;
+                            const f32x2_t r2 = {__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
+                            y2 = y2 * r2;
+                        }
+                        f[2 * e] = y2.x; f[2 * e + 1] = y2.y;
+                    }
+                    qv = pack16<T>(f);
+                }
+                *(u32x4_t*)(ldsA + lds_swz(row, c16)) = qv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int row = lds_row0 + i * (NW / 8);
+            *(u32x4_t*)(ldsW + lds_swz(row, c16)) = rw[i];
+        }
+    };
+    auto compute = [&](int it) {
+        const bool s1 = it >= nit0;
+        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+        const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
+        const int segrows = (seg - 1) * sg.stride + sg.taps;
+        const int j = a.flat ? r / seg : 0;
+        const int abase = j * segrows + (r - j * seg) * sg.stride;
+        for (int tap = 0; tap < sg.taps; ++tap) {
+            const int arow = abase + sg.off0 + tap * sg.step - off_min;
+            const int wrow = tap * TN + r;
+            if constexpr (kBf16) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t fa_ = *(const bf16x8_t*)(ldsA + lds_swz(arow, ks * 2 + h));
+                    const bf16x8_t fb_ = *(const bf16x8_t*)(ldsW + lds_swz(wrow, ks * 2 + h));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_, fb_, acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const float4 a0 = *(const float4*)(ldsA + lds_swz(arow, ks * 4 + 2 * h));
+                    const float4 a1 = *(const float4*)(ldsA + lds_swz(arow, ks * 4 + 2 * h + 1));
+                    const float4 w0 = *(const float4*)(ldsW + lds_swz(wrow, ks * 4 + 2 * h));
+                    const float4 w1 = *(const float4*)(ldsW + lds_swz(wrow, ks * 4 + 2 * h + 1));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w0.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w0.w, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w1.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w1.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w1.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w1.w, acc, 0, 0, 0);
+                }
+            }
+        }
+    };
+    // wave-private pipeline: a wave's own LDS writes are visible to its later reads (in-order LDS queue); the
+    // fences only stop the compiler from reordering across the hand-off points
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (it_begin < it_end) {
+        load_regs(it_begin);
+        for (int it = it_begin; it < it_end; ++it) {
+            wave_sync();
+            store_lds(it);
+            wave_sync();
+            if (it + 1 < it_end) load_regs(it + 1);
+            compute(it);
+        }
+    }
+
+    // ---- cross-wave reduction + epilogue ------------------------------------------------------------------
+    __syncthreads();
+    float* part = (float*)smem;                            // [4][32][32] fp32 partial tiles (16 KB)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        part[(wave * 32 + row) * 32 + r] = acc[e];
+    }
+    __syncthreads();
+    constexpr int CPR = TN / EPC;                          // chunks per row: 4 (bf16) / 8 (fp32)
+    constexpr int NCH = TM * CPR;                          // 128 / 256 chunks in the tile
+    T* out = (T*)a.out;
+    const T* res = (const T*)a.res;
+    const bool active = tid < NCH;
+    const int row = tid / CPR, cc = tid - (tid / CPR) * CPR;
+    const int n = n0 + cc * EPC;
+    int bb, m;
+    bool ok;
+    const long long rows_total = (long long)a.B * a.mrows;
+    if (a.flat) {
+        const long long R = R0 + row;
+        ok = R < rows_total;
+        bb = (int)(R / a.mrows);
+        m = (int)(R - (long long)bb * a.mrows);
+    } else {
+        bb = b0; m = m0 + row;
+        ok = m < a.mrows;
+    }
+    ok = ok && active && n < a.n;
+    float s1 = 0.f, s2 = 0.f;
+    if (active) {
+        float v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+                const float4 q = *(const float4*)(part + (w * 32 + row) * 32 + cc * EPC + e);
+                v[e] += q.x; v[e + 1] += q.y; v[e + 2] += q.z; v[e + 3] += q.w;
+            }
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int bi = (n + e) % a.bias_mod;
+                float bsum = 0.f;
+                if (a.bias0) bsum += a.bias0[bi];
+                if (a.bias1) bsum += a.bias1[bi];
+                v[e] += bsum;
+            }
+            const unsigned off = (unsigned)((bb * a.out_rows + m) * a.out_c + n);
+            if (res) {
+                float rr[EPC];
+                unpack16<T>(*(const u32x4_t*)(res + off), rr);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+            }
+            if (a.gelu) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
+            }
+            *(u32x4_t*)(out + off) = pack16<T>(v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+        }
+    }
+    if (a.stats != nullptr && tid < NCH) {      // wave-uniform: NCH is a multiple of 64
+        // a wave covers 64 / CPR consecutive rows, all inside one sample (seg is a multiple of that)
+        const int gs = a.out_c / a.stats_groups;
+        const int tpg = gs / EPC;
+        for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        for (int o = CPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (lane < CPR && (cc & (tpg - 1)) == 0 && n < a.n) {
+            const int frow = (tid >> 6) * (64 / CPR);       // first tile row of this wave
+            const int sb = a.flat ? (int)((R0 + frow) / a.mrows) : b0;
+            if (sb < a.B) {
+                double* sp = a.stats + ((size_t)sb * a.stats_groups + n / gs) * 2;
+                atomicAdd(sp, (double)s1);
+                atomicAdd(sp + 1, (double)s2);
+            }
+        }
+    }
+}
+
 // host-side launcher (adf_gemm.hip); *stats_fused tells whether the requested statistics were produced
 const char* launch_conv_gemm(const GemmArgs& a, int dtype_bf16, hipStream_t stream, bool* stats_fused = nullptr);
 

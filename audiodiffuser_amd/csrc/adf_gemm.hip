@@ -58,6 +58,24 @@ const char* launch_ws_variant(const GemmArgs& a, hipStream_t stream) {
 }
 
 template <typename T>
+const char* launch_ksplit(const GemmArgs& a, hipStream_t stream) {
+    constexpr int lds = 4 * kKsWaveLds;
+    static bool attr_set = false;
+    auto kern = conv_gemm_ksplit_kernel<T>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, ksplit) failed";
+        attr_set = true;
+    }
+    const int tiles_n = (a.n_pad + 31) / 32;
+    const long long tiles_m = a.flat ? ((long long)a.B * a.mrows + 31) / 32 : (long long)((a.mrows + 31) / 32) * a.B;
+    const long long blocks = tiles_m * tiles_n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return "conv_gemm_ksplit: bad grid";
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_ksplit: launch failed";
+}
+
+template <typename T>
 const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
     if (tm == 128 && tn == 128) return launch_variant<T, 2, 2, 2, 2>(a, s);
     if (tm == 128 && tn == 64) return launch_variant<T, 2, 1, 2, 2>(a, s);
@@ -135,6 +153,35 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                         (!flat || a.mrows % rpk == 0);
         if (!ok) a.stats = nullptr;
         else if (stats_fused) *stats_fused = true;
+    }
+    {
+        // short levels (few rows, long K): intra-block split-K, 32 x 32 tiles, 4 waves x K/4 each
+        static int use_ks = -1;
+        if (use_ks < 0) { const char* e = getenv("ADF_GEMM_KSPLIT"); use_ks = e ? atoi(e) : 1; }
+        int nit_total = 0;
+        bool ks_ok = use_ks && !a.scatter_f && (long long)a.B * a.mrows <= 4096;
+        const int ks_flat = (can_flat && a.mrows < 32 && 32 % a.mrows == 0) ? 1 : 0;
+        const int ks_seg = ks_flat ? a.mrows : 32;
+        if (!ks_flat && !raw && a.mrows < 32) ks_ok = false;     // per-sample tiles of a tiny sample: leave to the plain kernel
+        for (int s = 0; s < a.nseg; ++s) {
+            const GemmSeg& g = a.seg[s];
+            if (g.stride != 1 || g.taps > kTapGroup) ks_ok = false;
+            if ((32 / ks_seg) * ((ks_seg - 1) + g.taps) > kKsARows) ks_ok = false;
+            nit_total += g.nchunk;
+        }
+        if (ks_ok && nit_total >= 4) {
+            a.flat = ks_flat;
+            a.seg_rows = ks_seg;
+            if (a_in.stats) {
+                const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
+                const int rows_per_wave = 64 / (32 / epc);
+                const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= 32 &&
+                                (ks_seg % rows_per_wave == 0);
+                a.stats = ok ? a_in.stats : nullptr;
+                if (stats_fused) *stats_fused = ok;
+            }
+            return dtype_bf16 ? launch_ksplit<bf16_t>(a, stream) : launch_ksplit<float>(a, stream);
+        }
     }
     {
         // large stride-1 layers: weight-stationary persistent kernel when the weights of an N tile fit in LDS
