@@ -97,7 +97,7 @@ constexpr int gemm_lds_bytes() {
 }
 
 template <typename T, int MT, int NT, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 1)) conv_gemm_kernel(const GemmArgs a) {
     constexpr int TM = 32 * MT * WM, TN = 32 * NT * WN, NTHR = 64 * WM * WN;
     constexpr int EPC = Elem<T>::kPerChunk;
     constexpr int KC = kRowBytes / (int)sizeof(T);
@@ -231,13 +231,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
             const int nrows = nsegs * ((seg - 1) * sg.stride + sg.taps);
             const bool act = sg.act != 0 && !(a.dbg & 2);
             const bool use_ab = sg.ab != nullptr;
-            f32x2_t fa2[EPC / 2], fb2[EPC / 2], za2[EPC / 2], zb2[EPC / 2];
+            f32x2_t fa2[EPC / 2], fb2[EPC / 2];
 #pragma unroll
             for (int e = 0; e < EPC / 2; ++e) {
                 fa2[e] = use_ab ? f32x2_t{abq[e].x, abq[e].z} : f32x2_t{raw_scale, raw_scale};
                 fb2[e] = use_ab ? f32x2_t{abq[e].y, abq[e].w} : f32x2_t{0.f, 0.f};
-                za2[e] = fa2[e] * -1.4426950408889634f;
-                zb2[e] = fb2[e] * -1.4426950408889634f;
             }
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
@@ -252,7 +250,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
                             for (int e = 0; e < EPC / 2; ++e) {
                                 const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
                                 const f32x2_t v2 = x2 * fa2[e] + fb2[e];
-                                const f32x2_t z2 = x2 * za2[e] + zb2[e];
+                                const f32x2_t z2 = v2 * -1.4426950408889634f;
                                 f32x2_t d2 = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
                                 d2 = d2 + 1.0f;
                                 const f32x2_t r2 = {__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};

@@ -77,6 +77,8 @@ const char* launch_ksplit(const GemmArgs& a, hipStream_t stream) {
 
 template <typename T>
 const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
+    { static int w8 = -1; if (w8 < 0) { const char* e = getenv("ADF_GEMM_W8"); w8 = e ? atoi(e) : 0; }
+      if (w8 && tm == 128 && tn == 128) return launch_variant<T, 2, 1, 2, 4>(a, s); }
     if (tm == 128 && tn == 128) return launch_variant<T, 2, 2, 2, 2>(a, s);
     if (tm == 128 && tn == 64) return launch_variant<T, 2, 1, 2, 2>(a, s);
     if (tm == 128 && tn == 32) return launch_variant<T, 1, 1, 4, 1>(a, s);

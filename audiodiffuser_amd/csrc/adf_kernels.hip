@@ -493,35 +493,45 @@ __global__ void __launch_bounds__(256) to_out_kernel(const T* __restrict__ h, co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int halo = (wl + stride - 1) / stride;
     float* ws = (float*)smem;              // [nf][wl]   (for this output channel)
-    float* P = ws + nf * wl;               // [R + 2*halo][wl]
+    float* P = ws + nf * wl;               // [R + 2*halo][wl] tap products of every staged feature row
     const int b = blockIdx.y, oc = blockIdx.z;
     for (int i = threadIdx.x; i < nf * wl; i += 256) {
         const int k = i % wl, ci = i / wl;
         ws[i] = w[((size_t)ci * out_ch + oc) * wl + k];
     }
     __syncthreads();
+    // coalesced: cpr consecutive lanes read the cpr 16-byte chunks of one feature row, each forms the tap
+    // products of its EPC channels, and a shuffle tree over the cpr lanes sums them
+    const int cpr = nf / EPC;              // power of two <= 64 (checked by the launcher)
+    const int cc = threadIdx.x % cpr, rsub = threadIdx.x / cpr, rstep = 256 / cpr;
     const int i0 = blockIdx.x * R - halo;
     const int nrows = R + 2 * halo;
-    for (int rr = threadIdx.x; rr < nrows; rr += 256) {
+    const int niter = (nrows + rstep - 1) / rstep;                    // same trip count for every lane (shuffles inside)
+    for (int itr = 0; itr < niter; ++itr) {
+        const int rr = rsub + itr * rstep;
         const int i = i0 + rr;
+        const bool rok = rr < nrows && i >= 0 && i < Lh;
         float p[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) p[k] = 0.f;
-        if (i >= 0 && i < Lh) {
-            const T* row = h + ((size_t)b * Lh + i) * nf;
-            for (int c = 0; c < nf; c += EPC) {
-                float f[EPC];
-                unpack16<T>(*(const u32x4_t*)(row + c), f);
+        if (rok) {
+            float f[EPC];
+            unpack16<T>(*(const u32x4_t*)(h + ((size_t)b * Lh + i) * nf + (size_t)cc * EPC), f);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float* wr = ws + (c + e) * wl;
+            for (int e = 0; e < EPC; ++e) {
+                const float* wr = ws + (cc * EPC + e) * wl;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) if (k < wl) p[k] = fmaf(f[e], wr[k], p[k]);
-                }
+                for (int k = 0; k < 16; ++k) if (k < wl) p[k] = fmaf(f[e], wr[k], p[k]);
             }
         }
+        for (int o = 1; o < cpr; o <<= 1) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) if (k < wl) P[rr * wl + k] = p[k];
+            for (int k = 0; k < 16; ++k) if (k < wl) p[k] += __shfl_xor(p[k], o, 64);
+        }
+        if (cc == 0 && rr < nrows) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (k < wl) P[rr * wl + k] = p[k];
+        }
     }
     __syncthreads();
     const int L = Lh * stride;
@@ -554,6 +564,7 @@ const char* launch_to_out(const void* h, const float* w, float* out, int bf16, i
     const int epc = bf16 ? 8 : 4;
     if (nf % epc) return "to_out: num_filters must be a multiple of a 16-byte chunk";
     if (wl > 16) return "to_out: window_length > 16 unsupported";
+    { const int cpr = nf / epc; if (cpr > 64 || (cpr & (cpr - 1))) return "to_out: num_filters / chunk must be a power of two <= 64"; }
     const int halo = (wl + stride - 1) / stride;
     const size_t lds = ((size_t)nf * wl + (size_t)(256 + 2 * halo) * wl) * sizeof(float);
     dim3 grid(ceil_div(Lh, 256), B, out_ch);
