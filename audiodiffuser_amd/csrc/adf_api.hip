@@ -323,20 +323,19 @@ struct Walker {
         if (ctot != r.cin) check("resblock: channel mismatch");
         double* s0 = ensure_stats(x);
         double* s1 = skip ? ensure_stats(*skip) : nullptr;
-        float* ab1 = (float*)alloc((size_t)B * ctot * 2 * 4);
-        if (live()) {
-            GnFinalizeArgs f;
-            memset(&f, 0, sizeof(f));
-            f.stats0 = s0; f.stats1 = s1; f.c0 = x.C; f.c1 = skip ? skip->C : 0; f.L = x.L; f.G = G; f.B = B;
-            f.scale1 = sscale; f.eps = 1e-5f; f.gamma = r.g1w; f.beta = r.g1b; f.film = nullptr; f.ab = ab1;
-            check(launch_gn_finalize(f, s));
-        }
         const bool short_level = x.L <= 64 && (x.L & (x.L - 1)) == 0;
+        float* ab1 = (float*)alloc((size_t)B * ctot * 2 * 4);
+        GnFinalizeArgs f1;
+        memset(&f1, 0, sizeof(f1));
+        f1.stats0 = s0; f1.stats1 = s1; f1.c0 = x.C; f1.c1 = skip ? skip->C : 0; f1.L = x.L; f1.G = G; f1.B = B;
+        f1.scale1 = sscale; f1.eps = 1e-5f; f1.gamma = r.g1w; f1.beta = r.g1b; f1.film = nullptr; f1.ab = ab1;
+        if (live() && !short_level) check(launch_gn_finalize(f1, s));
         Act h1 = new_act(r.cout, x.L);
         GemmArgs g1 = gemm_base(h1, x.L, x.L, r.c1);
         if (short_level) {
+            // short levels: one launch normalises + activates the (concatenated) input; the GEMM then takes raw tiles
             Act a1 = new_act(ctot, x.L);
-            if (live()) check(launch_gn_apply(x.p, skip ? skip->p : nullptr, x.C, skip ? skip->C : 0, x.L, B, ab1, 1, a1.p, h->bf16, s));
+            if (live()) check(launch_gn_norm_apply(x.p, skip ? skip->p : nullptr, f1, 1, a1.p, h->bf16, s));
             g1.seg[0] = seg_of(a1, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, r.c1);
         } else {
             g1.seg[0] = seg_of(x, skip, ab1, sscale, 1, 3, 1, -1, 1, r.c1);
@@ -344,19 +343,17 @@ struct Walker {
         run_gemm(g1, h1, true);
         double* sh = ensure_stats(h1);
         float* ab2 = (float*)alloc((size_t)B * r.cout * 2 * 4);
-        if (live()) {
-            GnFinalizeArgs f;
-            memset(&f, 0, sizeof(f));
-            f.stats0 = sh; f.c0 = r.cout; f.L = x.L; f.G = G; f.B = B; f.scale1 = 1.f; f.eps = 1e-5f;
-            f.gamma = r.g2w; f.beta = r.g2b;
-            f.film = p->film + r.film_off; f.film_bstride = nb == 1 ? 0 : h->film_total; f.ab = ab2;
-            check(launch_gn_finalize(f, s));
-        }
+        GnFinalizeArgs f2;
+        memset(&f2, 0, sizeof(f2));
+        f2.stats0 = sh; f2.c0 = r.cout; f2.L = x.L; f2.G = G; f2.B = B; f2.scale1 = 1.f; f2.eps = 1e-5f;
+        f2.gamma = r.g2w; f2.beta = r.g2b;
+        f2.film = p->film + r.film_off; f2.film_bstride = nb == 1 ? 0 : h->film_total; f2.ab = ab2;
+        if (live() && !short_level) check(launch_gn_finalize(f2, s));
         Act y = new_act(r.cout, x.L);
         GemmArgs g2 = gemm_base(y, x.L, x.L, r.c2);
         if (short_level) {
             Act a2 = new_act(r.cout, x.L);
-            if (live()) check(launch_gn_apply(h1.p, nullptr, r.cout, 0, x.L, B, ab2, 1, a2.p, h->bf16, s));
+            if (live()) check(launch_gn_norm_apply(h1.p, nullptr, f2, 1, a2.p, h->bf16, s));
             g2.seg[0] = seg_of(a2, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, r.c2);
         } else {
             g2.seg[0] = seg_of(h1, nullptr, ab2, 1.f, 1, 3, 1, -1, 1, r.c2);

@@ -25,6 +25,9 @@ const char* launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
 const char* launch_gn_apply(const void* s0, const void* s1, int c0, int c1, int L, int B, const float* ab, int act, void* out,
                             int bf16, hipStream_t s);
 
+// gn_finalize + gn_apply fused (short levels): out = act(GroupNorm/FiLM affine of [src0 ; scale1*src1]).
+const char* launch_gn_norm_apply(const void* s0, const void* s1, const GnFinalizeArgs& a, int act, void* out, int bf16, hipStream_t s);
+
 // Row LayerNorm over the channel (last) dim of an NLC tensor; beta may be null (gain only).
 const char* launch_ln_rows(const void* x, void* y, int bf16, long long rows, int C, const float* gamma,
                            const float* beta, float eps, hipStream_t s);

@@ -143,6 +143,73 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ s0,
     *(u32x4_t*)(out + ((size_t)b * L + l) * ctot + c) = pack16<T>(f);
 }
 
+// gn_finalize + gn_apply in one launch for the short levels: every thread derives the affine of its own
+// channels straight from the statistics (the work is tiny, the point is one launch less per GroupNorm).
+template <typename T>
+__global__ void __launch_bounds__(256) gn_norm_apply_kernel(const T* __restrict__ s0, const T* __restrict__ s1, const GnFinalizeArgs a,
+                                                            int act, T* __restrict__ out) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    const int b = blockIdx.y;
+    const int ctot = a.c0 + a.c1, cpr = ctot / EPC;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.L * cpr) return;
+    const int cc = (int)(idx % cpr);
+    const int l = (int)(idx / cpr);
+    const int c = cc * EPC;
+    const bool from1 = c >= a.c0;
+    const T* src = from1 ? s1 + ((size_t)b * a.L + l) * a.c1 + (c - a.c0) : s0 + ((size_t)b * a.L + l) * a.c0 + c;
+    float f[EPC];
+    unpack16<T>(*(const u32x4_t*)src, f);
+    const int gs = ctot / a.G;
+    const double* st = from1 ? a.stats1 : a.stats0;
+    const int csrc = from1 ? a.c1 : a.c0;
+    const int fg = csrc / a.G;
+    const double sc = from1 ? (double)a.scale1 : 1.0;
+    const double cnt = (double)a.L * (double)gs;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int ch = c + e;
+        const int cstart = (ch / gs) * gs;
+        const int lc = from1 ? cstart - a.c0 : cstart;
+        const int g0 = lc / fg, g1 = (lc + gs + fg - 1) / fg;
+        double sum = 0.0, sq = 0.0;
+        for (int g = g0; g < g1; ++g) { sum += st[((size_t)b * a.G + g) * 2]; sq += st[((size_t)b * a.G + g) * 2 + 1]; }
+        sum *= sc; sq *= sc * sc;
+        const double mean = sum / cnt;
+        double var = sq / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        float A = rstd * a.gamma[ch];
+        float Bc = a.beta[ch] - (float)mean * A;
+        if (a.film) {
+            const float fs = a.film[(size_t)b * a.film_bstride + ch] + 1.0f;
+            const float fh = a.film[(size_t)b * a.film_bstride + ctot + ch];
+            A *= fs;
+            Bc = fmaf(Bc, fs, fh);
+        }
+        if (from1) A *= a.scale1;
+        const float v = fmaf(f[e], A, Bc);
+        f[e] = act ? silu_f(v) : v;
+    }
+    *(u32x4_t*)(out + ((size_t)b * a.L + l) * ctot + c) = pack16<T>(f);
+}
+
+const char* launch_gn_norm_apply(const void* s0, const void* s1, const GnFinalizeArgs& a, int act, void* out, int bf16, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    const int ctot = a.c0 + a.c1;
+    if (a.c0 % epc || a.c1 % epc) return "gn_norm_apply: channel counts must be multiples of a 16-byte chunk";
+    if (ctot % a.G) return "gn_norm_apply: channels not divisible by groups";
+    const int gs = ctot / a.G;
+    if (a.c0 % gs) return "gn_norm_apply: a group straddles the two concatenated sources";
+    if (a.c0 % a.G || (a.c1 && a.c1 % a.G)) return "gn_norm_apply: source channels not divisible by groups";
+    if (gs % (a.c0 / a.G) || (a.c1 && gs % (a.c1 / a.G))) return "gn_norm_apply: group size not a multiple of the stored group size";
+    const long long work = (long long)a.L * (ctot / epc);
+    dim3 grid((unsigned)((work + 255) / 256), a.B);
+    if (bf16) hipLaunchKernelGGL(gn_norm_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)s0, (const bf16_t*)s1, a, act, (bf16_t*)out);
+    else hipLaunchKernelGGL(gn_norm_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)s0, (const float*)s1, a, act, (float*)out);
+    return ADF_LAUNCH_CHECK("gn_norm_apply");
+}
+
 const char* launch_gn_apply(const void* s0, const void* s1, int c0, int c1, int L, int B, const float* ab, int act, void* out,
                             int bf16, hipStream_t s) {
     const int epc = bf16 ? 8 : 4;
