@@ -560,45 +560,35 @@ __global__ void __launch_bounds__(256) to_out_kernel(const T* __restrict__ h, co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int halo = (wl + stride - 1) / stride;
     float* ws = (float*)smem;              // [nf][wl]   (for this output channel)
-    float* P = ws + nf * wl;               // [R + 2*halo][wl] tap products of every staged feature row
+    float* P = ws + nf * wl;               // [R + 2*halo][wl]
     const int b = blockIdx.y, oc = blockIdx.z;
     for (int i = threadIdx.x; i < nf * wl; i += 256) {
         const int k = i % wl, ci = i / wl;
         ws[i] = w[((size_t)ci * out_ch + oc) * wl + k];
     }
     __syncthreads();
-    // coalesced: cpr consecutive lanes read the cpr 16-byte chunks of one feature row, each forms the tap
-    // products of its EPC channels, and a shuffle tree over the cpr lanes sums them
-    const int cpr = nf / EPC;              // power of two <= 64 (checked by the launcher)
-    const int cc = threadIdx.x % cpr, rsub = threadIdx.x / cpr, rstep = 256 / cpr;
     const int i0 = blockIdx.x * R - halo;
     const int nrows = R + 2 * halo;
-    const int niter = (nrows + rstep - 1) / rstep;                    // same trip count for every lane (shuffles inside)
-    for (int itr = 0; itr < niter; ++itr) {
-        const int rr = rsub + itr * rstep;
+    for (int rr = threadIdx.x; rr < nrows; rr += 256) {
         const int i = i0 + rr;
-        const bool rok = rr < nrows && i >= 0 && i < Lh;
         float p[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) p[k] = 0.f;
-        if (rok) {
-            float f[EPC];
-            unpack16<T>(*(const u32x4_t*)(h + ((size_t)b * Lh + i) * nf + (size_t)cc * EPC), f);
+        if (i >= 0 && i < Lh) {
+            const T* row = h + ((size_t)b * Lh + i) * nf;
+            for (int c = 0; c < nf; c += EPC) {
+                float f[EPC];
+                unpack16<T>(*(const u32x4_t*)(row + c), f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float* wr = ws + (cc * EPC + e) * wl;
+                for (int e = 0; e < EPC; ++e) {
+                    const float* wr = ws + (c + e) * wl;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) if (k < wl) p[k] = fmaf(f[e], wr[k], p[k]);
+                    for (int k = 0; k < 16; ++k) if (k < wl) p[k] = fmaf(f[e], wr[k], p[k]);
+                }
             }
         }
-        for (int o = 1; o < cpr; o <<= 1) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (k < wl) p[k] += __shfl_xor(p[k], o, 64);
-        }
-        if (cc == 0 && rr < nrows) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) if (k < wl) P[rr * wl + k] = p[k];
-        }
+        for (int k = 0; k < 16; ++k) if (k < wl) P[rr * wl + k] = p[k];
     }
     __syncthreads();
     const int L = Lh * stride;
@@ -625,16 +615,101 @@ __global__ void __launch_bounds__(256) to_out_kernel(const T* __restrict__ h, co
     }
 }
 
+// bf16 fast path: the tap products P[row][k] = sum_ci h[row][ci] * w[ci][k] are a skinny GEMM
+// (rows x nf) x (nf x wl<=32) done on MFMA with the A fragments loaded straight from global memory
+// (lane = row, 16 bytes = 8 consecutive channels: exactly the 32x32x16 A-operand layout, no LDS staging).
+typedef __attribute__((ext_vector_type(8))) __bf16 to_bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float to_f32x16_t;
+__global__ void __launch_bounds__(256) to_out_mfma_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w, float* __restrict__ out,
+                                                          int out_ch, int Lh, int nf, int wl, int stride, int pad, int mode,
+                                                          const float* __restrict__ x_noisy, const float* __restrict__ coef,
+                                                          int coef_bstride) {
+    constexpr int R = 256;                 // feature rows owned by a block
+    constexpr int MAXKS = 8;               // nf <= 128
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = (wl + stride - 1) / stride;
+    float* P = (float*)smem;               // [ceil32(R + 2*halo)][wl]
+    const int b = blockIdx.y, oc = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ksteps = nf / 16;
+    // B operand: lane (r = tap column, hh) holds w[ci = 16 ks + 8 hh + j][oc][tap r]
+    to_bf16x8_t bf[MAXKS];
+#pragma unroll
+    for (int ks = 0; ks < MAXKS; ++ks) {
+        u32x4_t q = u32x4_t{0u, 0u, 0u, 0u};
+        if (ks < ksteps && r < wl) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = w[((size_t)(16 * ks + 8 * hh + j) * out_ch + oc) * wl + r];
+            q = pack16<bf16_t>(f);
+        }
+        bf[ks] = __builtin_bit_cast(to_bf16x8_t, q);
+    }
+    const int i0 = blockIdx.x * R - halo;
+    const int nrows = R + 2 * halo;
+    const int ntile = (nrows + 31) / 32;
+    for (int t = wave; t < ntile; t += 4) {
+        const int i = i0 + t * 32 + r;                       // this lane's feature row (A operand row)
+        const int ic = i < 0 ? 0 : (i >= Lh ? Lh - 1 : i);   // clamped: out-of-range rows are masked below
+        const bf16_t* row = h + ((size_t)b * Lh + ic) * nf + hh * 8;
+        to_f32x16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) {
+            if (ks < ksteps) {
+                const to_bf16x8_t af = __builtin_bit_cast(to_bf16x8_t, *(const u32x4_t*)(row + ks * 16));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[ks], acc, 0, 0, 0);
+            }
+        }
+        if (r < wl) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int ii = i0 + rr;
+                if (rr < nrows) P[rr * wl + r] = (ii >= 0 && ii < Lh) ? acc[e] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int L = Lh * stride;
+    const int l0 = blockIdx.x * R * stride;
+    float c_skip = 0.f, c_out = 1.f;
+    if (mode == 1) { c_skip = coef[(size_t)b * coef_bstride + 2]; c_out = coef[(size_t)b * coef_bstride + 3]; }
+    for (int t = threadIdx.x; t < R * stride; t += 256) {
+        const int l = l0 + t;
+        if (l >= L) break;
+        float acc = 0.f;
+        const int k0 = (l + pad) % stride;
+        for (int k = k0; k < wl; k += stride) {
+            const int i = (l + pad - k) / stride;
+            if (i >= 0 && i < Lh && (l + pad - k) >= 0) acc += P[(i - i0) * wl + k];
+        }
+        const size_t o = ((size_t)b * out_ch + oc) * L + l;
+        float v = acc;
+        if (mode == 1) {
+            v = fmaf(c_skip, x_noisy[o], c_out * acc);
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+        }
+        out[o] = v;
+    }
+}
+
 const char* launch_to_out(const void* h, const float* w, float* out, int bf16, int B, int out_ch, int Lh, int nf,
                           int wl, int stride, int pad, int mode, const float* x_noisy, const float* coef,
                           int coef_bstride, hipStream_t s) {
     const int epc = bf16 ? 8 : 4;
     if (nf % epc) return "to_out: num_filters must be a multiple of a 16-byte chunk";
     if (wl > 16) return "to_out: window_length > 16 unsupported";
-    { const int cpr = nf / epc; if (cpr > 64 || (cpr & (cpr - 1))) return "to_out: num_filters / chunk must be a power of two <= 64"; }
     const int halo = (wl + stride - 1) / stride;
-    const size_t lds = ((size_t)nf * wl + (size_t)(256 + 2 * halo) * wl) * sizeof(float);
     dim3 grid(ceil_div(Lh, 256), B, out_ch);
+    if (bf16 && nf % 16 == 0 && nf <= 128) {
+        const size_t lds = (size_t)round_up(256 + 2 * halo, 32) * wl * sizeof(float);
+        hipLaunchKernelGGL(to_out_mfma_kernel, grid, dim3(256), lds, s, (const bf16_t*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
+        return ADF_LAUNCH_CHECK("to_out_mfma");
+    }
+    const size_t lds = ((size_t)nf * wl + (size_t)(256 + 2 * halo) * wl) * sizeof(float);
     if (bf16) hipLaunchKernelGGL(to_out_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
     else hipLaunchKernelGGL(to_out_kernel<float>, grid, dim3(256), lds, s, (const float*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
     return ADF_LAUNCH_CHECK("to_out");
