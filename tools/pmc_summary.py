@@ -18,5 +18,6 @@ for d in sys.argv[1:]:
         for c, v in e.items():
             if isinstance(v, float): o[c].append(v)
 for key, o in out.items():
-    if int(key[1]) < 200000: continue
+    import os
+    if int(key[1]) < int(os.environ.get("PMC_MIN_GRID", "200000")): continue
     print(key, {c: round(sum(v[-3:]) / len(v[-3:]), 1) for c, v in o.items()}, 'n=', max(len(v) for v in o.values()))
