@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadf_hip.so")
 SOURCES = ["adf_gemm.hip", "adf_kernels.hip", "adf_api.hip"]
-HEADERS = ["adf_common.h", "adf_gemm.h", "adf_kernels.h", os.path.join("..", "..", "include", "audiodiffuser_amd.h")]
+HEADERS = ["adf_common.h", "adf_gemm.h", "adf_gemm_pp.h", "adf_kernels.h", os.path.join("..", "..", "include", "audiodiffuser_amd.h")]
 ARCH = "gfx950"
 
 

@@ -1,5 +1,7 @@
 // Tile-shape dispatch for the fused implicit-GEMM kernel (see adf_gemm.h).
 #include "adf_gemm.h"
+#include "adf_gemm_pp.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace adf {
@@ -81,6 +83,49 @@ const char* launch_wsd(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_wsd: launch failed";
 }
 
+
+// Software-pipelined persistent 256 x 128 kernel (adf_gemm_pp.h): one 512-thread block per CU.
+const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    static int num_cu = 0;
+    auto kern = conv_gemm_pp_kernel;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess)
+            return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, pp) failed";
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu < 1)
+            num_cu = 256;
+        attr_set = true;
+    }
+    const int tiles_m = a.mrows / kPpTM, tiles_n = a.n_pad / kPpTN;
+    int tm_shift = 0, tn_shift = 0;
+    while ((1 << tm_shift) < tiles_m) ++tm_shift;
+    while ((1 << tn_shift) < tiles_n) ++tn_shift;
+    const long long tiles_total = (long long)a.B * tiles_m * tiles_n;
+    if (tiles_total <= 0 || tiles_total > 0x7fffffffLL) return "conv_gemm_pp: bad tile count";
+    const long long grid = tiles_total < num_cu ? tiles_total : num_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kPpLds, stream, a, (int)tiles_total, tm_shift, tn_shift);
+    return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_pp: launch failed";
+}
+
+// shapes the pipelined kernel is written for (see the header of adf_gemm_pp.h)
+bool pp_eligible(const GemmArgs& a) {
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (a.scatter_f || a.gelu || a.res || a.mrows % kPpTM || a.lin != a.mrows || a.out_rows != a.mrows) return false;
+    if (a.n != a.n_pad || a.out_c != a.n || a.n_pad % kPpTN || a.n_pad > kPpMaxN) return false;
+    if (!pow2(a.mrows / kPpTM) || !pow2(a.n_pad / kPpTN)) return false;
+    int nsteps = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const GemmSeg& g = a.seg[s];
+        if (g.stride != 1 || g.step != 1) return false;
+        if (!((g.taps == 3 && g.off0 == -1) || (g.taps == 1 && g.off0 == 0))) return false;
+        if (g.c0 % 32 || g.c1 % 32 || g.c0 + g.c1 > kPpMaxCin) return false;
+        if (s == 1 && (g.ab || g.act)) return false;
+        nsteps += (g.c0 + g.c1) / 32;
+    }
+    return nsteps >= 4;
+}
+
 template <typename T>
 const char* launch_ksplit(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 4 * kKsWaveLds;
@@ -115,6 +160,18 @@ const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
 }
 
 }  // namespace
+
+// ADF_GEMM_TRACE=1: print the kernel chosen for every launch (stderr)
+static void trace_route(const char* route, const GemmArgs& a, int tm, int tn) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ADF_GEMM_TRACE"); on = e ? atoi(e) : 0; }
+    if (!on) return;
+    fprintf(stderr, "[adf gemm] %-6s B=%d lin=%d mrows=%d n=%d/%d nseg=%d seg0(c=%d+%d taps=%d stride=%d off0=%d step=%d ab=%d act=%d)", route, a.B, a.lin, a.mrows,
+            a.n, a.n_pad, a.nseg, a.seg[0].c0, a.seg[0].c1, a.seg[0].taps, a.seg[0].stride, a.seg[0].off0, a.seg[0].step, a.seg[0].ab != nullptr, a.seg[0].act);
+    if (a.nseg > 1) fprintf(stderr, " seg1(c=%d+%d taps=%d ab=%d)", a.seg[1].c0, a.seg[1].c1, a.seg[1].taps, a.seg[1].ab != nullptr);
+    fprintf(stderr, " res=%d gelu=%d scatter=%d out=%dx%d stats=%d flat=%d tile=%dx%d\n", a.res != nullptr, a.gelu, a.scatter_f, a.out_rows, a.out_c, a.stats != nullptr,
+            a.flat, tm, tn);
+}
 
 const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t stream, bool* stats_fused) {
     GemmArgs a = a_in;
@@ -208,7 +265,31 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                 a.stats = ok ? a_in.stats : nullptr;
                 if (stats_fused) *stats_fused = ok;
             }
+            trace_route("ksplit", a, 32, 32);
             return dtype_bf16 ? launch_ksplit<bf16_t>(a, stream) : launch_ksplit<float>(a, stream);
+        }
+    }
+    {
+        // large stride-1 bf16 layers: software-pipelined persistent 256 x 128 kernel
+        static int use_pp = -1;
+        if (use_pp < 0) { const char* e = getenv("ADF_GEMM_PP"); use_pp = e ? atoi(e) : 0; }
+        if (use_pp && dtype_bf16 && !flat && tm == 128 && pp_eligible(a)) {
+            const long long tiles = (long long)a.B * (a.mrows / kPpTM) * (a.n_pad / kPpTN);
+            bool take = tiles >= 128;
+            if (take && use_pp < 2) {     // 1: only where the weights cannot stay resident in LDS (weight-stationary kernel otherwise)
+                bool ws_shape = (long long)((a.mrows + 127) / 128) * a.B >= 256 && ws_lds_bytes(a, 128) <= 160 * 1024;
+                if (ws_shape) take = false;
+            }
+            if (take) {
+                if (a_in.stats) {
+                    const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
+                    const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64;
+                    a.stats = ok ? a_in.stats : nullptr;
+                    if (stats_fused) *stats_fused = ok;
+                }
+                trace_route("pp", a, 256, 128);
+                return launch_pp(a, stream);
+            }
         }
     }
     {
@@ -233,6 +314,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                     a.stats = ok ? a_in.stats : nullptr;
                     if (stats_fused) *stats_fused = ok;
                 }
+                trace_route("ws", a, 128, wtn);
                 if (wtn == 128) return dtype_bf16 ? launch_ws_variant<bf16_t, 2, 2>(a, stream) : launch_ws_variant<float, 2, 2>(a, stream);
                 return dtype_bf16 ? launch_ws_variant<bf16_t, 1, 2>(a, stream) : launch_ws_variant<float, 1, 2>(a, stream);
             }
@@ -249,10 +331,12 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                     a.stats = ok ? a_in.stats : nullptr;
                     if (stats_fused) *stats_fused = ok;
                 }
+                trace_route("wsd", a, 128, 128);
                 return dtype_bf16 ? launch_wsd<bf16_t>(a, stream) : launch_wsd<float>(a, stream);
             }
         }
     }
+    trace_route("plain", a, tm, tn);
     return dtype_bf16 ? dispatch<bf16_t>(a, tm, tn, stream) : dispatch<float>(a, tm, tn, stream);
 }
 

@@ -13,7 +13,8 @@ out = {}
 for d in sys.argv[1:]:
     for k, e in load(d).items():
         if 'conv_gemm' not in e['name']: continue
-        key = (e['name'].split('<')[1].split('>')[0], e['grid'])
+        nm = e['name']
+        key = ((nm.split('(')[0].split('::')[-1].split('<')[0] + ' ' + (nm.split('<')[1].split('>')[0] if '<' in nm else '')).strip(), e['grid'])
         o = out.setdefault(key, collections.defaultdict(list))
         for c, v in e.items():
             if isinstance(v, float): o[c].append(v)
