@@ -219,7 +219,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         return tmn * ((a.n_pad + tn_ - 1) / tn_);
     };
     static int min_blocks = -1;
-    if (min_blocks < 0) { const char* e = getenv("ADF_GEMM_MINBLOCKS"); min_blocks = e ? atoi(e) : 256; }
+    if (min_blocks < 0) { const char* e = getenv("ADF_GEMM_MINBLOCKS"); min_blocks = e ? atoi(e) : 512; }
     while (nblocks(tm, tn) < min_blocks && tn > 32) tn >>= 1;
     while (nblocks(tm, tn) < min_blocks && tm > 32) {
         tm >>= 1;

@@ -201,3 +201,34 @@ def test_config3_attention_at_1024_tokens_vs_oracle():
     with torch.no_grad():
         yo = O.unet1d_forward(w, cfg, x, t)
     assert rel_err(y.cpu(), yo) < FP32_TIGHT
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
+def test_config2_batch8_every_layer_large_tile_routes(dtype, tol):
+    """BASELINE config 2 at batch 8, full length: >= 256 row tiles per layer, the size from which the launcher picks
+    the persistent weight-stationary / weight-streaming GEMM kernels.  Every recorded layer against the oracle."""
+    x = generate_noise(0, 8, 16384) * 0.7
+    errs, y, yo = tap_errors(A.config_c2(), x, torch.linspace(-1.0, 0.5, 8), dtype, 0)
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, bad
+
+
+def test_pipelined_dma_gemm_route_matches_default_route(tmp_path):
+    """The LDS-DMA pipelined GEMM kernel (adf_gemm_pp.h, opt-in with ADF_GEMM_PP) against the default routing on
+    the same bf16 network and inputs: the route is read once per process, so each side runs in a child process."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for pp in ("0", "2"):
+        path = str(tmp_path / f"pp{pp}.pt")
+        env = dict(os.environ, ADF_GEMM_PP=pp)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[pp] = torch.load(path)
+    a, b = outs["2"], outs["0"]
+    assert all(bool(torch.isfinite(v).all()) for v in a.values())
+    rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
+    # first resblock after the switch: only the accumulation order differs; end of the net: bf16 rounding noise compounds
+    assert rel("down0.block0") < 1e-3, rel("down0.block0")
+    assert rel("out") < 3e-2, rel("out")
