@@ -60,7 +60,7 @@ struct GemmArgs {
     int scatter_f, scatter_pad;  // transposed conv: n = phase*out_c + co -> row m*f + phase - pad
     double* stats;       // optional [B][stats_groups][2] (sum, sumsq) of the produced tensor
     int stats_groups;
-    int dbg;             // timing experiments only (ADF_GEMM_DBG): 1 skip stores, 2 skip prologue math, 4 skip MFMA, 8 skip stats
+    int dbg;             // timing experiments only (ADF_GEMM_DBG): 1 skip stores, 2 skip prologue math, 4 skip MFMA, 8 skip stats; pp kernel: 32 skip weight DMA, 64 skip activation DMA, 128 skip barriers
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void mfma_chunk_bf16(f32x16_t (&acc)[MT][NT], int h, 
 }
 
 template <typename T, int MT, int NT, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 1)) conv_gemm_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs a) {
     constexpr int TM = 32 * MT * WM, TN = 32 * NT * WN, NTHR = 64 * WM * WN;
     constexpr int EPC = Elem<T>::kPerChunk;
     constexpr int KC = kRowBytes / (int)sizeof(T);

@@ -3,6 +3,7 @@
 #include "adf_gemm_pp.h"
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace adf {
 
@@ -108,22 +109,42 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_pp: launch failed";
 }
 
-// shapes the pipelined kernel is written for (see the header of adf_gemm_pp.h)
+// shapes the pipelined kernel is written for (see the header of adf_gemm_pp.h); an identity residual counts as a
+// second segment
 bool pp_eligible(const GemmArgs& a) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (a.scatter_f || a.gelu || a.res || a.mrows % kPpTM || a.lin != a.mrows || a.out_rows != a.mrows) return false;
+    if (a.scatter_f || a.gelu || a.mrows % kPpTM || a.lin != a.mrows || a.out_rows != a.mrows) return false;
     if (a.n != a.n_pad || a.out_c != a.n || a.n_pad % kPpTN || a.n_pad > kPpMaxN) return false;
     if (!pow2(a.mrows / kPpTM) || !pow2(a.n_pad / kPpTN)) return false;
-    int nsteps = 0;
+    if (a.res && a.nseg > 1) return false;
+    int nb = a.res ? a.n / 64 : 0;
     for (int s = 0; s < a.nseg; ++s) {
         const GemmSeg& g = a.seg[s];
         if (g.stride != 1 || g.step != 1) return false;
         if (!((g.taps == 3 && g.off0 == -1) || (g.taps == 1 && g.off0 == 0))) return false;
-        if (g.c0 % 32 || g.c1 % 32 || g.c0 + g.c1 > kPpMaxCin) return false;
+        if (g.c0 % 64 || g.c1 % 64 || g.c0 + g.c1 > kPpMaxCin) return false;
         if (s == 1 && (g.ab || g.act)) return false;
-        nsteps += (g.c0 + g.c1) / 32;
+        nb += (g.c0 + g.c1) / 64;
     }
-    return nsteps >= 4;
+    return nb >= 2;
+}
+
+// packed bf16 identity [n/64 chunks][1 tap][n rows][64 channels]: row r of chunk c holds 1.0 at channel r - 64 c
+const void* pp_identity(int n, hipStream_t stream, const char** err) {
+    static void* cache[kPpMaxN / 64 + 1] = {};
+    const int idx = n / 64;
+    if (cache[idx]) return cache[idx];
+    const size_t elems = (size_t)(n / 64 + kTapGroup) * n * 64;     // over-allocated like every packed weight
+    std::vector<uint16_t> hbuf(elems, 0);
+    for (int r = 0; r < n; ++r) hbuf[((size_t)(r / 64) * n + r) * 64 + (r % 64)] = 0x3F80;
+    void* d = nullptr;
+    if (hipMalloc(&d, elems * 2) != hipSuccess) { *err = "conv_gemm_pp: hipMalloc(identity) failed"; return nullptr; }
+    if (hipMemcpyAsync(d, hbuf.data(), elems * 2, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+        *err = "conv_gemm_pp: identity upload failed";
+        return nullptr;
+    }
+    cache[idx] = d;
+    return d;
 }
 
 template <typename T>
@@ -146,8 +167,6 @@ const char* launch_ksplit(const GemmArgs& a, hipStream_t stream) {
 
 template <typename T>
 const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
-    { static int w8 = -1; if (w8 < 0) { const char* e = getenv("ADF_GEMM_W8"); w8 = e ? atoi(e) : 0; }
-      if (w8 && tm == 128 && tn == 128) return launch_variant<T, 2, 1, 2, 4>(a, s); }
     if (tm == 128 && tn == 128) return launch_variant<T, 2, 2, 2, 2>(a, s);
     if (tm == 128 && tn == 64) return launch_variant<T, 2, 1, 2, 2>(a, s);
     if (tm == 128 && tn == 32) return launch_variant<T, 1, 1, 4, 1>(a, s);
@@ -286,6 +305,17 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                     const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64;
                     a.stats = ok ? a_in.stats : nullptr;
                     if (stats_fused) *stats_fused = ok;
+                }
+                if (a.res) {                     // identity residual = a raw 1-tap segment against the packed identity
+                    const char* err = nullptr;
+                    const void* ident = pp_identity(a.n, stream, &err);
+                    if (!ident) return err;
+                    GemmSeg& g = a.seg[1];
+                    g = GemmSeg{};
+                    g.src0 = a.res; g.src1 = nullptr; g.c0 = a.n; g.c1 = 0; g.ab = nullptr; g.scale1 = 1.0f; g.act = 0;
+                    g.taps = 1; g.stride = 1; g.off0 = 0; g.step = 1; g.w = ident; g.nchunk = a.n / 64;
+                    a.nseg = 2;
+                    a.res = nullptr;
                 }
                 trace_route("pp", a, 256, 128);
                 return launch_pp(a, stream);
