@@ -289,16 +289,15 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         }
     }
     {
-        // large stride-1 bf16 layers: software-pipelined persistent 256 x 128 kernel
+        // large stride-1 bf16 layers: persistent LDS-DMA 256 x 128 kernel (adf_gemm_pp.h).  Measured on MI355X
+        // (profiles/README.md): 12-20 % faster than the other routes where it applies by default -- >= 256 tiles and
+        // no identity residual (those layers keep their weights resident in the weight-stationary kernel, which wins).
+        // ADF_GEMM_PP=0 disables it, =2 also takes identity-residual layers and >= 128 tiles (used by the tests).
         static int use_pp = -1;
-        if (use_pp < 0) { const char* e = getenv("ADF_GEMM_PP"); use_pp = e ? atoi(e) : 0; }
+        if (use_pp < 0) { const char* e = getenv("ADF_GEMM_PP"); use_pp = e ? atoi(e) : 1; }
         if (use_pp && dtype_bf16 && !flat && tm == 128 && pp_eligible(a)) {
             const long long tiles = (long long)a.B * (a.mrows / kPpTM) * (a.n_pad / kPpTN);
-            bool take = tiles >= 128;
-            if (take && use_pp < 2) {     // 1: only where the weights cannot stay resident in LDS (weight-stationary kernel otherwise)
-                bool ws_shape = (long long)((a.mrows + 127) / 128) * a.B >= 256 && ws_lds_bytes(a, 128) <= 160 * 1024;
-                if (ws_shape) take = false;
-            }
+            const bool take = use_pp >= 2 ? tiles >= 128 : (tiles >= 256 && !a.res);
             if (take) {
                 if (a_in.stats) {
                     const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;

@@ -31,6 +31,7 @@
 // tile counts powers of two, at least 2 K blocks, no phase scatter / GELU.
 #pragma once
 #include "adf_gemm.h"
+#include <type_traits>
 
 namespace adf {
 
@@ -59,6 +60,32 @@ __device__ __forceinline__ void pp_dma16(const char* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// Four pieces with one M0 set-up: piece 0 copies from g0, piece i > 0 from g1 + (i-1) * gstep; piece i lands at lds_dst + i * 8 KB.
+__device__ __forceinline__ void pp_dma16x4(const char* g0, const char* g1, unsigned gstep, unsigned lds_dst) {
+    unsigned keep;
+    const char* g2 = g1 + gstep;
+    const char* g3 = g2 + gstep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_dst) : "memory", "scc");
+}
+
+// wave-uniform description of one K block (64 channels of one segment) of one tile
+struct PpBlk {
+    const char* asrc;     // source tensor + byte offset of the block's first channel
+    const char* w;        // packed weights of (block, tap 0), column n0
+    unsigned rowbytes;    // bytes per row of the source tensor
+    unsigned rowbase;     // b0 * lin
+    int p_lo;             // position inside the sample of staged row 0 (m0 + off0)
+    int taps;
+    int tabofs;           // byte offset of the block's first channel inside the LDS affine table, or -1 = raw input
+    int act;
+    float scale;
+    int tseq, last;       // tile sequence number; last = the block is the last K block of its tile
+};
+
 __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int tiles_total, int tm_shift, int tn_shift) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,6 +97,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
+    const bool early = (wave & 4) == 0;            // waves w and w+4 share a SIMD: they run prologue and MFMAs in opposite order
     const int lrow = lane >> 3;                     // row inside an 8-row DMA piece
     // logical 16-byte chunk stored at this lane's slot: slot ^ ((row >> 1) & 7), row = 8 * piece + lrow, piece = wave + 8 i
     const int chunk = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
@@ -81,14 +109,13 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const int t_hi = (int)((long long)(bidx + 1) * tiles_total / nblk_grid);
     const int ntiles = t_hi - t_lo;
     if (ntiles <= 0) return;
-    if (a.dbg & 2048) return;
     const int ctot0 = a.seg[0].c0 + a.seg[0].c1;
     const int nb0 = ctot0 >> 6;                                              // 64-channel blocks of segment 0
     const int nb1 = a.nseg > 1 ? (a.seg[1].c0 + a.seg[1].c1) >> 6 : 0;
     const int nb = nb0 + nb1;                                                // K blocks per tile
-    const int taps0 = a.seg[0].taps, taps1 = a.nseg > 1 ? a.seg[1].taps : 1;
     const int GB = ntiles * nb;                                              // K blocks of this thread block
     const bool use_tab = a.seg[0].ab != nullptr;
+    const unsigned slab = (unsigned)a.n_pad * (unsigned)kRowBytes;           // one tap of packed weights
 
     auto geom = [&](int tseq, int& b0, int& m0, int& n0) __attribute__((always_inline)) {
         const int t = t_lo + tseq;
@@ -100,15 +127,32 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // wait until at most n of this wave's DMA instructions (the youngest ones) are still in flight
     auto wait_dma = [&](int n) __attribute__((always_inline)) {
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        }
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
+    auto desc = [&](int tseq, int blk) __attribute__((always_inline)) -> PpBlk {
+        const bool s1 = blk >= nb0;
+        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
+        const int bl = s1 ? blk - nb0 : blk;
+        const int cbase = bl * 64;
+        const bool from1 = sg.c1 > 0 && cbase >= sg.c0;                    // sources split at a multiple of 64
+        int b0, m0, n0;
+        geom(tseq, b0, m0, n0);
+        PpBlk d;
+        d.asrc = (from1 ? uniform_ptr(sg.src1) : uniform_ptr(sg.src0)) + (size_t)(cbase - (from1 ? sg.c0 : 0)) * 2;
+        d.w = uniform_ptr(sg.w) + ((size_t)(bl * sg.taps) * a.n_pad + n0) * kRowBytes;
+        d.rowbytes = (unsigned)(from1 ? sg.c1 : sg.c0) * 2u;
+        d.rowbase = (unsigned)(b0 * a.lin);
+        d.p_lo = m0 + sg.off0;
+        d.taps = sg.taps;
+        d.tabofs = (!s1 && use_tab) ? (tseq & 1) * kPpTab + cbase * 8 : -1;
+        d.act = sg.act;
+        d.scale = from1 ? sg.scale1 : 1.0f;
+        d.tseq = tseq;
+        d.last = blk == nb - 1;
+        return d;
     };
 
     // ---- block prologue (ordinary loads; the DMA pipeline starts after it) ---------------------------------
@@ -127,95 +171,63 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         if (tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b0 * ctot0 + tid * 2) * 2);
     }
     __syncthreads();
-    if (a.dbg & 1024) return;
 
-    // ---- DMA of the activations of K block (tseq, blk) into ring stage st: 4 pieces per wave (+ the halo piece
-    // in wave 0 of a 3-tap segment).  With the last block of a tile goes the affine table of the NEXT tile (two
-    // blocks before its first use is prepared).  Returns the number of DMA instructions this wave issued.
-    auto issue_a = [&](int tseq, int blk, int st, int part) __attribute__((always_inline)) -> int {
-        const bool s1 = blk >= nb0;
-        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
-        const int cbase = (s1 ? blk - nb0 : blk) * 64;
-        const bool halo = wave == 0 && sg.taps == 3;
-        const bool from1 = sg.c1 > 0 && cbase >= sg.c0;                    // uniform: sources split at a multiple of 64
-        const char* src = from1 ? uniform_ptr(sg.src1) : uniform_ptr(sg.src0);
-        const unsigned rowbytes = (unsigned)(from1 ? sg.c1 : sg.c0) * 2u;
-        const unsigned colbytes = (unsigned)(cbase - (from1 ? sg.c0 : 0)) * 2u + (unsigned)chunk * 16u;
-        int b0, m0, n0;
-        geom(tseq, b0, m0, n0);
-        const int p0 = m0 + sg.off0 + srow;                                 // input position of this lane's row, unit 0
-        const unsigned rowbase = (unsigned)(b0 * a.lin);
+    // ---- DMA of the activations of K block d into ring stage st: 4 pieces per wave (+ the halo piece in wave 0
+    // of a 3-tap block).  With the last block of a tile goes the affine table of the NEXT tile (two blocks before
+    // its first use is prepared).  Returns the number of DMA instructions this wave issued (0 / 4 / 5 / 6).
+    // part: 0 = pieces 0-1, 1 = pieces 2-3, 2 = halo + table, -1 = everything (pipeline fill)
+    auto issue_a = [&](const PpBlk& d, int st, int part) __attribute__((always_inline)) -> int {
+        const unsigned colbytes = (unsigned)chunk * 16u;
+        const int p0 = d.p_lo + srow;                                       // input position of this lane's row, unit 0
         const unsigned ldsA = (unsigned)(st * kPpAStage) + (unsigned)wave * 1024u;
-        // A 3-tap block is fetched in three parts, one per sub-step (pieces 0-1 | 2-3 | halo + next tile's table): the
-        // DMA queue returns in order, so a whole 33 KB block of HBM misses ahead of the next weight slab (L2 hits)
-        // would hold that slab back for ~3000 cycles.  part < 0 = everything at once (1-tap blocks, pipeline fill).
+        // only the first row of a tile (unit 0, p = -1) can be padding here; that lane fetches row 0 instead and is zeroed later
+        const char* g0 = d.asrc + ((long long)d.rowbase + p0) * (long long)d.rowbytes + colbytes;
+        const unsigned step = 64u * d.rowbytes;
         int n = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (part < 0 || part == (i >> 1)) {
-                const int p = p0 + i * 64;
+        if (part < 0) { pp_dma16x4(p0 < 0 ? g0 + d.rowbytes : g0, g0 + step, step, ldsA); n = 4; }
+        if (part == 0) { pp_dma16(p0 < 0 ? g0 + d.rowbytes : g0, ldsA); pp_dma16(g0 + step, ldsA + 8192u); n = 2; }
+        if (part == 1) { pp_dma16(g0 + 2 * step, ldsA + 16384u); pp_dma16(g0 + 3 * step, ldsA + 24576u); n = 2; }
+        if (part < 0 || part == 2) {
+            if (wave == 0 && d.taps == 3) {
+                const int p = d.p_lo + kPpTM + lrow;
                 const bool ok = p >= 0 && p < a.lin;
-                const unsigned off = ok ? (rowbase + (unsigned)p) * rowbytes + colbytes : 0u;   // padding rows: any address, zeroed later
-                pp_dma16(src + off, ldsA + (unsigned)i * 8192u);
-                ++n;
+                const unsigned off = ok ? (d.rowbase + (unsigned)p) * d.rowbytes + colbytes : 0u;
+                if (lane < 16) pp_dma16(d.asrc + off, (unsigned)(st * kPpAStage) + 32u * 1024u);
+                n += 1;
             }
-        }
-        if (halo && (part < 0 || part == 2)) {
-            const int p = m0 + sg.off0 + kPpTM + lrow;
-            const bool ok = p >= 0 && p < a.lin;
-            const unsigned off = ok ? (rowbase + (unsigned)p) * rowbytes + colbytes : 0u;
-            if (lane < 16) pp_dma16(src + off, (unsigned)(st * kPpAStage) + 32u * 1024u);
-            ++n;
-        }
-        if (use_tab && blk == nb - 1 && tseq + 1 < ntiles && (part < 0 || part == 2 || (part == 0 && sg.taps == 1))) {
-            geom(tseq + 1, b0, m0, n0);
-            const unsigned boff = (unsigned)wave * 1024u + lane_lds;
-            if ((unsigned)wave * 1024u < (unsigned)ctot0 * 8u) {             // wave-uniform: this wave owns a piece of the table
+            if (use_tab && d.last && d.tseq + 1 < ntiles && (unsigned)wave * 1024u < (unsigned)ctot0 * 8u) {
+                int b0, m0, n0;
+                geom(d.tseq + 1, b0, m0, n0);
+                const unsigned boff = (unsigned)wave * 1024u + lane_lds;
                 if (boff < (unsigned)ctot0 * 8u)
                     pp_dma16(uniform_ptr(a.seg[0].ab) + ((size_t)b0 * ctot0) * 8 + boff,
-                             (unsigned)(kPpOffTab + ((tseq + 1) & 1) * kPpTab) + (unsigned)wave * 1024u);
+                             (unsigned)(kPpOffTab + ((d.tseq + 1) & 1) * kPpTab) + (unsigned)wave * 1024u);
                 n += 1;
             }
         }
         return n;
     };
-    // ---- DMA of the weight slab of sub-step (tseq, blk, tap) into stage st: 2 pieces per wave --------------
-    auto issue_w = [&](int tseq, int blk, int tap, int st) __attribute__((always_inline)) {
-        const bool s1 = blk >= nb0;
-        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
-        const int bl = s1 ? blk - nb0 : blk;
-        int b0, m0, n0;
-        geom(tseq, b0, m0, n0);
-        const char* wp = uniform_ptr(sg.w) + ((size_t)(bl * sg.taps + tap) * a.n_pad + n0) * kRowBytes;
-        const char* wl = wp + (unsigned)srow * (unsigned)kRowBytes + (unsigned)chunk * 16u;
+    // ---- DMA of one weight slab (tap slab at wsrc) into W stage st: 2 pieces per wave ---------------------
+    const unsigned wlane = (unsigned)srow * (unsigned)kRowBytes + (unsigned)chunk * 16u;
+    auto issue_w = [&](const char* wsrc, int st) __attribute__((always_inline)) {
         const unsigned ldsW = (unsigned)(kPpOffW + st * kPpWStage) + (unsigned)wave * 1024u;
-        pp_dma16(wl, ldsW);
-        pp_dma16(wl + 64 * kRowBytes, ldsW + 8192u);
+        pp_dma16(wsrc + wlane, ldsW);
+        pp_dma16(wsrc + wlane + 64 * kRowBytes, ldsW + 8192u);
     };
 
-    // ---- fused prologue of K block (tseq, blk), in place on the chunks this wave fetched (stage st); zero padding
-    // for rows outside the sample.  Raw segments only need the zero fill (sample-edge tiles of a 3-tap segment).
-    auto transform = [&](int tseq, int blk, int st) __attribute__((always_inline)) {
-        const bool s1 = blk >= nb0;
-        const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
-        const int cbase = (s1 ? blk - nb0 : blk) * 64;
-        const bool with_tab = !s1 && use_tab;
-        const bool act = sg.act != 0 && !(a.dbg & 2);
-        const bool halo = wave == 0 && sg.taps == 3;
-        int b0, m0, n0;
-        geom(tseq, b0, m0, n0);
+    // ---- fused prologue of K block d, in place on the chunks this wave fetched (stage st); zero padding for rows
+    // outside the sample.  Raw blocks only need the zero fill (sample-edge tiles of a 3-tap block).
+    auto transform = [&](const PpBlk& d, int st) __attribute__((always_inline)) {
         char* const ldsA = smem + st * kPpAStage + wave * 1024 + lane_lds;
         char* const ldsH = smem + st * kPpAStage + 32 * 1024 + lane_lds;
-        const int p0 = m0 + sg.off0 + srow;
-        const int ph = m0 + sg.off0 + kPpTM + lrow;
-        const bool from1 = sg.c1 > 0 && cbase >= sg.c0;
-        const float scale = from1 ? sg.scale1 : 1.0f;
-        const bool math = with_tab || act || scale != 1.0f;                 // uniform
-        const bool edge = sg.taps == 3 && (m0 == 0 || m0 + kPpTM == a.lin); // uniform: a halo row is padding
-        if (math) {
+        const bool halo = wave == 0 && d.taps == 3;
+        const int p0 = d.p_lo + srow;
+        const int ph = d.p_lo + kPpTM + lrow;
+        const bool edge = d.taps == 3 && (d.p_lo < 0 || d.p_lo + kPpTM + 2 > a.lin);    // uniform: a halo row is padding
+        if (d.tabofs >= 0 || d.act || d.scale != 1.0f) {                   // uniform
             f32x2_t fa2[4], fb2[4];
-            if (with_tab) {
-                const f32x4_t* tp = (const f32x4_t*)(ldsTab + (tseq & 1) * kPpTab + (cbase + chunk * 8) * 8);
+            if (d.tabofs >= 0) {
+                const f32x4_t* tp = (const f32x4_t*)(ldsTab + d.tabofs + chunk * 64);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const f32x4_t t = tp[e];
@@ -224,35 +236,51 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { fa2[e] = f32x2_t{scale, scale}; fb2[e] = f32x2_t{0.f, 0.f}; }
+                for (int e = 0; e < 4; ++e) { fa2[e] = f32x2_t{d.scale, d.scale}; fb2[e] = f32x2_t{0.f, 0.f}; }
             }
-            auto unit = [&](char* addr, bool valid) __attribute__((always_inline)) {
-                const u32x4_t raw = *(const u32x4_t*)addr;
+            // 8-wide stages (all exps, then all adds, then all rcps ...) so the transcendentals of a chunk pipeline
+            // instead of forming one serial dependency chain per pair
+            auto math = [&](const u32x4_t& raw, auto actc) __attribute__((always_inline)) -> u32x4_t {
+                constexpr bool kAct = decltype(actc)::value;
                 float f[8];
                 unpack16<T>(raw, f);
+                f32x2_t v2[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
-                    f32x2_t v2 = x2 * fa2[e] + fb2[e];
-                    if (act) {
-                        const f32x2_t z2 = v2 * -1.4426950408889634f;
-                        f32x2_t d2 = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
-                        d2 = d2 + 1.0f;
-                        const f32x2_t r2 = {__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
-                        v2 = v2 * r2;
+                for (int e = 0; e < 4; ++e) v2[e] = f32x2_t{f[2 * e], f[2 * e + 1]} * fa2[e] + fb2[e];
+                if constexpr (kAct) {
+                    float ex[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2_t z2 = v2[e] * -1.4426950408889634f;
+                        ex[2 * e] = z2.x; ex[2 * e + 1] = z2.y;
                     }
-                    f[2 * e] = v2.x; f[2 * e + 1] = v2.y;
-                }
-                u32x4_t qv = pack16<T>(f);
-                qv.x = valid ? qv.x : 0u; qv.y = valid ? qv.y : 0u; qv.z = valid ? qv.z : 0u; qv.w = valid ? qv.w : 0u;
-                *(u32x4_t*)addr = qv;
-            };
 #pragma unroll
-            for (int i = 0; i < 4; ++i) unit(ldsA + i * 8192, p0 + i * 64 >= 0 && p0 + i * 64 < a.lin);
-            if (halo) {
-                if (lane < 16) unit(ldsH, ph >= 0 && ph < a.lin);
+                    for (int e = 0; e < 8; ++e) ex[e] = __builtin_amdgcn_exp2f(ex[e]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ex[e] += 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ex[e] = __builtin_amdgcn_rcpf(ex[e]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v2[e] = v2[e] * f32x2_t{ex[2 * e], ex[2 * e + 1]};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f[2 * e] = v2[e].x; f[2 * e + 1] = v2[e].y; }
+                return pack16<T>(f);
+            };
+            u32x4_t raw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw[i] = *(const u32x4_t*)(ldsA + i * 8192);
+            if (d.act) {                                                    // uniform: two straight-line versions
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::true_type{});
+                if (halo && lane < 16) *(u32x4_t*)ldsH = math(*(const u32x4_t*)ldsH, std::true_type{});
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::false_type{});
+                if (halo && lane < 16) *(u32x4_t*)ldsH = math(*(const u32x4_t*)ldsH, std::false_type{});
             }
-        } else if (edge) {
+        }
+        if (edge) {                                                         // conv zero padding applies to the activated tensor
             const u32x4_t z = u32x4_t{0u, 0u, 0u, 0u};
             if (p0 < 0) *(u32x4_t*)ldsA = z;
             if (halo && lane < 16 && ph >= a.lin) *(u32x4_t*)ldsH = z;
@@ -284,9 +312,11 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     }
     const int fw = (r >> 1) & 7;
     const unsigned wbase = (unsigned)((wn * 64 + r) * kPpRow + ((h ^ (fw & 1)) << 4) + ((fw >> 1) << 5));
-    auto mfma = [&](int tap, int stA, int stW) __attribute__((always_inline)) {
-        if (a.dbg & 4) return;
-        const unsigned ab = tap == 0 ? abase[0] : (tap == 1 ? abase[1] : abase[2]);
+    // `between(ks)` runs after the MFMAs of 16-channel group ks have been issued: the DMA instructions of the step are
+    // placed there, one or two per group, so the ~100 cycles each of them holds the wave are covered by queued MFMAs
+    auto mfma = [&](auto tapc, int stA, int stW, auto between) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value;
+        const unsigned ab = abase[TAP];
         const char* pa = smem + stA * kPpAStage;
         const char* pw = smem + kPpOffW + stW * kPpWStage;
         bf16x8_t fa[2][2], fb[2][2];
@@ -310,6 +340,9 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            between(ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -322,7 +355,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         float* scw = sc + (4 * h) * 64 + r;
         const float* scr = sc + rsub * 64 + cc * 8;
         T* out = (T*)a.out;
-        const bool stats_here = a.stats != nullptr && !(a.dbg & 8);
+        const bool stats_here = a.stats != nullptr;
         const int gs = stats_here ? a.out_c / a.stats_groups : 8;
         const int tpg = gs / 8;
         const int n = n0 + wn * 64 + cc * 8;
@@ -352,7 +385,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                     const float4 q0 = *(const float4*)(scr), q1 = *(const float4*)(scr + 4);
                     v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
                 }
-                if (!(a.dbg & 1)) *(u32x4_t*)(out + off) = pack16<T>(v);
+                *(u32x4_t*)(out + off) = pack16<T>(v);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2_t v2 = {v[e], v[e + 1]};
@@ -376,60 +409,77 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     };
 
     // ---- pipeline -----------------------------------------------------------------------------------------------
-    // global K-block counter g = tseq * nb + blk; activations of block g live in A stage g % 3, weights of the
-    // sub-step counted q live in W stage q & 1.
-    int ia_t = 0, ia_b = 0, ia_st = 0, ia_g = 0;            // activation DMA stream (two blocks ahead of the MFMAs)
-    int iw_t = 0, iw_b = 0, iw_tap = 0, iw_st = 0;          // weight DMA stream (one sub-step ahead)
-    bool iw_more = true;
-    auto adv_a = [&]() __attribute__((always_inline)) {
-        if (++ia_b == nb) { ia_b = 0; ++ia_t; }
-        ia_st = ia_st == kPpAStages - 1 ? 0 : ia_st + 1;
-        ++ia_g;
+    // K blocks are numbered g = tile * nb + blk over the whole thread block; the activations of block g live in A
+    // stage g % 3 (fetched while block g-2 computes, prepared in place during the last sub-step of block g-1), the
+    // weight slab of a sub-step lives in W stage (sub-step count) & 1 (fetched during the previous sub-step).
+    const std::integral_constant<int, 0> tap0{};
+    const std::integral_constant<int, 1> tap1{};
+    const std::integral_constant<int, 2> tap2{};
+    int nt = 0, nbk = 0;                                     // (tile, block) cursor of the descriptor stream
+    auto next_desc = [&]() __attribute__((always_inline)) -> PpBlk {
+        if (++nbk == nb) { nbk = 0; ++nt; }
+        return desc(nt < ntiles ? nt : ntiles - 1, nbk);     // past the end: a valid but unused descriptor
     };
-    auto adv_w = [&]() __attribute__((always_inline)) {
-        const int tp = iw_b >= nb0 ? taps1 : taps0;
-        if (++iw_tap == tp) {
-            iw_tap = 0;
-            if (++iw_b == nb) { iw_b = 0; ++iw_t; if (iw_t == ntiles) iw_more = false; }
-        }
-        iw_st ^= 1;
-    };
-    (void)issue_a(ia_t, ia_b, ia_st, -1); adv_a();
-    if (GB > 1) { (void)issue_a(ia_t, ia_b, ia_st, -1); adv_a(); }
-    issue_w(iw_t, iw_b, iw_tap, iw_st); adv_w();
+    PpBlk dc = desc(0, 0);
+    PpBlk d1 = next_desc();
+    PpBlk d2 = next_desc();
+    (void)issue_a(dc, 0, -1);
+    if (GB > 1) (void)issue_a(d1, 1, -1);
+    issue_w(dc.w, 0);
     wait_dma(0);
-    transform(0, 0, 0);
+    transform(dc, 0);
     lds_barrier();
 
     int stA = 0, stW = 0;
-    for (int tseq = 0; tseq < ntiles; ++tseq) {
-        if (tseq > 0 && !(a.dbg & 512)) {                    // the previous tile finished with the last sub-step
+    for (int g = 0; g < GB; ++g) {
+        const bool has1 = g + 1 < GB, has2 = g + 2 < GB;
+        const int stA1 = stA == kPpAStages - 1 ? 0 : stA + 1;
+        const int stA2 = stA1 == kPpAStages - 1 ? 0 : stA1 + 1;
+        if (g > 0 && (g % nb) == 0) {                        // first block of a tile: the previous tile is complete
             int b0, m0, n0;
-            geom(tseq, b0, m0, n0);
-            epilogue(tseq - 1, n0);
+            geom(dc.tseq, b0, m0, n0);
+            epilogue(dc.tseq - 1, n0);
         }
-        for (int blk = 0; blk < nb; ++blk) {
-            const int tp = blk >= nb0 ? taps1 : taps0;
-            for (int tap = 0; tap < tp; ++tap) {
-                int n_after_w = 0;
-                if (iw_more) { if (!(a.dbg & 32)) issue_w(iw_t, iw_b, iw_tap, iw_st); adv_w(); }
-                // activations of the block two ahead, all pieces at once (spreading them over the sub-steps of the
-                // block measured slower: the data then lands closer to its use)
-                if (tap == 0 && ia_g < GB) { n_after_w = (a.dbg & 64) ? 0 : issue_a(ia_t, ia_b, ia_st, -1); adv_a(); }
-                __builtin_amdgcn_sched_barrier(0);
-                mfma(tap, stA, stW);
-                __builtin_amdgcn_sched_barrier(0);
-                wait_dma(n_after_w);                          // the weights of the next sub-step (and everything older) have landed
-                if (tap == tp - 1) {                          // prepare the next K block in place
-                    int nt = tseq, nbk = blk + 1;
-                    if (nbk == nb) { nbk = 0; ++nt; }
-                    if (nt < ntiles && !(a.dbg & 256)) transform(nt, nbk, stA == kPpAStages - 1 ? 0 : stA + 1);
-                }
-                stW ^= 1;
-                if (!(a.dbg & 128)) lds_barrier();
-            }
-            stA = stA == kPpAStages - 1 ? 0 : stA + 1;
+        if (dc.taps == 3) {
+            // ---- tap 0: next slab = tap 1; the activations of block g+2 start their way (in three parts)
+            int nA = 0;
+            mfma(tap0, stA, stW, [&](int ks) __attribute__((always_inline)) {
+                if (ks == 0) issue_w(dc.w + slab, stW ^ 1);
+                else if (has2) nA += issue_a(d2, stA2, ks - 1);
+            });
+            wait_dma(nA);
+            stW ^= 1;
+            lds_barrier();
+            // ---- tap 1
+            mfma(tap1, stA, stW, [&](int ks) __attribute__((always_inline)) { if (ks == 0) issue_w(dc.w + slab + slab, stW ^ 1); });
+            wait_dma(0);
+            stW ^= 1;
+            lds_barrier();
+            // ---- tap 2: next slab = tap 0 of block g+1, whose activations are prepared beside the MFMAs: the two waves
+            // of a SIMD do it in opposite order
+            if (has1 && early) transform(d1, stA1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(tap2, stA, stW, [&](int ks) __attribute__((always_inline)) { if (ks == 0 && has1) issue_w(d1.w, stW ^ 1); });
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1 && !early) transform(d1, stA1);
+            wait_dma(0);
+            stW ^= 1;
+            lds_barrier();
+        } else {
+            // ---- single-tap block: everything of the next block is needed after this one sub-step
+            int nA = 0;
+            mfma(tap0, stA, stW, [&](int ks) __attribute__((always_inline)) {
+                if (ks == 0) { if (has1) issue_w(d1.w, stW ^ 1); }
+                else if (has2) nA += issue_a(d2, stA2, ks - 1);
+            });
+            wait_dma(nA);
+            if (has1) transform(d1, stA1);
+            stW ^= 1;
+            lds_barrier();
         }
+        dc = d1; d1 = d2;
+        d2 = next_desc();
+        stA = stA1;
     }
     wait_dma(0);
     epilogue(ntiles - 1, 0);
