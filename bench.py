@@ -88,6 +88,17 @@ def roofline(net, hd, batch, length, dtype, iters, device):
                           "mfma_TFLOPs": all_flops / (total_ms * 1e-3) / 1e12},
         "traffic": None,
     }
+    # HBM bytes per launch of the dominant kernel from the PMC counters: collected in a separate rocprofv3 run
+    # (counters cannot be read from inside this process), committed under profiles/ with the command that made it
+    tpath = os.path.join(ROOT, "profiles", "r01_dominant_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == out["kernel"] and tj.get("workload") == f"{net.cfg_name} {dtype} batch {batch} length {length}":
+                out["traffic"] = tj["hbm_bytes_per_launch"]
+                out["traffic_source"] = "profiles/r01_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except (ValueError, KeyError):
+            pass
     if os.environ.get("ADF_BENCH_VERBOSE"):
         out["rows"] = rows
     if out["bound"] == "hbm":
@@ -141,6 +152,7 @@ def main():
 
     cfg = A.PRESETS[a.config]()
     net = A.UNet1dBase.from_config(cfg, compute_dtype=a.dtype)
+    net.cfg_name = a.config
     net.load_state_dict(generate_weights(cfg, seed=0))     # every rank regenerates the same weights
     net = net.to(device)
     diff = A.EluDiffusion(sigma_data=0.2)
