@@ -5,7 +5,7 @@ Plugin surface (hydra ``_target_`` s): ``audiodiffuser_amd.UNet1dBase`` (model.n
 ``EDMAlphaSampler`` / ``DPMSampler`` (model.sampler), ``audiodiffuser_amd.KarrasSchedule``
 (model.noise_scheduler).
 """
-from .config import UNet1dConfig, config_c1, config_c2, config_c3, config_tiny, PRESETS  # noqa: F401
+from .config import UNet1dConfig, config_c1, config_c2, config_c3, config_tiny, config_tiny_cc, PRESETS  # noqa: F401
 from .scheduler import KarrasSchedule  # noqa: F401
 from .net import UNet1dBase  # noqa: F401
 from .diffusion import EluDiffusion  # noqa: F401

@@ -10,7 +10,7 @@ shipped 1-D experiment config
 from __future__ import annotations
 
 from dataclasses import dataclass, field, asdict
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 
 @dataclass
@@ -33,6 +33,9 @@ class UNet1dConfig:
     use_skip_scale: bool = True
     use_attention_bottleneck: bool = True
     cond_drop_prob: float = 0.0
+    # class conditioning for classifier-free guidance (reference: unet1d.py:824-847, conditioner.py:59-111)
+    class_cond: bool = False
+    num_classes: Optional[int] = None
 
     # ---- derived -----------------------------------------------------
     @property
@@ -42,6 +45,11 @@ class UNet1dConfig:
     @property
     def time_embed_dim(self) -> int:
         return self.channels * 4
+
+    @property
+    def classes_dim(self) -> int:
+        """Width of the class embedding that joins the time embedding in every FiLM projection (0 = unconditional)."""
+        return self.channels * 4 if self.class_cond else 0
 
     @property
     def total_downsample(self) -> int:
@@ -60,11 +68,15 @@ class UNet1dConfig:
             raise ValueError("num_filters must equal channels*multipliers[0] (to_in feeds downsamples[0])")
         if self.channels % 2:
             raise ValueError("channels must be even (LearnedPositionalEmbedding)")
+        if self.class_cond and not (isinstance(self.num_classes, int) and self.num_classes > 0):
+            raise ValueError("class_cond=True needs num_classes (label conditioning; class_embed_dim inputs are outside the path)")
 
     def to_kwargs(self) -> dict:
         """kwargs accepted by the reference ``UNet1dBase`` constructor."""
         d = asdict(self)
         d.pop("out_channels")
+        if not self.class_cond:
+            d.pop("class_cond"); d.pop("num_classes")
         return d
 
 
@@ -91,4 +103,11 @@ def config_tiny() -> UNet1dConfig:
                         num_blocks=[1, 2, 1], attentions=[False, True, True])
 
 
-PRESETS = {"c1": config_c1, "c2": config_c2, "c3": config_c3, "tiny": config_tiny}
+def config_tiny_cc() -> UNet1dConfig:
+    """``config_tiny`` with class conditioning (10 labels, the sc09 digit count) for the CFG tests."""
+    c = config_tiny()
+    c.class_cond, c.num_classes = True, 10
+    return c
+
+
+PRESETS = {"c1": config_c1, "c2": config_c2, "c3": config_c3, "tiny": config_tiny, "tiny_cc": config_tiny_cc}

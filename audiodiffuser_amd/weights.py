@@ -60,13 +60,25 @@ def param_specs(cfg: UNet1dConfig) -> "OrderedDict[str, Spec]":
     ch, temb = cfg.channels, cfg.time_embed_dim
     n = cfg.num_layers
     s: "OrderedDict[str, Spec]" = OrderedDict()
+    if cfg.class_cond:      # LabelEmbedder is registered before the U-Net (unet1d.py:841-847, conditioner.py:64-90)
+        cdim = cfg.classes_dim
+        s["label_conditioner.null_classes_emb"] = ((1, ch), "embed")
+        s["label_conditioner.label_emb.weight"] = ((cfg.num_classes, ch), "embed")
+        s["label_conditioner.class_to_cond.0.weight"] = ((ch,), "norm_w")
+        s["label_conditioner.class_to_cond.0.bias"] = ((ch,), "norm_b")
+        s["label_conditioner.class_to_cond.1.weight"] = ((cdim, ch), "linear_w")
+        s["label_conditioner.class_to_cond.1.bias"] = ((cdim,), "bias")
+        s["label_conditioner.class_to_cond.3.weight"] = ((cdim, cdim), "linear_w")
+        s["label_conditioner.class_to_cond.3.bias"] = ((cdim,), "bias")
+    temb = temb + cfg.classes_dim   # every FiLM projection reads cat(time_embed, class_embed) (unet1d.py:272, :306-308)
+    tdim = cfg.time_embed_dim
     s["unet.to_in.to_in.weight"] = ((cfg.num_filters, cfg.in_channels, cfg.window_length), "conv_w")
     s["unet.to_out.to_out.weight"] = ((cfg.num_filters, cfg.out_channels, cfg.window_length), "convT_w")
     s["unet.to_time.0.0.weights"] = ((ch // 2,), "fourier")
-    s["unet.to_time.0.1.weight"] = ((temb, ch + 1), "linear_w")
-    s["unet.to_time.0.1.bias"] = ((temb,), "bias")
-    s["unet.to_time.2.weight"] = ((temb, temb), "linear_w")
-    s["unet.to_time.2.bias"] = ((temb,), "bias")
+    s["unet.to_time.0.1.weight"] = ((tdim, ch + 1), "linear_w")
+    s["unet.to_time.0.1.bias"] = ((tdim,), "bias")
+    s["unet.to_time.2.weight"] = ((tdim, tdim), "linear_w")
+    s["unet.to_time.2.bias"] = ((tdim,), "bias")
     for i in range(n):
         cin, cout = ch * cfg.multipliers[i], ch * cfg.multipliers[i + 1]
         f = cfg.factors[i]
@@ -122,7 +134,7 @@ def generate_tensor(name: str, shape: Tuple[int, ...], kind: str, seed: int = 0)
         return 1.0 + 0.1 * z
     if kind == "norm_b":
         return 0.1 * z
-    if kind == "fourier":
+    if kind in ("fourier", "embed"):
         return z
     raise ValueError(kind)
 

@@ -28,22 +28,32 @@ def edm_scale_weights(sigmas: torch.Tensor, sigma_data: float, ndim: int) -> Tup
     return c_skip, c_out, c_in, c_noise
 
 
-def denoise(net: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x_noisy: torch.Tensor,
-            sigma_data: float, sigma=None, sigmas: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """src/models/components/diffusion.py:32-63 with cond_scale == 1 and dynamic_threshold == 0
-    (clip = clamp(-1, 1), components/utils.py:20-22).  Exactly one of sigma / sigmas."""
+def denoise(net: Callable[..., torch.Tensor], x_noisy: torch.Tensor,
+            sigma_data: float, sigma=None, sigmas: Optional[torch.Tensor] = None, cond_scale: float = 1.0) -> torch.Tensor:
+    """src/models/components/diffusion.py:32-63 at inference with dynamic_threshold == 0
+    (clip = clamp(-1, 1), components/utils.py:20-22).  Exactly one of sigma / sigmas.
+    cond_scale != 1: classifier-free guidance (:52-54); ``net`` must then accept cond_drop_prob."""
     assert (sigma is None) ^ (sigmas is None), "Either sigma or sigmas must be provided"
     b = x_noisy.shape[0]
     if sigmas is None:
         sigmas = torch.full((b,), float(sigma), dtype=torch.float32)   # components/utils.py:41-52
     c_skip, c_out, c_in, c_noise = edm_scale_weights(sigmas, sigma_data, x_noisy.ndim)
-    pred = net(c_in * x_noisy, c_noise)
+    if cond_scale == 1.0:
+        pred = net(c_in * x_noisy, c_noise)
+    else:
+        pred = net(c_in * x_noisy, c_noise, cond_drop_prob=0.0)
+        null = net(c_in * x_noisy, c_noise, cond_drop_prob=1.0)
+        pred = null + (pred - null) * cond_scale
     return (c_skip * x_noisy + c_out * pred).clamp(-1.0, 1.0)
 
 
-def make_denoiser(p: P, cfg: UNet1dConfig, sigma_data: float) -> Callable:
+def make_denoiser(p: P, cfg: UNet1dConfig, sigma_data: float, classes: Optional[torch.Tensor] = None,
+                  cond_scale: float = 1.0) -> Callable:
     """fn(x, sigma) -> denoised, the closure the samplers call (module call site:
-    src/models/diffunet_complex_module.py:86-89)."""
+    src/models/diffunet_complex_module.py:86-89); ``classes`` / ``cond_scale`` as the module forwards them."""
+    def net(xi, t, cond_drop_prob=0.0):
+        return unet1d_forward(p, cfg, xi, t, classes=classes, cond_drop_prob=cond_drop_prob)
+
     def fn(x, sigma=None, sigmas=None):
-        return denoise(lambda xi, t: unet1d_forward(p, cfg, xi, t), x, sigma_data, sigma=sigma, sigmas=sigmas)
+        return denoise(net, x, sigma_data, sigma=sigma, sigmas=sigmas, cond_scale=cond_scale)
     return fn

@@ -291,6 +291,41 @@ def main():
     assert worst < 5e-4, sampler_report
     report["samplers"] = sampler_report
 
+    # ---- 7. class conditioning + classifier-free guidance ----------------------
+    from audiodiffuser_amd.config import config_tiny_cc
+    cfg = config_tiny_cc()
+    w = generate_weights(cfg, seed=0)
+    net = build_ref_net(ref, cfg, w)
+    layout["tiny_cc"] = {"num_params": sum(v.numel() for v in net.state_dict().values()), "num_tensors": len(net.state_dict()),
+                         "keys": {k: list(v.shape) for k, v in net.state_dict().items()}}
+    B, L = 3, 256
+    x = generate_noise(40, B, L) * 0.8
+    t = torch.tensor([-0.7, 0.1, 0.45])
+    classes = torch.tensor([3, 0, 9], dtype=torch.int64)
+    cfg_report = {}
+    with torch.no_grad():
+        for tag, cdp in (("cond", 0.0), ("null", 1.0)):
+            r = net(x, t, classes=classes, cond_drop_prob=cdp)
+            o = O.unet1d_forward(w, cfg, x, t, classes=classes, cond_drop_prob=cdp)
+            cfg_report[f"net_{tag}"] = rel_err(o, r)
+            out[f"cc_net_{tag}_y"] = r.numpy()
+        out["cc_net_x"] = x.numpy(); out["cc_net_t"] = t.numpy(); out["cc_classes"] = classes.numpy()
+        xn = generate_noise(50, B, L)
+        for si, (sg, cs) in enumerate(((8.0, 2.5), (0.6, 7.0))):
+            r = diff.denoise_fn(xn * sg, net=net, sigma=torch.tensor(sg), inference=True, cond_scale=cs, classes=classes)
+            o = E.make_denoiser(w, cfg, 0.2, classes=classes, cond_scale=cs)(xn * sg, sigma=torch.tensor(sg))
+            cfg_report[f"denoise_{si}"] = rel_err(o, r)
+            out[f"cc_denoise_{si}"] = r.numpy()
+        sg = ref["KarrasSchedule"](sigma_min=0.002, sigma_max=80.0, rho=7.0, num_steps=8)()
+        smp = ref["EDMSampler"](s_churn=0.0, s_noise=1.0, num_steps=8, use_heun=True, cond_scale=3.0)
+        nz = generate_noise(60, B, L)
+        y = smp(nz, fn=diff.denoise_fn, net=net, sigmas=sg, classes=classes)
+        yo = S.edm_sampler(nz, E.make_denoiser(w, cfg, 0.2, classes=classes, cond_scale=3.0), sg, 8, s_churn=0.0, s_noise=1.0)
+        cfg_report["heun8_cfg3"] = rel_err(yo, y)
+        out["cc_heun8_final"] = y.numpy()
+    assert max(cfg_report.values()) < 5e-4, cfg_report
+    report["class_cond_cfg"] = cfg_report
+
     print(json.dumps(report, indent=1))
     if args.check_only:
         return

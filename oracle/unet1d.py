@@ -46,8 +46,24 @@ def conv_block(p: P, pre: str, x: torch.Tensor, groups: int,
     return F.conv1d(F.silu(h), p[f"{pre}.project.weight"], p[f"{pre}.project.bias"], padding=1)
 
 
+def label_embedding(p: P, classes: torch.Tensor, cond_drop_prob: float) -> torch.Tensor:
+    """src/models/backbones/conditioner.py:92-111 with prob_mask_like (operator_utils.py:46-52) at its two
+    deterministic settings: cond_drop_prob 0 keeps every label, 1 replaces every label by the null embedding.
+    classes: int64 [B] -> [B, 4*channels]."""
+    emb = F.embedding(classes, p["label_conditioner.label_emb.weight"])
+    if cond_drop_prob > 0:
+        if cond_drop_prob != 1:
+            raise ValueError("the oracle covers cond_drop_prob 0 and 1 (inference); other values draw a random mask")
+        emb = p["label_conditioner.null_classes_emb"].expand_as(emb)
+    c = emb.shape[-1]
+    h = F.layer_norm(emb, (c,), p["label_conditioner.class_to_cond.0.weight"], p["label_conditioner.class_to_cond.0.bias"], 1e-5)
+    h = F.linear(h, p["label_conditioner.class_to_cond.1.weight"], p["label_conditioner.class_to_cond.1.bias"])
+    return F.linear(F.silu(h), p["label_conditioner.class_to_cond.3.weight"], p["label_conditioner.class_to_cond.3.bias"])
+
+
 def resnet_block(p: P, pre: str, x: torch.Tensor, temb: torch.Tensor, groups: int) -> torch.Tensor:
-    """unet1d.py:297-316.  FiLM (scale, shift) = chunk(Linear(SiLU(temb))) feeds block2 only."""
+    """unet1d.py:297-316.  FiLM (scale, shift) = chunk(Linear(SiLU(cat(time_embed, class_embed)))) feeds block2 only
+    (the caller passes the concatenation as ``temb``)."""
     cond = F.linear(F.silu(temb), p[f"{pre}.to_cond_embedding.1.weight"], p[f"{pre}.to_cond_embedding.1.bias"])
     scale, shift = cond[:, :, None].chunk(2, dim=1)
     h = conv_block(p, f"{pre}.block1", x, groups)
@@ -105,8 +121,9 @@ def upsample_conv(p: P, pre: str, x: torch.Tensor, factor: int) -> torch.Tensor:
 
 # ---------------------------------------------------------------- whole network
 def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
-                   taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
-    """unet1d.py:864-893 -> :771-816 (unconditional path: classes=None, no context).
+                   taps: Optional[Dict[str, torch.Tensor]] = None, classes: Optional[torch.Tensor] = None,
+                   cond_drop_prob: float = 0.0) -> torch.Tensor:
+    """unet1d.py:864-893 -> :771-816 (no text context; ``classes`` = int64 labels for a class-conditional net).
 
     x: [B, in_channels, L], t: [B] (= c_noise).  ``taps`` optionally records
     intermediate activations by name (used by kernel-level parity tests)."""
@@ -121,6 +138,8 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
 
     h = rec("to_in", F.conv1d(x, p["unet.to_in.to_in.weight"], stride=cfg.stride, padding=pad))  # :584-591
     temb = rec("temb", time_embedding(p, t))
+    if classes is not None:                                                       # :877, resblocks :306-308
+        temb = torch.cat((temb, rec("class_emb", label_embedding(p, classes, cond_drop_prob))), dim=-1)
     skips_list: List[List[torch.Tensor]] = []
     for i in range(n):                                                            # :792-801, :441-468
         pre = f"unet.downsamples.{i}"
