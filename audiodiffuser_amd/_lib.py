@@ -31,7 +31,7 @@ class AdfNetConfig(C.Structure):
         ("attentions", C.c_int32 * ADF_MAX_LAYERS),
         ("attention_heads", C.c_int32), ("attention_multiplier", C.c_int32),
         ("use_skip_scale", C.c_int32), ("use_attention_bottleneck", C.c_int32),
-        ("dtype", C.c_int32), ("flags", C.c_int32),
+        ("dtype", C.c_int32), ("flags", C.c_int32), ("num_classes", C.c_int32),
     ]
 
 
@@ -54,6 +54,7 @@ EXPORTS = {
     "adf_weight_numel": (C.c_int64, [C.c_void_p, C.c_int]),
     "adf_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "adf_weights_missing": (C.c_int, [C.c_void_p]),
+    "adf_set_condition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "adf_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adf_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adf_sampler_run": (C.c_int, [C.c_void_p, C.POINTER(AdfSamplerDesc), C.POINTER(C.c_float), C.c_int, C.c_void_p,
@@ -110,6 +111,7 @@ def make_config(cfg: UNet1dConfig, dtype: int, flags: int = 0) -> AdfNetConfig:
     c.use_skip_scale = 1 if cfg.use_skip_scale else 0
     c.use_attention_bottleneck = 1 if cfg.use_attention_bottleneck else 0
     c.dtype, c.flags = dtype, flags
+    c.num_classes = int(cfg.num_classes) if cfg.class_cond else 0
     return c
 
 

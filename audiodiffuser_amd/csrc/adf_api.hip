@@ -67,6 +67,7 @@ struct Plan {
     // sampler state (fp32 [B][C][L] each)
     float* sb[10] = {nullptr};
     float* noise_stage = nullptr; float* out_stage = nullptr; float* inj_stage = nullptr; size_t inj_cap = 0;
+    float* cfg_c = nullptr; float* cfg_n = nullptr;      // raw network outputs of the two CFG branches
     std::map<std::string, hipGraphExec_t> graphs;
 };
 
@@ -84,6 +85,17 @@ struct adf_handle {
     float *to_in_w = nullptr, *to_out_w = nullptr, *fourier = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr,
           *t_b2 = nullptr, *film_w = nullptr, *film_b = nullptr;
     int film_total = 0;
+    // class conditioning (LabelEmbedder) and the state set by adf_set_condition
+    float *lab_null = nullptr, *lab_emb = nullptr, *lab_lnw = nullptr, *lab_lnb = nullptr, *lab_w1 = nullptr, *lab_b1 = nullptr,
+          *lab_w2 = nullptr, *lab_b2 = nullptr;
+    int cdim = 0;                       // width of the class embedding (4 * channels) or 0
+    bool cond_on = false;
+    int cond_B = 0;
+    float cond_scale = 1.0f;
+    long long* cond_classes = nullptr;  // [cond_B]
+    float* cond_emb = nullptr;          // [cond_B + 1][cdim], last row = null embedding
+    float* cond_film = nullptr;         // [cond_B + 1][film_total]: class part of every FiLM projection
+    int cond_cap = 0;
     std::vector<DownW> downs;
     ResW mid_pre, mid_post;
     TrW mid_tr;
@@ -178,14 +190,26 @@ struct Registrar {
 int build_weights(adf_handle* h) {
     const adf_net_config& c = h->cfg;
     Registrar R{h};
-    const int ch = c.channels, temb = 4 * ch, n = c.num_layers;
+    const int ch = c.channels, tdim = 4 * ch, n = c.num_layers;
+    h->cdim = c.num_classes > 0 ? 4 * ch : 0;
+    const int temb = tdim + h->cdim;     // every FiLM Linear reads cat(time_embed, class_embed) (unet1d.py:272)
+    if (c.num_classes > 0) {             // conditioner.py:64-90, registered before the U-Net
+        h->lab_null = R.reg_f32("label_conditioner.null_classes_emb", ch);
+        h->lab_emb = R.reg_f32("label_conditioner.label_emb.weight", (int64_t)c.num_classes * ch);
+        h->lab_lnw = R.reg_f32("label_conditioner.class_to_cond.0.weight", ch);
+        h->lab_lnb = R.reg_f32("label_conditioner.class_to_cond.0.bias", ch);
+        h->lab_w1 = R.reg_f32("label_conditioner.class_to_cond.1.weight", (int64_t)h->cdim * ch);
+        h->lab_b1 = R.reg_f32("label_conditioner.class_to_cond.1.bias", h->cdim);
+        h->lab_w2 = R.reg_f32("label_conditioner.class_to_cond.3.weight", (int64_t)h->cdim * h->cdim);
+        h->lab_b2 = R.reg_f32("label_conditioner.class_to_cond.3.bias", h->cdim);
+    }
     h->to_in_w = R.reg_f32("unet.to_in.to_in.weight", (int64_t)c.num_filters * c.in_channels * c.window_length);
     h->to_out_w = R.reg_f32("unet.to_out.to_out.weight", (int64_t)c.num_filters * c.out_channels * c.window_length);
     h->fourier = R.reg_f32("unet.to_time.0.0.weights", ch / 2);
-    h->t_w1 = R.reg_f32("unet.to_time.0.1.weight", (int64_t)temb * (ch + 1));
-    h->t_b1 = R.reg_f32("unet.to_time.0.1.bias", temb);
-    h->t_w2 = R.reg_f32("unet.to_time.2.weight", (int64_t)temb * temb);
-    h->t_b2 = R.reg_f32("unet.to_time.2.bias", temb);
+    h->t_w1 = R.reg_f32("unet.to_time.0.1.weight", (int64_t)tdim * (ch + 1));
+    h->t_b1 = R.reg_f32("unet.to_time.0.1.bias", tdim);
+    h->t_w2 = R.reg_f32("unet.to_time.2.weight", (int64_t)tdim * tdim);
+    h->t_b2 = R.reg_f32("unet.to_time.2.bias", tdim);
     h->downs.resize(n);
     for (int i = 0; i < n; ++i) {
         DownW& d = h->downs[i];
@@ -233,6 +257,8 @@ struct Walker {
     Plan* p;
     hipStream_t s;
     bool bad = false;
+    const float* film2 = nullptr;       // class part of the FiLM projections for this pass (FwdIO::film2)
+    int film2_bstride = 0;
 
     void check(const char* e) { if (e && !bad) { bad = true; h->err = e; } }
     void* alloc(size_t bytes) {
@@ -348,6 +374,7 @@ struct Walker {
         f2.stats0 = sh; f2.c0 = r.cout; f2.L = x.L; f2.G = G; f2.B = B; f2.scale1 = 1.f; f2.eps = 1e-5f;
         f2.gamma = r.g2w; f2.beta = r.g2b;
         f2.film = p->film + r.film_off; f2.film_bstride = nb == 1 ? 0 : h->film_total; f2.ab = ab2;
+        if (film2) { f2.film2 = film2 + r.film_off; f2.film2_bstride = film2_bstride; }
         if (live() && !short_level) check(launch_gn_finalize(f2, s));
         Act y = new_act(r.cout, x.L);
         GemmArgs g2 = gemm_base(y, x.L, x.L, r.c2);
@@ -392,14 +419,16 @@ struct Walker {
 };
 
 struct FwdIO {
-    const float* x; float* out;
-    const float* t; int t_stride; int nb;
-    const float* coef; int coef_bstride; int mode; const float* x_noisy;
+    const float* x = nullptr; float* out = nullptr;
+    const float* t = nullptr; int t_stride = 0; int nb = 0;
+    const float* coef = nullptr; int coef_bstride = 0; int mode = 0; const float* x_noisy = nullptr;
+    const float* film2 = nullptr; int film2_bstride = 0;   // class part of the FiLM projections (rows of adf_handle::cond_film)
 };
 
 int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     const adf_net_config& c = h->cfg;
     Walker W{h, p, s};
+    W.film2 = io.film2; W.film2_bstride = io.film2_bstride;
     p->arena_off = 0; p->stats_off = 0;
     p->taps.clear(); p->rbs.clear();
     const int B = p->B, L = p->L, n = c.num_layers;
@@ -414,7 +443,7 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         te.t = io.t; te.t_stride = io.t_stride; te.nb = io.nb; te.ch = c.channels;
         te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb;
         W.check(launch_time_embed(te, s));
-        W.check(launch_film(p->temb, h->film_w, h->film_b, p->film, io.nb, tdim, h->film_total, s));
+        W.check(launch_film(p->temb, tdim, h->film_w, tdim + h->cdim, 0, h->film_b, p->film, io.nb, h->film_total, s));
     }
     Act x = W.new_act(c.num_filters, L / c.stride);
     if (W.live())
@@ -484,7 +513,6 @@ int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
     p->B = B; p->L = L;
     p->dry = true;
     FwdIO io;
-    memset(&io, 0, sizeof(io));
     io.nb = B;
     if (forward(h, p, io, s)) { delete p; return 1; }
     p->arena_bytes = p->arena_off; p->stats_bytes = p->stats_off;
@@ -511,12 +539,54 @@ int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
     return 0;
 }
 
+// class part of the FiLM projections for one network pass: the per-sample rows, or the null row for every sample
+int cond_rows(adf_handle* h, int B, bool null_branch, FwdIO& io) {
+    if (h->cdim == 0) return 0;
+    if (!h->cond_on || h->cond_B != B)
+        return fail(h, "class-conditional network: call adf_set_condition with the labels of this batch first");
+    if (null_branch) { io.film2 = h->cond_film + (size_t)B * h->film_total; io.film2_bstride = 0; }
+    else { io.film2 = h->cond_film; io.film2_bstride = h->film_total; }
+    return 0;
+}
+
+// (allocated outside graph capture: adf_sampler_run calls this before it starts capturing)
+int ensure_cfg_buffers(adf_handle* h, Plan* p) {
+    if (p->cfg_c) return 0;
+    const size_t wave = (size_t)p->B * h->cfg.out_channels * p->L;
+    p->cfg_c = (float*)dalloc(h, wave * 4);
+    p->cfg_n = (float*)dalloc(h, wave * 4);
+    if (!p->cfg_c || !p->cfg_n) return fail(h, "device allocation failed for the guidance buffers");
+    return 0;
+}
+
+// One denoiser evaluation.  io carries x / t / coef (preconditioning scalars already in p->coef); with classifier-free
+// guidance the network runs twice (labels, null labels) in raw mode and cfg_combine applies guidance + preconditioning.
+int denoise_io(adf_handle* h, Plan* p, FwdIO io, float* out, hipStream_t s) {
+    const bool cfg = h->cdim > 0 && h->cond_on && h->cond_scale != 1.0f;
+    if (!cfg) {
+        if (cond_rows(h, p->B, false, io)) return 1;
+        io.out = out; io.mode = 1;
+        return forward(h, p, io, s);
+    }
+    const size_t wave = (size_t)p->B * h->cfg.out_channels * p->L;
+    if (ensure_cfg_buffers(h, p)) return 1;
+    io.mode = 0;                                     // raw network output; c_in is still applied by to_in
+    io.out = p->cfg_c;
+    if (cond_rows(h, p->B, false, io) || forward(h, p, io, s)) return 1;
+    io.out = p->cfg_n;
+    if (cond_rows(h, p->B, true, io) || forward(h, p, io, s)) return 1;
+    if (const char* e = launch_cfg_combine(out, io.x_noisy, p->cfg_c, p->cfg_n, io.coef, io.coef_bstride, h->cond_scale,
+                                           (long long)h->cfg.out_channels * p->L, (long long)wave, s))
+        return fail(h, e);
+    return 0;
+}
+
 int denoise_scalar(adf_handle* h, Plan* p, const float* x, float sigma, float sigma_data, float* out, hipStream_t s) {
     if (const char* e = launch_edm_coef(nullptr, sigma, 1, sigma_data, p->coef, s)) return fail(h, e);
     FwdIO io;
-    io.x = x; io.out = out; io.t = p->coef + 1; io.t_stride = 4; io.nb = 1;
-    io.coef = p->coef; io.coef_bstride = 0; io.mode = 1; io.x_noisy = x;
-    return forward(h, p, io, s);
+    io.x = x; io.t = p->coef + 1; io.t_stride = 4; io.nb = 1;
+    io.coef = p->coef; io.coef_bstride = 0; io.x_noisy = x;
+    return denoise_io(h, p, io, out, s);
 }
 
 // ---- sampler drivers -----------------------------------------------------------------------------------
@@ -749,8 +819,40 @@ int adf_net_forward(adf_handle* h, const float* x, const float* t, float* out, i
     Plan* p;
     if (get_plan(h, B, L, s, &p)) return 1;
     FwdIO io;
-    io.x = x; io.out = out; io.t = t; io.t_stride = 1; io.nb = B; io.coef = nullptr; io.coef_bstride = 0; io.mode = 0; io.x_noisy = nullptr;
+    io.x = x; io.out = out; io.t = t; io.t_stride = 1; io.nb = B;
+    if (cond_rows(h, B, false, io)) return 1;
     return forward(h, p, io, s);
+}
+
+int adf_set_condition(adf_handle* h, const int64_t* classes_dev, int B, int null_labels, float cond_scale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!classes_dev) { h->cond_on = false; h->cond_scale = 1.0f; return 0; }
+    if (h->cdim == 0) return fail(h, "adf_set_condition: the network was built without class conditioning (num_classes = 0)");
+    if (B < 1) return fail(h, "adf_set_condition: bad batch size");
+    if (adf_weights_missing(h)) return fail(h, "weights are not fully loaded");
+    if (B > h->cond_cap) {
+        h->cond_classes = (long long*)dalloc(h, (size_t)B * 8);
+        h->cond_emb = (float*)dalloc(h, (size_t)(B + 1) * h->cdim * 4);
+        h->cond_film = (float*)dalloc(h, (size_t)(B + 1) * h->film_total * 4);
+        if (!h->cond_classes || !h->cond_emb || !h->cond_film) return fail(h, "device allocation failed for the class condition");
+        h->cond_cap = B;
+        // graphs captured earlier hold the old buffer addresses
+        for (auto& kv : h->plans) {
+            for (auto& g : kv.second->graphs) (void)hipGraphExecDestroy(g.second);
+            kv.second->graphs.clear();
+        }
+    }
+    if (hipMemcpyAsync(h->cond_classes, classes_dev, (size_t)B * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "class label copy failed");
+    const adf_net_config& c = h->cfg;
+    if (const char* e = launch_class_embed(h->cond_classes, c.num_classes, null_labels ? 1 : 0, h->lab_emb, h->lab_null, h->lab_lnw, h->lab_lnb,
+                                           h->lab_w1, h->lab_b1, h->lab_w2, h->lab_b2, c.channels, h->cdim, h->cond_emb, B + 1, s))
+        return fail(h, e);
+    // class part of every FiLM projection: columns [tdim, tdim + cdim) of the concatenated weight, no bias (it is in the time part)
+    if (const char* e = launch_film(h->cond_emb, h->cdim, h->film_w, 4 * c.channels + h->cdim, 4 * c.channels, nullptr, h->cond_film, B + 1,
+                                    h->film_total, s))
+        return fail(h, e);
+    h->cond_on = true; h->cond_B = B; h->cond_scale = cond_scale;
+    return 0;
 }
 
 int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, float sigma, float sigma_data, float* out, int B,
@@ -761,9 +863,9 @@ int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, fl
     if (!sigmas_dev) return denoise_scalar(h, p, x_noisy, sigma, sigma_data, out, s);
     if (const char* e = launch_edm_coef(sigmas_dev, 0.f, B, sigma_data, p->coef, s)) return fail(h, e);
     FwdIO io;
-    io.x = x_noisy; io.out = out; io.t = p->coef + 1; io.t_stride = 4; io.nb = B;
-    io.coef = p->coef; io.coef_bstride = 4; io.mode = 1; io.x_noisy = x_noisy;
-    return forward(h, p, io, s);
+    io.x = x_noisy; io.t = p->coef + 1; io.t_stride = 4; io.nb = B;
+    io.coef = p->coef; io.coef_bstride = 4; io.x_noisy = x_noisy;
+    return denoise_io(h, p, io, out, s);
 }
 
 int adf_sampler_nfe(const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas) {
@@ -782,6 +884,10 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     if (get_plan(h, B, L, s, &p)) return 1;
     const long long n = (long long)B * h->cfg.out_channels * L;
     if (h->cfg.in_channels != h->cfg.out_channels) return fail(h, "sampler needs in_channels == out_channels");
+    if (h->cdim > 0) {
+        if (!h->cond_on || h->cond_B != B) return fail(h, "class-conditional network: call adf_set_condition with the labels of this batch first");
+        if (h->cond_scale != 1.0f && ensure_cfg_buffers(h, p)) return 1;
+    }
     if (hipMemcpyAsync(p->noise_stage, noise, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "noise copy failed");
     if (injected_noise) {
         const size_t need = (size_t)desc->num_steps * n;
@@ -817,6 +923,8 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     std::string key((const char*)desc, sizeof(*desc));
     key.append((const char*)sigmas_host, (size_t)n_sigmas * 4);
     key.push_back(injected_noise ? 'i' : 'n');
+    key.push_back(h->cond_on ? 'c' : 'u');                   // the guidance branch structure is part of the captured graph
+    key.append((const char*)&h->cond_scale, sizeof(float));
     auto it = p->graphs.find(key);
     if (it == p->graphs.end()) {
         const hipError_t be = hipStreamBeginCapture(gs, hipStreamCaptureModeRelaxed);

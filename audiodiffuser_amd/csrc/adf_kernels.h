@@ -17,6 +17,7 @@ struct GnFinalizeArgs {
     float scale1, eps;
     const float* gamma; const float* beta;        // [c0+c1]
     const float* film; int film_bstride;           // film[b*bstride + c] = scale, film[b*bstride + ctot + c] = shift
+    const float* film2; int film2_bstride;         // optional second addend (class-embedding part of the projection)
     float* ab;                                     // [B][c0+c1][2]
 };
 const char* launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
@@ -58,9 +59,16 @@ struct TimeEmbedArgs {
 };
 const char* launch_time_embed(const TimeEmbedArgs& a, hipStream_t s);
 
-// All resblocks' FiLM projections at once: film[b][j] = bias[j] + sum_i W[j][i] * silu(temb[b][i]).
-const char* launch_film(const float* temb, const float* w, const float* bias, float* film, int nb, int tdim,
+// All resblocks' FiLM projections at once: film[b][j] = bias[j] + sum_i W[j][w_col0 + i] * silu(in[b][i]), rows of W are ldw long.
+const char* launch_film(const float* in, int in_dim, const float* w, int ldw, int w_col0, const float* bias, float* film, int nb,
                         int total, hipStream_t s);
+// LabelEmbedder: class embeddings [nrows][cdim], last row = null embedding (conditioner.py:92-111).
+const char* launch_class_embed(const long long* classes, int num_classes, int null_all, const float* emb, const float* null_emb,
+                               const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2, const float* b2,
+                               int ch, int cdim, float* out, int nrows, hipStream_t s);
+// out = clamp(c_skip x + c_out (fn + (fc - fn) scale), -1, 1); coef rows are (c_in, c_noise, c_skip, c_out).
+const char* launch_cfg_combine(float* out, const float* x, const float* fc, const float* fn, const float* coef, int coef_bstride,
+                               float scale, long long per_sample, long long n, hipStream_t s);
 
 // ---- sampler state updates (fp32, flat arrays of n elements) --------------------------------
 const char* launch_scale(float* out, const float* in, float s, long long n, hipStream_t st);

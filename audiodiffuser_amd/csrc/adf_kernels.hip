@@ -96,8 +96,12 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
         float A = rstd * gam;
         float Bc = bet - meanf * A;
         if (a.film) {
-            const float fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
-            const float fh = a.film[(size_t)b * a.film_bstride + ctot + c];
+            float fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
+            float fh = a.film[(size_t)b * a.film_bstride + ctot + c];
+            if (a.film2) {      // class-embedding part of the FiLM projection (precomputed per sampler run)
+                fs += a.film2[(size_t)b * a.film2_bstride + c];
+                fh += a.film2[(size_t)b * a.film2_bstride + ctot + c];
+            }
             A *= fs;
             Bc = fmaf(Bc, fs, fh);
         }
@@ -182,8 +186,12 @@ __global__ void __launch_bounds__(256) gn_norm_apply_kernel(const T* __restrict_
         float A = rstd * a.gamma[ch];
         float Bc = a.beta[ch] - (float)mean * A;
         if (a.film) {
-            const float fs = a.film[(size_t)b * a.film_bstride + ch] + 1.0f;
-            const float fh = a.film[(size_t)b * a.film_bstride + ctot + ch];
+            float fs = a.film[(size_t)b * a.film_bstride + ch] + 1.0f;
+            float fh = a.film[(size_t)b * a.film_bstride + ctot + ch];
+            if (a.film2) {
+                fs += a.film2[(size_t)b * a.film2_bstride + ch];
+                fh += a.film2[(size_t)b * a.film2_bstride + ctot + ch];
+            }
             A *= fs;
             Bc = fmaf(Bc, fs, fh);
         }
@@ -774,23 +782,101 @@ const char* launch_time_embed(const TimeEmbedArgs& a, hipStream_t s) {
 }
 
 // FiLM projections of every resblock in one launch (unet1d.py:269-276, 306-310): one wave per output row.
-__global__ void __launch_bounds__(256) film_kernel(const float* __restrict__ temb, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, float* __restrict__ film, int nb, int tdim, int total) {
+// film[b][j] = bias[j] + sum_{i < in_dim} W[j][w_col0 + i] * silu(in[b][i]);  W rows are ldw floats long (the
+// reference Linear reads cat(time_embed, class_embed): the two column ranges are projected separately).
+__global__ void __launch_bounds__(256) film_kernel(const float* __restrict__ in, int in_dim, const float* __restrict__ w, int ldw,
+                                                   int w_col0, const float* __restrict__ bias, float* __restrict__ film, int nb, int total) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= total) return;
-    const float* wr = w + (size_t)j * tdim;
+    const float* wr = w + (size_t)j * ldw + w_col0;
+    const float bj = bias ? bias[j] : 0.f;
     for (int b = 0; b < nb; ++b) {
         float acc = 0.f;
-        for (int i = lane; i < tdim; i += 64) acc = fmaf(wr[i], silu_f(temb[(size_t)b * tdim + i]), acc);
+        for (int i = lane; i < in_dim; i += 64) acc = fmaf(wr[i], silu_f(in[(size_t)b * in_dim + i]), acc);
         acc = wave_sum(acc);
-        if (lane == 0) film[(size_t)b * total + j] = acc + bias[j];
+        if (lane == 0) film[(size_t)b * total + j] = acc + bj;
     }
 }
 
-const char* launch_film(const float* temb, const float* w, const float* bias, float* film, int nb, int tdim, int total, hipStream_t s) {
-    hipLaunchKernelGGL(film_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, s, temb, w, bias, film, nb, tdim, total);
+const char* launch_film(const float* in, int in_dim, const float* w, int ldw, int w_col0, const float* bias, float* film, int nb,
+                        int total, hipStream_t s) {
+    hipLaunchKernelGGL(film_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, s, in, in_dim, w, ldw, w_col0, bias, film, nb, total);
     return ADF_LAUNCH_CHECK("film");
+}
+
+// LabelEmbedder (conditioner.py:92-111): row b < nb-1 takes label_emb[classes[b]] (or the null embedding when
+// null_all), the last row always the null embedding; then LayerNorm -> Linear -> SiLU -> Linear.  One block per row.
+__global__ void __launch_bounds__(256) class_embed_kernel(const long long* __restrict__ classes, int num_classes, int null_all,
+                                                          const float* __restrict__ emb, const float* __restrict__ null_emb,
+                                                          const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2, int ch, int cdim,
+                                                          float* __restrict__ out, int nrows) {
+    __shared__ float e[512];
+    __shared__ float hdn[2048];
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool use_null = b == nrows - 1 || null_all;
+    long long cls = use_null ? 0 : classes[b];
+    cls = cls < 0 ? 0 : (cls >= num_classes ? num_classes - 1 : cls);      // the host checks the range; never read outside
+    const float* src = use_null ? null_emb : emb + (size_t)cls * ch;
+    float v0 = 0.f;
+    for (int i = tid; i < ch; i += 256) { e[i] = src[i]; v0 += src[i]; }
+    v0 = wave_sum(v0);
+    if ((tid & 63) == 0) red[tid >> 6] = v0;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)ch;
+    __syncthreads();
+    float v1 = 0.f;
+    for (int i = tid; i < ch; i += 256) { const float d = e[i] - mean; v1 += d * d; }
+    v1 = wave_sum(v1);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = v1;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)ch + 1e-5f);
+    for (int i = tid; i < ch; i += 256) e[i] = (e[i] - mean) * rstd * lnw[i] + lnb[i];
+    __syncthreads();
+    for (int j = tid; j < cdim; j += 256) {
+        float acc = b1[j];
+        for (int i = 0; i < ch; ++i) acc = fmaf(w1[(size_t)j * ch + i], e[i], acc);
+        hdn[j] = silu_f(acc);
+    }
+    __syncthreads();
+    for (int j = tid; j < cdim; j += 256) {
+        float acc = b2[j];
+        for (int i = 0; i < cdim; ++i) acc = fmaf(w2[(size_t)j * cdim + i], hdn[i], acc);
+        out[(size_t)b * cdim + j] = acc;
+    }
+}
+
+const char* launch_class_embed(const long long* classes, int num_classes, int null_all, const float* emb, const float* null_emb,
+                               const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2, const float* b2,
+                               int ch, int cdim, float* out, int nrows, hipStream_t s) {
+    if (ch > 512 || cdim > 2048) return "class_embed: channels too large";
+    hipLaunchKernelGGL(class_embed_kernel, dim3(nrows), dim3(256), 0, s, classes, num_classes, null_all, emb, null_emb, lnw, lnb, w1, b1,
+                       w2, b2, ch, cdim, out, nrows);
+    return ADF_LAUNCH_CHECK("class_embed");
+}
+
+// Classifier-free guidance + EDM preconditioning (diffusion.py:52-59): out = clamp(c_skip x + c_out (n + (c - n) s), -1, 1)
+__global__ void __launch_bounds__(256) cfg_combine_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ fc,
+                                                          const float* __restrict__ fn, const float* __restrict__ coef, int coef_bstride,
+                                                          float scale, long long per_sample, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long b = i / per_sample;
+        const float c_skip = coef[b * coef_bstride + 2], c_out = coef[b * coef_bstride + 3];
+        const float nl = fn[i];
+        const float pred = nl + (fc[i] - nl) * scale;
+        out[i] = fminf(fmaxf(c_skip * x[i] + c_out * pred, -1.0f), 1.0f);
+    }
+}
+
+const char* launch_cfg_combine(float* out, const float* x, const float* fc, const float* fn, const float* coef, int coef_bstride,
+                               float scale, long long per_sample, long long n, hipStream_t s) {
+    long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s, out, x, fc, fn, coef,
+                       coef_bstride, scale, per_sample, n);
+    return ADF_LAUNCH_CHECK("cfg_combine");
 }
 
 // =====================================================================================================

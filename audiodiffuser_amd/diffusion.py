@@ -2,8 +2,9 @@
 (reference: src/models/components/diffusion.py:15-63 ``Diffusion``, :217-257 ``EluDiffusion``).
 
 ``denoise_fn`` keeps the reference signature.  When ``net`` is the HIP ``UNet1dBase`` and the call
-is the plain inference case (no classifier-free guidance, clamp clipping) the whole thing --
-c_in scaling, sigma embedding, U-Net, c_skip/c_out combine, clamp -- is one ``adf_denoise`` call.
+is the inference case with clamp clipping the whole thing -- c_in scaling, sigma embedding, U-Net,
+(for a class-conditional net: label embedding and classifier-free guidance), c_skip/c_out combine,
+clamp -- is one ``adf_denoise`` call.
 For any other ``net`` (e.g. an unpickled reference module, diffunet_complex_module.py:239-242) the
 same arithmetic is expressed with tensor ops around ``net(...)``; that branch exists for interface
 compatibility and is not the accelerated path.
@@ -46,8 +47,14 @@ class EluDiffusion(nn.Module):
         return (sigmas ** 2 + self.sigma_data ** 2) * (sigmas * self.sigma_data) ** -2
 
     def _native_ok(self, net, inference: bool, cond_scale: float, kwargs: dict) -> bool:
-        return (isinstance(net, UNet1dBase) and inference and cond_scale == 1.0 and self.dynamic_threshold == 0.0
-                and all(v is None for v in kwargs.values()))
+        """The HIP fast path covers inference with clamp clipping; the only conditioning kwarg it understands is
+        ``classes`` (labels) on a class-conditional net, where ``cond_scale != 1`` is classifier-free guidance."""
+        if not (isinstance(net, UNet1dBase) and inference and self.dynamic_threshold == 0.0):
+            return False
+        extra = {k: v for k, v in kwargs.items() if v is not None}
+        if net.cfg.class_cond:
+            return set(extra) == {"classes"}
+        return not extra and cond_scale == 1.0
 
     # diffusion.py:32-63
     def denoise_fn(self, x_noisy: Tensor, net: nn.Module = None, inference: bool = False, cond_scale: float = 1.0,
@@ -56,6 +63,8 @@ class EluDiffusion(nn.Module):
         if self._native_ok(net, inference, cond_scale, kwargs) and x_noisy.is_cuda:
             hd = net.native(x_noisy.device)
             x = x_noisy.detach().to(torch.float32).contiguous()
+            if net.cfg.class_cond:      # labels + guidance scale for this call (diffusion.py:49-54)
+                hd.set_condition(kwargs["classes"], x.device, null_labels=False, cond_scale=float(cond_scale))
             if sigmas is not None:
                 sv = sigmas.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
                 return hd.denoise(x, self.sigma_data, sigmas=sv).to(x_noisy.dtype)

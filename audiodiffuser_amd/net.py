@@ -77,6 +77,22 @@ class NativeHandle:
         if missing:
             raise _lib.AdfError(f"{missing} state_dict tensors were not provided to the HIP library")
 
+    # ---- class conditioning / classifier-free guidance state for the calls that follow -------
+    def set_condition(self, classes: Optional[torch.Tensor], device: torch.device, null_labels: bool = False,
+                      cond_scale: float = 1.0) -> None:
+        """``classes``: int64 labels [B] (or None to clear).  Mirrors ``UNet1dBase.forward(classes=, cond_drop_prob=)``
+        (cond_drop_prob 1 = ``null_labels``) and the ``cond_scale`` of ``Diffusion.denoise_fn`` (diffusion.py:49-54)."""
+        if classes is None:
+            self.check(self.lib.adf_set_condition(self.h, C.c_void_p(0), 0, 0, 1.0, C.c_void_p(_stream_ptr(device))), "adf_set_condition")
+            return
+        if not self.cfg.class_cond:
+            raise ValueError("classes were given to a network built without class_cond=True")
+        cl = classes.detach().to(device=device, dtype=torch.int64).reshape(-1).contiguous()
+        if cl.numel() and (int(cl.min()) < 0 or int(cl.max()) >= self.cfg.num_classes):
+            raise IndexError("class label out of range")           # nn.Embedding raises the same way
+        self.check(self.lib.adf_set_condition(self.h, C.c_void_p(cl.data_ptr()), cl.numel(), 1 if null_labels else 0, float(cond_scale),
+                                              C.c_void_p(_stream_ptr(device))), "adf_set_condition")
+
     # ---- compute entry points (all tensors fp32, contiguous, on the handle's device) ----
     def net_forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         out = torch.empty((x.shape[0], self.cfg.out_channels, x.shape[-1]), device=x.device, dtype=torch.float32)
@@ -132,7 +148,7 @@ def _init_like_reference(name: str, shape, kind: str) -> torch.Tensor:
         return t.fill_(1.0)
     if kind == "norm_b":
         return t.zero_()
-    if kind == "fourier":
+    if kind in ("fourier", "embed"):
         return t.normal_()
     raise ValueError(kind)
 
@@ -146,15 +162,18 @@ class UNet1dBase(nn.Module):
                  use_self_text_cond: bool = False, use_condition_block: bool = False,
                  compute_dtype: str = "fp32", native_flags: int = 0, **kwargs):
         super().__init__()
-        if class_cond or text_cond or use_condition_block:
-            raise NotImplementedError("class/text/channel conditioning is outside the round-1 hot path (SURVEY.md 8f)")
+        if text_cond or use_condition_block or use_self_text_cond:
+            raise NotImplementedError("text / channel conditioning is outside the hot path (SURVEY.md 8f)")
+        if class_cond and class_embed_dim is not None:
+            raise NotImplementedError("class_embed_dim (embedding inputs instead of labels) is outside the hot path")
         if compute_dtype not in _DTYPES:
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
         out_channels = kwargs.pop("out_channels", None)
         self.cond_drop_prob = cond_drop_prob
         self.compute_dtype = compute_dtype
         self.native_flags = native_flags
-        self.cfg = UNet1dConfig(channels=channels, cond_drop_prob=cond_drop_prob, **kwargs)
+        self.cfg = UNet1dConfig(channels=channels, cond_drop_prob=cond_drop_prob, class_cond=bool(class_cond),
+                                num_classes=num_classes if class_cond else None, **kwargs)
         self.cfg.out_channels = out_channels if out_channels is not None else self.cfg.in_channels  # unet1d.py:607
         self.cfg.validate()
         self._specs = param_specs(self.cfg)
@@ -192,9 +211,20 @@ class UNet1dBase(nn.Module):
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, classes=None, text_embeds=None, text_mask=None,
                 inj_embeddings=None, inj_channels=None, cond_drop_prob=None, **kwargs) -> torch.Tensor:
-        if classes is not None or text_embeds is not None or inj_embeddings is not None or inj_channels is not None:
-            raise NotImplementedError("conditioning inputs are outside the round-1 hot path (SURVEY.md 8f)")
+        if text_embeds is not None or inj_embeddings is not None or inj_channels is not None:
+            raise NotImplementedError("text / injected conditioning inputs are outside the hot path (SURVEY.md 8f)")
         hd = self.native(x.device)
+        if self.cfg.class_cond:
+            # unet1d.py:874-877: labels -> LabelEmbedder(classes, cond_drop_prob); the label mask is deterministic only
+            # at cond_drop_prob 0 (keep all) and 1 (null embedding for all), the two values inference uses
+            if classes is None:
+                raise ValueError("a class-conditional UNet1dBase needs `classes`")
+            cdp = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+            if cdp not in (0, 0.0, 1, 1.0):
+                raise NotImplementedError("cond_drop_prob other than 0 or 1 draws a random label mask (training only)")
+            hd.set_condition(classes, x.device, null_labels=bool(cdp), cond_scale=1.0)
+        elif classes is not None:
+            raise ValueError("classes were given to a network built without class_cond=True")
         xin = x.detach().to(torch.float32).contiguous()
         tin = t.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         if tin.numel() != xin.shape[0]:

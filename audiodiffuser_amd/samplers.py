@@ -24,12 +24,24 @@ from .net import UNet1dBase
 
 
 def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict) -> Optional[EluDiffusion]:
+    """The whole loop runs inside the HIP library when ``fn`` is this package's ``EluDiffusion.denoise_fn`` and ``net``
+    its ``UNet1dBase``.  The only conditioning it understands is ``classes`` (labels) on a class-conditional net, where
+    ``cond_scale != 1`` is classifier-free guidance (two network passes per evaluation)."""
     owner = getattr(fn, "__self__", None)
-    if (isinstance(owner, EluDiffusion) and getattr(fn, "__func__", None) is EluDiffusion.denoise_fn
-            and isinstance(net, UNet1dBase) and cond_scale == 1.0 and owner.dynamic_threshold == 0.0
-            and all(v is None for v in kwargs.values())):
-        return owner
-    return None
+    if not (isinstance(owner, EluDiffusion) and getattr(fn, "__func__", None) is EluDiffusion.denoise_fn
+            and isinstance(net, UNet1dBase) and owner.dynamic_threshold == 0.0):
+        return None
+    extra = {k: v for k, v in kwargs.items() if v is not None}
+    if net.cfg.class_cond:
+        return owner if set(extra) == {"classes"} else None
+    return owner if (not extra and cond_scale == 1.0) else None
+
+
+def _condition(net: UNet1dBase, hd, device, cond_scale: float, kwargs: dict) -> None:
+    """Labels + guidance scale of this sampler run (the reference forwards them to every fn call, e.g.
+    sampler_edm.py:341-345)."""
+    if net.cfg.class_cond:
+        hd.set_condition(kwargs["classes"], device, null_labels=False, cond_scale=float(cond_scale))
 
 
 def _prep(noise: Tensor) -> Tensor:
@@ -61,6 +73,7 @@ class EDMSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
             inj = injected_noise
             if inj is None and self.s_churn > 0:
                 # same draw order as the reference's per-step randn_like (sampler_edm.py:346)
@@ -110,7 +123,9 @@ class EDMAlphaSampler(nn.Module):
         diff = _native_pair(fn, net, self.cond_scale, kwargs)
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
-            return net.native(x.device).sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         x = sigmas[0] * noise                                            # sampler_edm.py:284-300
         for i in range(self.num_steps - 1):
             s, s_next = sigmas[i], sigmas[i + 1]
@@ -158,7 +173,9 @@ class DPMSampler(nn.Module):
         diff = _native_pair(fn, net, self.cond_scale, kwargs)
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
-            return net.native(x.device).sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         # ---- interface-compatibility branch (sampler_edm.py:710-768, :624-690) --------------------
         steps, order = self.num_steps, self.order
         assert steps >= order

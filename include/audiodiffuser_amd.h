@@ -34,7 +34,7 @@ extern "C" {
 #define ADF_DTYPE_F32 0  /* parity mode: fp32 storage, exact-fp32 MFMA */
 #define ADF_DTYPE_BF16 1 /* throughput mode: bf16 storage, fp32 accumulate */
 
-/* Hyper-parameters of UNet1dBase (unconditional path); same meaning as the reference kwargs. */
+/* Hyper-parameters of UNet1dBase; same meaning as the reference kwargs. */
 typedef struct adf_net_config {
     int32_t channels, num_filters, window_length, stride, in_channels, out_channels;
     int32_t resnet_groups, kernel_multiplier_downsample;
@@ -47,6 +47,7 @@ typedef struct adf_net_config {
     int32_t use_skip_scale, use_attention_bottleneck;
     int32_t dtype;                          /* ADF_DTYPE_* */
     int32_t flags;                          /* ADF_FLAG_* */
+    int32_t num_classes;                    /* > 0: class_cond=True with that many labels (LabelEmbedder); 0: unconditional */
 } adf_net_config;
 
 #define ADF_FLAG_SEPARATE_GN_STATS 1 /* compute GroupNorm statistics in a separate pass instead of the GEMM epilogue */
@@ -78,6 +79,14 @@ const char* adf_weight_name(const adf_handle* h, int index);
 int64_t adf_weight_numel(const adf_handle* h, int index);
 int adf_load_weight(adf_handle* h, const char* name, const float* dev_fp32, int64_t numel, void* stream);
 int adf_weights_missing(const adf_handle* h);      /* number of tensors not loaded yet */
+
+/* Class conditioning / classifier-free guidance for the calls that follow with the same B
+ * (UNet1dBase.forward(classes=, cond_drop_prob=) unet1d.py:864-893, LabelEmbedder conditioner.py:59-111, the CFG branch
+ * of Diffusion.denoise_fn diffusion.py:49-54).  classes_dev: int64 [B] labels on the device, or NULL to clear the
+ * condition.  null_labels != 0: every sample uses the null embedding (cond_drop_prob = 1).  cond_scale applies to
+ * adf_denoise / adf_sampler_run only: != 1 runs the network twice per evaluation (labels, null) and combines
+ * null + (cond - null) * cond_scale before the EDM preconditioning.  A class-conditional network needs a condition. */
+int adf_set_condition(adf_handle* h, const int64_t* classes_dev, int B, int null_labels, float cond_scale, void* stream);
 
 /* out = net(x, t):  x [B][in_channels][L], t [B], out [B][out_channels][L] */
 int adf_net_forward(adf_handle* h, const float* x, const float* t, float* out, int B, int L, void* stream);

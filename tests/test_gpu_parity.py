@@ -232,3 +232,57 @@ def test_pipelined_dma_gemm_route_matches_default_route(tmp_path):
     # first resblock after the switch: only the accumulation order differs; end of the net: bf16 rounding noise compounds
     assert rel("down0.block0") < 1e-3, rel("down0.block0")
     assert rel("out") < 3e-2, rel("out")
+
+
+# ---- class conditioning + classifier-free guidance ------------------------------------
+def _cc_net(dtype="fp32"):
+    cfg = A.config_tiny_cc()
+    net = A.UNet1dBase.from_config(cfg, compute_dtype=dtype)
+    w = generate_weights(cfg, seed=0)
+    net.load_state_dict(w)
+    return cfg, w, net.cuda()
+
+
+@pytest.mark.parametrize("tag,cdp", [("cond", 0.0), ("null", 1.0)])
+def test_class_cond_net_vs_reference_golden(golden, tag, cdp):
+    """UNet1dBase.forward(classes=, cond_drop_prob=) on the HIP path against the reference's own output."""
+    cfg, w, net = _cc_net()
+    y = net(T(golden["cc_net_x"]).cuda(), T(golden["cc_net_t"]).cuda(), classes=T(golden["cc_classes"]).cuda(), cond_drop_prob=cdp)
+    assert rel_err(y.cpu(), T(golden[f"cc_net_{tag}_y"])) < FP32_TIGHT
+    with pytest.raises(ValueError):
+        net(T(golden["cc_net_x"]).cuda(), T(golden["cc_net_t"]).cuda())            # labels are required
+    with pytest.raises(IndexError):
+        net(T(golden["cc_net_x"]).cuda(), T(golden["cc_net_t"]).cuda(), classes=torch.tensor([0, 1, 10]).cuda())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_cfg_denoise_and_sampler_vs_reference_golden(golden, graph):
+    """Classifier-free guidance: denoise_fn(cond_scale != 1) and a guided 8-step Heun run (15 NFE x 2 network
+    passes) against the reference's outputs; eager and hipGraph."""
+    cfg, w, net = _cc_net()
+    d = A.EluDiffusion(sigma_data=0.2)
+    classes = T(golden["cc_classes"]).cuda()
+    xn = generate_noise(50, 3, 256).cuda()
+    for si, (sg, cs) in enumerate(((8.0, 2.5), (0.6, 7.0))):
+        y = d.denoise_fn(xn * sg, net=net, sigma=torch.tensor(sg), inference=True, cond_scale=cs, classes=classes)
+        assert rel_err(y.cpu(), T(golden[f"cc_denoise_{si}"])) < FP32_TIGHT, si
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 8)()
+    smp = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=8, use_heun=True, cond_scale=3.0, use_graph=graph)
+    nz = generate_noise(60, 3, 256).cuda()
+    for _ in range(2):                                   # second call replays the captured graph
+        y = smp(nz, fn=d.denoise_fn, net=net, sigmas=sig, classes=classes)
+        assert rel_err(y.cpu(), T(golden["cc_heun8_final"])) < FP32_TOL
+    # other labels through the same captured graph must change the result (the condition buffers are re-filled)
+    y2 = smp(nz, fn=d.denoise_fn, net=net, sigmas=sig, classes=torch.tensor([1, 1, 1]).cuda())
+    assert rel_err(y2.cpu(), T(golden["cc_heun8_final"])) > 1e-3
+
+
+def test_cfg_bf16_close_to_fp32():
+    cfg, w, net16 = _cc_net("bf16")
+    _, _, net32 = _cc_net("fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    x = (generate_noise(5, 4, 1024) * 2.0).cuda()
+    cl = torch.tensor([0, 3, 7, 9]).cuda()
+    a = d.denoise_fn(x, net=net16, sigma=torch.tensor(2.0), inference=True, cond_scale=4.0, classes=cl)
+    b = d.denoise_fn(x, net=net32, sigma=torch.tensor(2.0), inference=True, cond_scale=4.0, classes=cl)
+    assert rel_err(a, b) < BF16_TOL

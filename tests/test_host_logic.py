@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.AdfNetConfig) == 4 * (9 + 13 + 12 * 3 + 4 + 2)
+    assert C.sizeof(_lib.AdfNetConfig) == 4 * (9 + 13 + 12 * 3 + 4 + 2 + 1)
     assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 11
 
 
@@ -86,9 +86,32 @@ def test_net_plugin_refuses_cpu_and_conditioning():
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 1, 64), torch.zeros(1))      # no CPU fallback for the HIP path
     with pytest.raises(NotImplementedError):
-        A.UNet1dBase(class_cond=True, num_classes=10, **A.config_tiny().to_kwargs())
+        A.UNet1dBase(text_cond=True, **A.config_tiny().to_kwargs())
+    with pytest.raises(NotImplementedError):
+        A.UNet1dBase(class_cond=True, class_embed_dim=32, **A.config_tiny().to_kwargs())
+    with pytest.raises(ValueError):
+        A.UNet1dBase(class_cond=True, **A.config_tiny().to_kwargs())      # needs num_classes
     with pytest.raises(ValueError):
         A.UNet1dBase(compute_dtype="fp8", **A.config_tiny().to_kwargs())
+
+
+def test_class_cond_plugin_contract():
+    """class_cond=True: LabelEmbedder parameters come first and every FiLM Linear reads cat(time, class) embeddings,
+    exactly the reference's state_dict (tests/golden/state_dict_layout.json "tiny_cc")."""
+    import json
+    lay = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))["tiny_cc"]
+    net = A.UNet1dBase.from_config(A.config_tiny_cc())
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(lay["keys"].keys())
+    assert all(list(v.shape) == lay["keys"][k] for k, v in sd.items())
+    c = _lib.make_config(net.cfg, _lib.DTYPE_F32)
+    assert c.num_classes == 10 and _lib.make_config(A.config_tiny(), _lib.DTYPE_F32).num_classes == 0
+    # the fast path takes `classes` (and any cond_scale) only for a class-conditional net
+    d = A.EluDiffusion(sigma_data=0.2)
+    assert d._native_ok(net, True, 3.0, {"classes": torch.zeros(2, dtype=torch.int64)})
+    assert not d._native_ok(net, True, 3.0, {"classes": torch.zeros(2, dtype=torch.int64), "text_embeds": torch.zeros(1)})
+    plain = A.UNet1dBase.from_config(A.config_tiny())
+    assert d._native_ok(plain, True, 1.0, {}) and not d._native_ok(plain, True, 2.0, {})
 
 
 def test_scale_weights_plugin(golden):

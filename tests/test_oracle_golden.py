@@ -149,3 +149,42 @@ def test_samplers_with_tiny_net(golden):
         inj = torch.stack([torch.randn((2, 1, 256), generator=torch.Generator().manual_seed(9000 + i)) for i in range(12)])
         y = S.edm_sampler(noise, fn, s12, 12, s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, injected_noise=inj)
         assert rel(y, T(golden["smp_churn12_tiny_net_final"])) < 1e-5
+
+
+# ---- class conditioning + classifier-free guidance ---------------------------------------
+def _cc():
+    from audiodiffuser_amd.config import config_tiny_cc
+    cfg = config_tiny_cc()
+    return cfg, generate_weights(cfg, seed=0)
+
+
+def test_class_cond_layout_matches_reference():
+    cfg, w = _cc()
+    lay = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))["tiny_cc"]
+    assert list(w.keys()) == list(lay["keys"].keys())                       # LabelEmbedder first, reference order
+    assert all(list(v.shape) == lay["keys"][k] for k, v in w.items())
+    assert count_parameters(cfg) == lay["num_params"]
+
+
+@pytest.mark.parametrize("tag,cdp", [("cond", 0.0), ("null", 1.0)])
+def test_class_cond_net(golden, tag, cdp):
+    cfg, w = _cc()
+    with torch.no_grad():
+        y = O.unet1d_forward(w, cfg, T(golden["cc_net_x"]), T(golden["cc_net_t"]), classes=T(golden["cc_classes"]), cond_drop_prob=cdp)
+    assert rel(y, T(golden[f"cc_net_{tag}_y"])) < 1e-6
+
+
+def test_cfg_denoise_and_sampler(golden):
+    cfg, w = _cc()
+    classes = T(golden["cc_classes"])
+    xn = generate_noise(50, 3, 256)
+    with torch.no_grad():
+        for si, (sg, cs) in enumerate(((8.0, 2.5), (0.6, 7.0))):
+            o = E.make_denoiser(w, cfg, 0.2, classes=classes, cond_scale=cs)(xn * sg, sigma=torch.tensor(sg))
+            assert rel(o, T(golden[f"cc_denoise_{si}"])) < 2e-5
+        sig = E.karras_sigmas(0.002, 80.0, 7.0, 8)
+        y = S.edm_sampler(generate_noise(60, 3, 256), E.make_denoiser(w, cfg, 0.2, classes=classes, cond_scale=3.0), sig, 8,
+                          s_churn=0.0, s_noise=1.0)
+    assert rel(y, T(golden["cc_heun8_final"])) < 5e-4
+    with pytest.raises(ValueError):
+        O.label_embedding(w, classes, 0.3)        # random label masks are a training-time feature
