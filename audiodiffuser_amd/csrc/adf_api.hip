@@ -734,8 +734,87 @@ int run_dpm(SamplerCtx& c, float** result) {
     return 0;
 }
 
+// DPM2Sampler: sampler_edm.py:470-493 (loop over num_steps-1 steps, final clamp), :428-468 (step).  As written in
+// the reference the churned point only feeds the first derivative; both updates start from the un-churned x.
+int run_dpm2(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int N = d.num_steps;
+    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "DPM2Sampler: need at least num_steps (>= 2) sigmas");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* XH = c.count_only ? nullptr : p->sb[2];
+    float* X2 = c.count_only ? nullptr : p->sb[3];
+    float* DEN = c.count_only ? nullptr : p->sb[5];
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    const float gmax = fminf(d.s_churn / (float)N, (float)(std::sqrt(2.0) - 1.0));
+    for (int i = 0; i + 1 < N; ++i) {
+        const float sg = c.sig[i], sn = c.sig[i + 1];
+        const float gamma = (sg >= d.s_tmin && sg <= d.s_tmax) ? gmax : 0.0f;
+        const float s_hat = sg + gamma * sg;
+        const float* xh = X;
+        if (gamma > 0.f) {
+            if (!c.count_only) {
+                if (!p->inj_stage) return fail(c.h, "DPM2Sampler with churn needs injected_noise");
+                const float cc = sqrtf(s_hat * s_hat - sg * sg);
+                if (c.ck(launch_churn(XH, X, p->inj_stage + (size_t)i * c.n, cc, d.s_noise, c.n, c.s))) return 1;
+            }
+            xh = XH;
+        }
+        if (c.den(xh, s_hat, DEN)) return 1;
+        if (sn == 0.0f) {
+            if (!c.count_only && c.ck(launch_dstep(XN, X, xh, DEN, s_hat, sn - s_hat, c.n, c.s))) return 1;
+        } else {
+            const float lh = logf(s_hat), ln = logf(sn);
+            const float s_mid = expf(lh + 0.5f * (ln - lh));                 // log().lerp(log(), 0.5).exp() in fp32
+            if (!c.count_only && c.ck(launch_dstep(X2, X, xh, DEN, s_hat, s_mid - s_hat, c.n, c.s))) return 1;
+            if (c.den(X2, s_mid, DEN)) return 1;
+            if (!c.count_only && c.ck(launch_dstep(XN, X, X2, DEN, s_mid, sn - s_hat, c.n, c.s))) return 1;
+        }
+        std::swap(X, XN);
+    }
+    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
+    *result = X;
+    return 0;
+}
+
+// ADPM2Sampler: stochastic_sampler_edm.py:85-100 (loop, final clamp), :53-83 (step), :29-32 (get_sigmas); fp32 scalars
+int run_adpm2(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int N = d.num_steps;
+    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "ADPM2Sampler: need at least num_steps (>= 2) sigmas");
+    if (!(d.rho > 0.f)) return c.count_only ? 1 : fail(c.h, "ADPM2Sampler: rho must be positive");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* XM = c.count_only ? nullptr : p->sb[3];
+    float* DEN = c.count_only ? nullptr : p->sb[5];
+    if (!c.count_only && !p->inj_stage) return fail(c.h, "ADPM2Sampler needs injected_noise (one draw per step)");
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    for (int i = 0; i + 1 < N; ++i) {
+        const float sg = c.sig[i], sn = c.sig[i + 1];
+        const float up_raw = d.eta * sqrtf(sn * sn * (sg * sg - sn * sn) / (sg * sg));
+        const float s_up = sn < up_raw ? sn : up_raw;                          // python min(sigma_next, ...)
+        const float s_down = sqrtf(sn * sn - s_up * s_up);
+        const float inv = 1.0f / d.rho;
+        const float s_mid = powf((powf(sg, inv) + powf(s_down, inv)) / 2.0f, d.rho);
+        if (c.den(X, sg, DEN)) return 1;
+        if (!c.count_only && c.ck(launch_dstep(XM, X, X, DEN, sg, s_mid - sg, c.n, c.s))) return 1;
+        if (c.den(XM, s_mid, DEN)) return 1;
+        if (!c.count_only) {
+            if (c.ck(launch_dstep(XN, X, XM, DEN, s_mid, s_down - sg, c.n, c.s))) return 1;
+            if (c.ck(launch_churn(X, XN, p->inj_stage + (size_t)i * c.n, s_up, 1.0f, c.n, c.s))) return 1;   // x + sigma_up * randn
+        }
+    }
+    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
+    *result = X;
+    return 0;
+}
+
 int run_sampler(SamplerCtx& c, float** result) {
     switch (c.d->kind) {
+        case ADF_SAMPLER_DPM2: return run_dpm2(c, result);
+        case ADF_SAMPLER_ADPM2: return run_adpm2(c, result);
         case ADF_SAMPLER_EDM: return run_edm(c, result);
         case ADF_SAMPLER_EDM_ALPHA: return run_edm_alpha(c, result);
         case ADF_SAMPLER_DPM_MULTISTEP: return run_dpm(c, result);
@@ -890,7 +969,9 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     }
     if (hipMemcpyAsync(p->noise_stage, noise, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "noise copy failed");
     if (injected_noise) {
-        const size_t need = (size_t)desc->num_steps * n;
+        // one draw per step: the EDM sampler steps num_steps times, the DPM2 family num_steps - 1 times
+        const int ndraws = (desc->kind == ADF_SAMPLER_DPM2 || desc->kind == ADF_SAMPLER_ADPM2) ? desc->num_steps - 1 : desc->num_steps;
+        const size_t need = (size_t)(ndraws > 0 ? ndraws : 0) * n;
         if (p->inj_cap < need) {
             p->inj_stage = (float*)dalloc(h, need * 4);
             if (!p->inj_stage) return fail(h, "device allocation failed for injected noise");
@@ -899,8 +980,10 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
             p->graphs.clear();
         }
         if (hipMemcpyAsync(p->inj_stage, injected_noise, need * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "injected-noise copy failed");
-    } else if (desc->kind == ADF_SAMPLER_EDM && desc->s_churn > 0.f) {
-        return fail(h, "EDMSampler with s_churn > 0 needs injected_noise (pre-drawn randn_like tensors)");
+    } else if ((desc->kind == ADF_SAMPLER_EDM || desc->kind == ADF_SAMPLER_DPM2) && desc->s_churn > 0.f) {
+        return fail(h, "a sampler with s_churn > 0 needs injected_noise (pre-drawn randn_like tensors)");
+    } else if (desc->kind == ADF_SAMPLER_ADPM2) {
+        return fail(h, "ADPM2Sampler needs injected_noise (one pre-drawn randn_like tensor per step)");
     }
     SamplerCtx c{h, p, desc, sigmas_host, n_sigmas, s, n};
     float* result = nullptr;

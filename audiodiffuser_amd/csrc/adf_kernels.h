@@ -85,6 +85,9 @@ struct DpmArgs {
     const float* m0; const float* m1; const float* m2;
 };
 const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st);
+// x_next = x_base + ((x_eval - den) / sigma) * dt  (DPM2 / ancestral DPM2 steps)
+const char* launch_dstep(float* x_next, const float* x_base, const float* x_eval, const float* den, float sigma, float dt, long long n,
+                         hipStream_t st);
 const char* launch_clamp(float* x, long long n, hipStream_t st);
 
 const char* launch_nlc_to_ncl_f32(const void* x, float* y, int bf16, int B, int L, int C, hipStream_t st);

@@ -896,6 +896,12 @@ __global__ void __launch_bounds__(256) churn_kernel(float* o, const float* x, co
 __global__ void __launch_bounds__(256) euler_kernel(float* xn, float* d, const float* x, const float* den, float sigma, float dt, long long n) {
     ADF_EW_LOOP { const float dd = (x[i] - den[i]) / sigma; d[i] = dd; xn[i] = x[i] + dt * dd; }
 }
+// x_next = x_base + ((x_eval - den) / sigma) * dt: the update of the DPM2-family steps, whose derivative is taken at
+// x_eval but applied to x_base (sampler_edm.py:448-464, stochastic_sampler_edm.py:69-81)
+__global__ void __launch_bounds__(256) dstep_kernel(float* xn, const float* xb, const float* xe, const float* den, float sigma, float dt,
+                                                    long long n) {
+    ADF_EW_LOOP { const float dd = (xe[i] - den[i]) / sigma; xn[i] = xb[i] + dd * dt; }
+}
 __global__ void __launch_bounds__(256) rk2_kernel(float* xn, const float* x, const float* d, const float* xe, const float* den2,
                                                   float sigma2, float h, float w1, float w2, long long n) {
     ADF_EW_LOOP { const float d2 = (xe[i] - den2[i]) / sigma2; xn[i] = x[i] + h * (w1 * d[i] + w2 * d2); }
@@ -941,6 +947,10 @@ const char* launch_rk2(float* x_next, const float* x, const float* d, const floa
 const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st) {
     hipLaunchKernelGGL(dpm_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x_out, x, a, clamp, n);
     return ADF_LAUNCH_CHECK("dpm_update");
+}
+const char* launch_dstep(float* xn, const float* xb, const float* xe, const float* den, float sigma, float dt, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(dstep_kernel, dim3(ew_grid(n)), dim3(256), 0, st, xn, xb, xe, den, sigma, dt, n);
+    return ADF_LAUNCH_CHECK("dstep");
 }
 const char* launch_clamp(float* x, long long n, hipStream_t st) {
     hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, n);

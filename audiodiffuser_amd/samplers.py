@@ -207,3 +207,99 @@ class DPMSampler(nn.Module):
             if step < steps:
                 m_hist = (m_hist + [call(x, s_cur)])[-order:]
         return x.clamp(-1.0, 1.0)
+
+
+class DPM2Sampler(nn.Module):
+    """'DPM2 Karras' (reference: src/models/components/sampler_edm.py:401-493): midpoint method in log-sigma with the
+    EDM churn.  ``injected_noise`` ([num_steps-1, B, C, L]) replaces the per-step ``randn_like`` draws."""
+
+    def __init__(self, rho: float = 2.0, num_steps: int = 50, cond_scale: float = 1.0, s_tmin: float = 0,
+                 s_tmax: float = float("inf"), s_churn: float = 150.0, s_noise: float = 1.04, use_graph: bool = True):
+        super().__init__()
+        self.rho, self.num_steps, self.cond_scale = rho, num_steps, cond_scale
+        self.s_tmin, self.s_tmax, self.s_noise, self.s_churn, self.use_graph = s_tmin, s_tmax, s_noise, s_churn, use_graph
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_DPM2, self.num_steps
+        d.s_tmin, d.s_tmax, d.s_churn, d.s_noise = self.s_tmin, min(self.s_tmax, 3.0e38), self.s_churn, self.s_noise
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, 0, sigma_data, int(self.use_graph)
+        d.rho, d.eta = float(self.rho), 1.0
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
+                **kwargs) -> Tensor:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            inj = injected_noise
+            if inj is None and self.s_churn > 0:
+                inj = torch.stack([torch.randn_like(x) for _ in range(self.num_steps - 1)])   # reference draw order (:439)
+            if inj is not None:
+                inj = inj.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
+        # ---- interface-compatibility branch (sampler_edm.py:428-493) ----------------------------------
+        x = sigmas[0] * noise
+        gam = torch.where((sigmas >= self.s_tmin) & (sigmas <= self.s_tmax), min(self.s_churn / self.num_steps, sqrt(2) - 1), 0.0)
+        for i in range(self.num_steps - 1):
+            s, s_next, g = sigmas[i], sigmas[i + 1], gam[i]
+            s_hat = s + g * s
+            eps = self.s_noise * (injected_noise[i] if injected_noise is not None else torch.randn_like(x))
+            x_hat = x + (s_hat ** 2 - s ** 2) ** 0.5 * eps if g > 0 else x
+            d = (x_hat - fn(x_hat, net=net, sigma=s_hat, inference=True, cond_scale=self.cond_scale, **kwargs)) / s_hat
+            if s_next == 0.0:
+                x = x + d * (s_next - s_hat)
+            else:
+                s_mid = s_hat.log().lerp(s_next.log(), 0.5).exp()
+                x_2 = x + d * (s_mid - s_hat)
+                d_2 = (x_2 - fn(x_2, net=net, sigma=s_mid, inference=True, cond_scale=self.cond_scale, **kwargs)) / s_mid
+                x = x + d_2 * (s_next - s_hat)
+        return x.clamp(-1.0, 1.0)
+
+
+class ADPM2Sampler(nn.Module):
+    """'DPM2 a Karras', the ancestral DPM-Solver-2 (reference: src/models/components/stochastic_sampler_edm.py:35-100;
+    the Lightning module's default sampler).  Fresh noise of scale sigma_up is added every step:
+    ``injected_noise`` ([num_steps-1, B, C, L]) replaces those ``randn_like`` draws."""
+
+    def __init__(self, rho: float = 1.0, num_steps: int = 50, cond_scale: float = 1.0, eta: float = 1.0, use_graph: bool = True):
+        super().__init__()
+        self.rho, self.num_steps, self.cond_scale, self.eta, self.use_graph = rho, num_steps, cond_scale, eta, use_graph
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_ADPM2, self.num_steps
+        d.s_tmin, d.s_tmax, d.s_churn, d.s_noise = 0.0, 3.0e38, 0.0, 1.0
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, 0, sigma_data, int(self.use_graph)
+        d.rho, d.eta = float(self.rho), float(self.eta)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
+                **kwargs) -> Tensor:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            inj = injected_noise
+            if inj is None:
+                inj = torch.stack([torch.randn_like(x) for _ in range(self.num_steps - 1)])   # reference draw order (:82)
+            inj = inj.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
+        # ---- interface-compatibility branch (stochastic_sampler_edm.py:29-32, :53-100) -----------------
+        x = sigmas[0] * noise
+        for i in range(self.num_steps - 1):
+            s, s_next = sigmas[i], sigmas[i + 1]
+            s_up = min(s_next, self.eta * (s_next ** 2 * (s ** 2 - s_next ** 2) / s ** 2) ** 0.5)
+            s_down = (s_next ** 2 - s_up ** 2) ** 0.5
+            d = (x - fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)) / s
+            s_mid = ((s ** (1 / self.rho) + s_down ** (1 / self.rho)) / 2) ** self.rho
+            x_mid = x + d * (s_mid - s)
+            d_mid = (x_mid - fn(x_mid, net=net, sigma=s_mid, inference=True, cond_scale=self.cond_scale, **kwargs)) / s_mid
+            x = x + d_mid * (s_down - s)
+            x = x + (injected_noise[i] if injected_noise is not None else torch.randn_like(x)) * s_up
+        return x.clamp(-1.0, 1.0)

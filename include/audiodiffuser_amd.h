@@ -6,8 +6,9 @@
  *   adf_net_forward                <- UNet1dBase.forward            (src/models/backbones/unet1d.py:864-893, :771-816)
  *   adf_denoise                    <- Diffusion.denoise_fn + EluDiffusion.get_scale_weights + clip
  *                                     (src/models/components/diffusion.py:32-63, :232-241; components/utils.py:20-22)
- *   adf_sampler_run                <- EDMSampler.forward / EDMAlphaSampler.forward / DPMSampler.forward (multistep)
- *                                     (src/models/components/sampler_edm.py:371-397, :284-300, :710-768)
+ *   adf_sampler_run                <- EDMSampler.forward / EDMAlphaSampler.forward / DPMSampler.forward (multistep) /
+ *                                     DPM2Sampler.forward (src/models/components/sampler_edm.py:371-397, :284-300,
+ *                                     :710-768, :470-493) and ADPM2Sampler.forward (stochastic_sampler_edm.py:85-100)
  *   the call site all of them sit behind: src/models/diffunet_complex_module.py:86-89
  *
  * Conventions
@@ -55,6 +56,8 @@ typedef struct adf_net_config {
 #define ADF_SAMPLER_EDM 0       /* EDMSampler: Heun + optional churn      */
 #define ADF_SAMPLER_EDM_ALPHA 1 /* EDMAlphaSampler: generalised RK2        */
 #define ADF_SAMPLER_DPM_MULTISTEP 2 /* DPMSampler(multisteps=True, x0_pred=True, log_time_spacing=False) */
+#define ADF_SAMPLER_DPM2 3      /* DPM2Sampler ("DPM2 Karras", optional churn)   sampler_edm.py:401-493 */
+#define ADF_SAMPLER_ADPM2 4     /* ADPM2Sampler ("DPM2 a Karras", ancestral)     stochastic_sampler_edm.py:35-100 */
 
 typedef struct adf_sampler_desc {
     int32_t kind;
@@ -65,6 +68,7 @@ typedef struct adf_sampler_desc {
     int32_t order;       /* DPM: 1..3 */
     float sigma_data;    /* EluDiffusion.sigma_data */
     int32_t use_graph;   /* capture the whole step loop into one hipGraph and replay it */
+    float rho, eta;      /* ADPM2 */
 } adf_sampler_desc;
 
 typedef struct adf_handle adf_handle;
@@ -97,7 +101,8 @@ int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, fl
 
 /* Full sampling loop.  sigmas_host: the schedule tensor (host, n_sigmas entries) the reference passes as
  * `sigmas`; noise: unit-variance [B][C][L]; injected_noise: [num_steps][B][C][L] draws replacing
- * randn_like (required when the EDM sampler churns, may be NULL otherwise). */
+ * randn_like, one per step in the reference's order (required when the EDM / DPM2 sampler churns and always for
+ * ADPM2, which adds noise every step; may be NULL otherwise). */
 int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas,
                     const float* noise, const float* injected_noise, float* out, int B, int L, void* stream);
 int adf_sampler_nfe(const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas);

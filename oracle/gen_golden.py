@@ -44,8 +44,11 @@ def import_reference():
     from src.models.components.diffusion import EluDiffusion
     from src.models.components.sampler_edm import EDMSampler, EDMAlphaSampler, DPMSampler
     from src.models.components.scheduler import KarrasSchedule
+    from src.models.components.sampler_edm import DPM2Sampler
+    from src.models.components.stochastic_sampler_edm import ADPM2Sampler
     return dict(UNet1dBase=UNet1dBase, EluDiffusion=EluDiffusion, EDMSampler=EDMSampler,
-                EDMAlphaSampler=EDMAlphaSampler, DPMSampler=DPMSampler, KarrasSchedule=KarrasSchedule)
+                EDMAlphaSampler=EDMAlphaSampler, DPMSampler=DPMSampler, KarrasSchedule=KarrasSchedule,
+                DPM2Sampler=DPM2Sampler, ADPM2Sampler=ADPM2Sampler)
 
 
 def build_ref_net(ref, cfg, weights):
@@ -325,6 +328,45 @@ def main():
         out["cc_heun8_final"] = y.numpy()
     assert max(cfg_report.values()) < 5e-4, cfg_report
     report["class_cond_cfg"] = cfg_report
+
+    # ---- 8. DPM2 / ancestral DPM2 samplers with recorded randn draws ------------
+    cfg, w, net = nets["tiny"]
+    fn_o = E.make_denoiser(w, cfg, 0.2)
+    noise = generate_noise(70, 2, 256)
+    sg = E.karras_sigmas(0.002, 80.0, 7.0, 10)
+    more = {}
+
+    def run_recorded(sampler, seed0):
+        draws = []
+        real = torch.randn_like
+        def rec(x, *a, **k):
+            g = torch.Generator(); g.manual_seed(seed0 + len(draws))
+            z = torch.randn(x.shape, generator=g, dtype=x.dtype); draws.append(z); return z
+        torch.randn_like = rec
+        try:
+            with torch.no_grad():
+                y = sampler(noise, fn=diff.denoise_fn, net=net, sigmas=sg)
+        finally:
+            torch.randn_like = real
+        return y, torch.stack(draws)
+
+    y, inj = run_recorded(ref["DPM2Sampler"](num_steps=10, s_tmin=0.05, s_tmax=50.0, s_churn=30.0, s_noise=1.003), 9100)
+    with torch.no_grad():
+        yo = S.dpm2_sampler(noise, fn_o, sg, 10, s_tmin=0.05, s_tmax=50.0, s_churn=30.0, s_noise=1.003, injected_noise=inj)
+    more["dpm2_churn"] = rel_err(yo, y); out["smp_dpm2_churn10_final"] = y.numpy()
+    assert inj.shape[0] == 9
+    y, inj = run_recorded(ref["DPM2Sampler"](num_steps=10, s_churn=0.0, s_noise=1.0), 9200)
+    with torch.no_grad():
+        yo = S.dpm2_sampler(noise, fn_o, sg, 10, s_churn=0.0, s_noise=1.0, injected_noise=inj)
+    more["dpm2_ode"] = rel_err(yo, y); out["smp_dpm2_ode10_final"] = y.numpy()
+    for rho, eta, tag in ((1.0, 1.0, "r1"), (7.0, 0.6, "r7")):
+        y, inj = run_recorded(ref["ADPM2Sampler"](rho=rho, num_steps=10, eta=eta), 9300)
+        with torch.no_grad():
+            yo = S.adpm2_sampler(noise, fn_o, sg, 10, rho=rho, eta=eta, injected_noise=inj)
+        more[f"adpm2_{tag}"] = rel_err(yo, y); out[f"smp_adpm2_{tag}_final"] = y.numpy()
+        assert inj.shape[0] == 9
+    assert max(more.values()) < 5e-4, more
+    report["dpm2_samplers"] = more
 
     print(json.dumps(report, indent=1))
     if args.check_only:

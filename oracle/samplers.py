@@ -111,3 +111,44 @@ def dpm_multistep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tenso
         if trace is not None:
             trace.append(x.clone())
     return x.clamp(-1.0, 1.0)
+
+
+def dpm2_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int,
+                 s_tmin: float = 0.0, s_tmax: float = float("inf"), s_churn: float = 150.0, s_noise: float = 1.04,
+                 injected_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sampler_edm.py:470-493 (loop, num_steps-1 iterations, final clamp) and :428-468 (step, 'DPM2 Karras').
+    Kept as written in the reference: the churned point x_hat only feeds the first derivative, both updates start
+    from the UN-churned x (:449, :458, :464); a draw is consumed every step (:439)."""
+    x = sigmas[0] * noise
+    gam = torch.where((sigmas >= s_tmin) & (sigmas <= s_tmax), min(s_churn / num_steps, sqrt(2) - 1), 0.0)
+    for i in range(num_steps - 1):
+        s, s_next, g = sigmas[i], sigmas[i + 1], gam[i]
+        s_hat = s + g * s
+        eps = s_noise * (injected_noise[i] if injected_noise is not None else torch.randn_like(x))
+        x_hat = x + (s_hat ** 2 - s ** 2) ** 0.5 * eps if g > 0 else x
+        d = (x_hat - fn(x_hat, sigma=s_hat)) / s_hat
+        if s_next == 0.0:
+            x = x + d * (s_next - s_hat)
+        else:
+            s_mid = s_hat.log().lerp(s_next.log(), 0.5).exp()
+            x_2 = x + d * (s_mid - s_hat)
+            d_2 = (x_2 - fn(x_2, sigma=s_mid)) / s_mid
+            x = x + d_2 * (s_next - s_hat)
+    return x.clamp(-1.0, 1.0)
+
+
+def adpm2_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int, rho: float = 1.0,
+                  eta: float = 1.0, injected_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """stochastic_sampler_edm.py:85-100 (loop, final clamp), :53-83 (step, 'DPM2 a Karras'), :29-32 (get_sigmas)."""
+    x = sigmas[0] * noise
+    for i in range(num_steps - 1):
+        s, s_next = sigmas[i], sigmas[i + 1]
+        s_up = min(s_next, eta * (s_next ** 2 * (s ** 2 - s_next ** 2) / s ** 2) ** 0.5)
+        s_down = (s_next ** 2 - s_up ** 2) ** 0.5
+        d = (x - fn(x, sigma=s)) / s
+        s_mid = ((s ** (1 / rho) + s_down ** (1 / rho)) / 2) ** rho
+        x_mid = x + d * (s_mid - s)
+        d_mid = (x_mid - fn(x_mid, sigma=s_mid)) / s_mid
+        x = x + d_mid * (s_down - s)
+        x = x + (injected_noise[i] if injected_noise is not None else torch.randn_like(x)) * s_up
+    return x.clamp(-1.0, 1.0)

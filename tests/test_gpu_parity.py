@@ -286,3 +286,30 @@ def test_cfg_bf16_close_to_fp32():
     a = d.denoise_fn(x, net=net16, sigma=torch.tensor(2.0), inference=True, cond_scale=4.0, classes=cl)
     b = d.denoise_fn(x, net=net32, sigma=torch.tensor(2.0), inference=True, cond_scale=4.0, classes=cl)
     assert rel_err(a, b) < BF16_TOL
+
+
+# ---- DPM2 / ancestral DPM2 samplers ------------------------------------------------------
+@pytest.mark.parametrize("graph", [False, True])
+def test_dpm2_family_vs_reference_golden(golden, graph):
+    """DPM2Sampler (with and without churn) and ADPM2Sampler (two rho / eta settings) with the draws the reference
+    consumed, against the reference's own results."""
+    from test_oracle_golden import recorded_draws
+    net, _ = make_net(A.config_tiny(), "fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    noise = generate_noise(70, 2, 256).cuda()
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 10)()
+    shape = (2, 1, 256)
+    cases = [
+        (A.DPM2Sampler(num_steps=10, s_tmin=0.05, s_tmax=50.0, s_churn=30.0, s_noise=1.003, use_graph=graph), 9100, "smp_dpm2_churn10_final"),
+        (A.DPM2Sampler(num_steps=10, s_churn=0.0, s_noise=1.0, use_graph=graph), 9200, "smp_dpm2_ode10_final"),
+        (A.ADPM2Sampler(rho=1.0, num_steps=10, eta=1.0, use_graph=graph), 9300, "smp_adpm2_r1_final"),
+        (A.ADPM2Sampler(rho=7.0, num_steps=10, eta=0.6, use_graph=graph), 9300, "smp_adpm2_r7_final"),
+    ]
+    for smp, seed0, key in cases:
+        inj = recorded_draws(seed0, 9, shape).cuda()
+        for _ in range(2):
+            y = smp(noise, fn=d.denoise_fn, net=net, sigmas=sig, injected_noise=inj)
+            assert rel_err(y.cpu(), T(golden[key])) < FP32_TOL, key
+    # without injected noise the ancestral sampler draws its own and still returns clamped, finite audio
+    y = A.ADPM2Sampler(num_steps=6)(noise, fn=d.denoise_fn, net=net, sigmas=A.KarrasSchedule(0.002, 80.0, 7.0, 6)())
+    assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0

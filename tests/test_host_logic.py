@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AdfNetConfig) == 4 * (9 + 13 + 12 * 3 + 4 + 2 + 1)
-    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 11
+    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 13
 
 
 def test_sampler_nfe_via_abi():
@@ -58,6 +58,8 @@ def test_sampler_nfe_via_abi():
     assert nfe(A.DPMSampler(1.0, order=3, num_steps=50, multisteps=True, x0_pred=True, log_time_spacing=False)._desc(0.2), 50) == 49
     bad = A.DPMSampler(1.0, order=4, num_steps=50, multisteps=True, x0_pred=True, log_time_spacing=False)._desc(0.2)
     assert nfe(bad, 50) == -1
+    assert nfe(A.DPM2Sampler(num_steps=50, s_churn=0.0)._desc(0.2), 50) == 2 * 49      # no sigma_next == 0 inside the schedule
+    assert nfe(A.ADPM2Sampler(num_steps=50)._desc(0.2), 50) == 2 * 49
 
 
 # ---- plugin surface -------------------------------------------------------------------------------
@@ -175,3 +177,18 @@ def test_rank_noise_is_keyed_by_global_index():
     full = generate_noise(0, 8, 64)
     parts = torch.cat([rank_noise(8, 64, r, 4) for r in range(4)])
     assert torch.equal(full, parts)
+
+
+def test_dpm2_family_compat_branch_matches_oracle():
+    """The tensor-op branch of DPM2Sampler / ADPM2Sampler (foreign fn / net) against the oracle loops, mock denoiser."""
+    from oracle import samplers as S
+    from audiodiffuser_amd.weights import generate_noise
+    noise = generate_noise(3, 2, 128)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 9)()
+    inj = torch.stack([generate_noise(100 + i, 2, 128) for i in range(8)])
+    mock = lambda x, net=None, sigma=None, **k: 0.5 * x / (1 + sigma)
+    fn_o = lambda x, sigma=None: 0.5 * x / (1 + sigma)
+    y = A.DPM2Sampler(num_steps=9, s_tmin=0.05, s_tmax=50.0, s_churn=20.0, s_noise=1.01)(noise, fn=mock, net=None, sigmas=sig, injected_noise=inj)
+    assert torch.equal(y, S.dpm2_sampler(noise, fn_o, sig, 9, s_tmin=0.05, s_tmax=50.0, s_churn=20.0, s_noise=1.01, injected_noise=inj))
+    y = A.ADPM2Sampler(rho=7.0, num_steps=9, eta=0.8)(noise, fn=mock, net=None, sigmas=sig, injected_noise=inj)
+    assert torch.equal(y, S.adpm2_sampler(noise, fn_o, sig, 9, rho=7.0, eta=0.8, injected_noise=inj))

@@ -188,3 +188,29 @@ def test_cfg_denoise_and_sampler(golden):
     assert rel(y, T(golden["cc_heun8_final"])) < 5e-4
     with pytest.raises(ValueError):
         O.label_embedding(w, classes, 0.3)        # random label masks are a training-time feature
+
+
+# ---- DPM2 / ancestral DPM2 samplers -------------------------------------------------------
+def recorded_draws(seed0, count, shape):
+    """The randn_like draws gen_golden.py fed the reference (generator seed = seed0 + draw index)."""
+    out = []
+    for i in range(count):
+        g = torch.Generator(); g.manual_seed(seed0 + i)
+        out.append(torch.randn(shape, generator=g, dtype=torch.float32))
+    return torch.stack(out)
+
+
+def test_dpm2_family_with_tiny_net(golden):
+    cfg = config_tiny()
+    fn = E.make_denoiser(generate_weights(cfg, seed=0), cfg, 0.2)
+    noise = generate_noise(70, 2, 256)
+    sig = E.karras_sigmas(0.002, 80.0, 7.0, 10)
+    with torch.no_grad():
+        y = S.dpm2_sampler(noise, fn, sig, 10, s_tmin=0.05, s_tmax=50.0, s_churn=30.0, s_noise=1.003,
+                           injected_noise=recorded_draws(9100, 9, noise.shape))
+        assert rel(y, T(golden["smp_dpm2_churn10_final"])) < 5e-4
+        y = S.dpm2_sampler(noise, fn, sig, 10, s_churn=0.0, s_noise=1.0, injected_noise=recorded_draws(9200, 9, noise.shape))
+        assert rel(y, T(golden["smp_dpm2_ode10_final"])) < 5e-4
+        for rho, eta, tag in ((1.0, 1.0, "r1"), (7.0, 0.6, "r7")):
+            y = S.adpm2_sampler(noise, fn, sig, 10, rho=rho, eta=eta, injected_noise=recorded_draws(9300, 9, noise.shape))
+            assert rel(y, T(golden[f"smp_adpm2_{tag}_final"])) < 5e-4, tag
