@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+WORKLOADS = {"c1": "BASELINE configs[0] network", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2] network (attention from the 16x level)"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
@@ -203,7 +204,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "waveforms_per_s": waveforms / dt, "nfe_per_waveform": nfe, "finite_and_clamped": ok,
-        "config": {"workload": f"BASELINE configs[1]: UNet1d {cfg.channels} ch ({a.config}), {a.length}-sample waveforms, "
+        "config": {"workload": f"{WORKLOADS.get(a.config, a.config)}: UNet1d {cfg.channels} ch ({a.config}), {a.length}-sample waveforms, "
                                f"KarrasSchedule N={a.num_steps} {a.sampler}, batch {a.batch}/GPU, random-init weights",
                    "global_batch": global_batch, "sampler": a.sampler, "num_steps": a.num_steps, "nfe": nfe,
                    "hipgraph": not a.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
