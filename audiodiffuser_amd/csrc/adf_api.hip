@@ -316,7 +316,7 @@ struct Walker {
         return sg;
     }
     void run_gemm(GemmArgs& g, Act& out, bool want_stats) {
-        const bool ask = want_stats && can_fuse_stats(out.C) && !g.scatter_f;
+        const bool ask = want_stats && can_fuse_stats(out.C);      // also for the phase-scattered transposed convs
         if (ask) {
             out.stats = alloc_stats();
             g.stats = out.stats; g.stats_groups = h->cfg.resnet_groups;

@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
                     const int trow = k * RPK;                       // any row of the segment just finished
                     const int bb = a.flat ? (int)((R0 + trow) / a.mrows) : b0;
                     if (bb < a.B) {
-                        double* sp = a.stats + ((size_t)bb * a.stats_groups + n / gs) * 2;
+                        double* sp = a.stats + ((size_t)bb * a.stats_groups + (a.scatter_f ? n % a.out_c : n) / gs) * 2;   // scatter: n = phase * out_c + channel
                         atomicAdd(sp, (double)s1);
                         atomicAdd(sp + 1, (double)s2);
                     }
@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(512) conv_gemm_ws_kernel(const GemmArgs a, int
                     for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     for (int o = CPW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     if (lane < CPW && (cc & (tpg - 1)) == 0 && n < a.n) {
-                        double* sp = a.stats + ((size_t)b0 * a.stats_groups + n / gs) * 2;
+                        double* sp = a.stats + ((size_t)b0 * a.stats_groups + (a.scatter_f ? n % a.out_c : n) / gs) * 2;
                         atomicAdd(sp, (double)s1);
                         atomicAdd(sp + 1, (double)s2);
                     }
@@ -1407,7 +1407,7 @@ __global__ void __launch_bounds__(512) conv_gemm_wsd_kernel(const GemmArgs a, in
                     for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     for (int o = CPW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     if (lane < CPW && (cc & (tpg - 1)) == 0 && n < a.n) {
-                        double* sp = a.stats + ((size_t)b0 * a.stats_groups + n / gs) * 2;
+                        double* sp = a.stats + ((size_t)b0 * a.stats_groups + (a.scatter_f ? n % a.out_c : n) / gs) * 2;
                         atomicAdd(sp, (double)s1);
                         atomicAdd(sp + 1, (double)s2);
                     }

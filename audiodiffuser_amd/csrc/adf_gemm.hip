@@ -253,7 +253,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         const int nthr = (tm == 64 && tn == 32) || (tm == 32 && tn == 64) ? 128 : ((tm == 32 && tn == 32) ? 64 : 256);
         const int rpk = nthr * epc / tn;
         const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
-        const bool ok = !a.scatter_f && gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= tn &&
+        const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= tn &&
                         (!flat || a.mrows % rpk == 0);
         if (!ok) a.stats = nullptr;
         else if (stats_fused) *stats_fused = true;
@@ -339,7 +339,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                 if (a_in.stats) {
                     const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
                     const int wcols = wtn / 2;    // columns owned by one consumer wave
-                    const bool ok = !a.scatter_f && gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= wcols;
+                    const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= wcols;
                     a.stats = ok ? a_in.stats : nullptr;
                     if (stats_fused) *stats_fused = ok;
                 }
@@ -356,7 +356,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             if (wsd_ok) {
                 if (a_in.stats) {
                     const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
-                    const bool ok = !a.scatter_f && gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= 64;
+                    const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= 64;
                     a.stats = ok ? a_in.stats : nullptr;
                     if (stats_fused) *stats_fused = ok;
                 }
