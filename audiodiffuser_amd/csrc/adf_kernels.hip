@@ -232,41 +232,50 @@ const char* launch_gn_apply(const void* s0, const void* s1, int c0, int c1, int 
 // =====================================================================================================
 // Row LayerNorm (nn.LayerNorm in TransformerBlock1d unet1d.py:80,111; LayerNorm1d :31-43 in NLC)
 // =====================================================================================================
-template <typename T, int MAXCH>
+// LPR lanes share a row (so short rows do not idle half the wave): a wave normalises 64/LPR rows at once, a thread
+// holds CPL 16-byte chunks of its row in registers; two-pass variance on the registers (no E[x^2] - mean^2).
+template <typename T, int LPR, int CPL>
 __global__ void __launch_bounds__(256) ln_rows_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
     constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int RPW = 64 / LPR;                       // rows per wave
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int sub = lane % LPR;                         // lane inside its row group
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
+    const long long r = live ? row : rows - 1;          // out-of-range groups recompute the last row and do not store
     const int cpr = C / EPC;
-    float f[MAXCH][EPC];
+    float f[CPL][EPC];
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int cc = lane + k * 64;
+    for (int k = 0; k < CPL; ++k) {
+        const int cc = sub + k * LPR;
         if (cc < cpr) {
-            const u32x4_t v = *(const u32x4_t*)(x + row * C + (size_t)cc * EPC);
+            const u32x4_t v = *(const u32x4_t*)(x + r * C + (size_t)cc * EPC);
             unpack16<T>(v, f[k]);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) sum += f[k][e];
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)C;
     float sq = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int cc = lane + k * 64;
+    for (int k = 0; k < CPL; ++k) {
+        const int cc = sub + k * LPR;
         if (cc < cpr) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { const float d = f[k][e] - mean; sq = fmaf(d, d, sq); }
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int cc = lane + k * 64;
-        if (cc < cpr) {
+    for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int cc = sub + k * LPR;
+        if (cc < cpr && live) {
             float o[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
@@ -275,20 +284,37 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const T* __restrict__ x, T
                 if (beta) v += beta[c];
                 o[e] = v;
             }
-            *(u32x4_t*)(y + row * C + (size_t)cc * EPC) = pack16<T>(o);
+            *(u32x4_t*)(y + r * C + (size_t)cc * EPC) = pack16<T>(o);
         }
     }
+}
+
+template <typename T>
+static const char* ln_rows_dispatch(const T* x, T* y, long long rows, int C, const float* gamma, const float* beta, float eps, hipStream_t s) {
+    const int cpr = C / Elem<T>::kPerChunk;
+#define ADF_LN(LPR, CPL)                                                                                                          \
+    do {                                                                                                                          \
+        const unsigned grid = (unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)));                                         \
+        hipLaunchKernelGGL((ln_rows_kernel<T, LPR, CPL>), dim3(grid), dim3(256), 0, s, x, y, rows, C, gamma, beta, eps);       \
+        return ADF_LAUNCH_CHECK("ln_rows");                                                                                       \
+    } while (0)
+    if (cpr <= 8) ADF_LN(8, 1);
+    if (cpr <= 16) ADF_LN(16, 1);
+    if (cpr <= 32) ADF_LN(32, 1);
+    if (cpr <= 64) ADF_LN(64, 1);
+    if (cpr <= 128) ADF_LN(64, 2);
+    if (cpr <= 256) ADF_LN(64, 4);
+#undef ADF_LN
+    return "ln_rows: C too large";
 }
 
 const char* launch_ln_rows(const void* x, void* y, int bf16, long long rows, int C, const float* gamma,
                            const float* beta, float eps, hipStream_t s) {
     const int epc = bf16 ? 8 : 4;
     if (C % epc) return "ln_rows: C must be a multiple of a 16-byte chunk";
-    if (C / epc > 64 * 4) return "ln_rows: C too large";
-    const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (bf16) hipLaunchKernelGGL((ln_rows_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C, gamma, beta, eps);
-    else hipLaunchKernelGGL((ln_rows_kernel<float, 4>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, rows, C, gamma, beta, eps);
-    return ADF_LAUNCH_CHECK("ln_rows");
+    if (rows < 1) return "ln_rows: no rows";
+    if (bf16) return ln_rows_dispatch<bf16_t>((const bf16_t*)x, (bf16_t*)y, rows, C, gamma, beta, eps, s);
+    return ln_rows_dispatch<float>((const float*)x, (float*)y, rows, C, gamma, beta, eps, s);
 }
 
 // =====================================================================================================
