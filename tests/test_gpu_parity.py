@@ -213,20 +213,23 @@ def test_config2_batch8_every_layer_large_tile_routes(dtype, tol):
     assert not bad, bad
 
 
-def test_pipelined_dma_gemm_route_matches_default_route(tmp_path):
-    """The LDS-DMA pipelined GEMM kernel (adf_gemm_pp.h, opt-in with ADF_GEMM_PP) against the default routing on
-    the same bf16 network and inputs: the route is read once per process, so each side runs in a child process."""
+@pytest.mark.parametrize("batch,pp", [(8, "2"), (24, "1")])
+def test_pipelined_dma_gemm_route_matches_plain_routes(tmp_path, batch, pp):
+    """The persistent LDS-DMA GEMM kernel (adf_gemm_pp.h) against the other routes (ADF_GEMM_PP=0) on the same bf16
+    network and inputs.  batch 8 with ADF_GEMM_PP=2: every eligible layer incl. the identity-residual segment;
+    batch 24 with the default routing: 384 tiles over 256 persistent blocks (uneven tile ranges, several samples per
+    block).  The route is read once per process, so each side runs in a child process."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for pp in ("0", "2"):
-        path = str(tmp_path / f"pp{pp}.pt")
-        env = dict(os.environ, ADF_GEMM_PP=pp)
+    for mode in ("0", pp):
+        path = str(tmp_path / f"pp{mode}.pt")
+        env = dict(os.environ, ADF_GEMM_PP=mode, B=str(batch))
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs[pp] = torch.load(path)
-    a, b = outs["2"], outs["0"]
+        outs[mode] = torch.load(path)
+    a, b = outs[pp], outs["0"]
     assert all(bool(torch.isfinite(v).all()) for v in a.values())
     rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
     # first resblock after the switch: only the accumulation order differs; end of the net: bf16 rounding noise compounds
