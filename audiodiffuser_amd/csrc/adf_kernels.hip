@@ -234,6 +234,7 @@ const char* launch_gn_apply(const void* s0, const void* s1, int c0, int c1, int 
 // =====================================================================================================
 // LPR lanes share a row (so short rows do not idle half the wave): a wave normalises 64/LPR rows at once, a thread
 // holds CPL 16-byte chunks of its row in registers; two-pass variance on the registers (no E[x^2] - mean^2).
+// The grid is capped and every wave walks its rows with a stride: gamma / beta of the lane's channels are loaded once.
 template <typename T, int LPR, int CPL>
 __global__ void __launch_bounds__(256) ln_rows_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
@@ -241,50 +242,59 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const T* __restrict__ x, T
     constexpr int RPW = 64 / LPR;                       // rows per wave
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;                         // lane inside its row group
-    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
-    const bool live = row < rows;
-    const long long r = live ? row : rows - 1;          // out-of-range groups recompute the last row and do not store
     const int cpr = C / EPC;
-    float f[CPL][EPC];
-    float sum = 0.f;
+    float gm[CPL][EPC], bt[CPL][EPC];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int cc = sub + k * LPR;
-        if (cc < cpr) {
-            const u32x4_t v = *(const u32x4_t*)(x + r * C + (size_t)cc * EPC);
-            unpack16<T>(v, f[k]);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) sum += f[k][e];
+        for (int e = 0; e < EPC; ++e) {
+            gm[k][e] = cc < cpr ? gamma[cc * EPC + e] : 0.f;
+            bt[k][e] = (cc < cpr && beta) ? beta[cc * EPC + e] : 0.f;
         }
     }
+    const float inv_c = 1.0f / (float)C;
+    const long long stride = (long long)gridDim.x * 4 * RPW;
+    for (long long rb = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW; rb < rows; rb += stride) {   // wave-uniform trip count
+        const long long row = rb + lane / LPR;
+        const bool live = row < rows;
+        const long long r = live ? row : rows - 1;      // out-of-range groups recompute the last row and do not store
+        float f[CPL][EPC];
+        float sum = 0.f;
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const float mean = sum / (float)C;
-    float sq = 0.f;
+        for (int k = 0; k < CPL; ++k) {
+            const int cc = sub + k * LPR;
+            if (cc < cpr) {
+                const u32x4_t v = *(const u32x4_t*)(x + r * C + (size_t)cc * EPC);
+                unpack16<T>(v, f[k]);
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const int cc = sub + k * LPR;
-        if (cc < cpr) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) { const float d = f[k][e] - mean; sq = fmaf(d, d, sq); }
-        }
-    }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    const float rstd = rsqrtf(sq / (float)C + eps);
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const int cc = sub + k * LPR;
-        if (cc < cpr && live) {
-            float o[EPC];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const int c = cc * EPC + e;
-                float v = (f[k][e] - mean) * rstd * gamma[c];
-                if (beta) v += beta[c];
-                o[e] = v;
+                for (int e = 0; e < EPC; ++e) sum += f[k][e];
             }
-            *(u32x4_t*)(y + r * C + (size_t)cc * EPC) = pack16<T>(o);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int cc = sub + k * LPR;
+            if (cc < cpr) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { const float d = f[k][e] - mean; sq = fmaf(d, d, sq); }
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rstd = rsqrtf(sq * inv_c + eps);
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int cc = sub + k * LPR;
+            if (cc < cpr && live) {
+                float o[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o[e] = (f[k][e] - mean) * rstd * gm[k][e] + bt[k][e];
+                *(u32x4_t*)(y + r * C + (size_t)cc * EPC) = pack16<T>(o);
+            }
         }
     }
 }
@@ -294,8 +304,9 @@ static const char* ln_rows_dispatch(const T* x, T* y, long long rows, int C, con
     const int cpr = C / Elem<T>::kPerChunk;
 #define ADF_LN(LPR, CPL)                                                                                                          \
     do {                                                                                                                          \
-        const unsigned grid = (unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)));                                         \
-        hipLaunchKernelGGL((ln_rows_kernel<T, LPR, CPL>), dim3(grid), dim3(256), 0, s, x, y, rows, C, gamma, beta, eps);       \
+        long long grid = (rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR));                                                          \
+        if (grid > 4096) grid = 4096;                                                                                            \
+        hipLaunchKernelGGL((ln_rows_kernel<T, LPR, CPL>), dim3((unsigned)grid), dim3(256), 0, s, x, y, rows, C, gamma, beta, eps); \
         return ADF_LAUNCH_CHECK("ln_rows");                                                                                       \
     } while (0)
     if (cpr <= 8) ADF_LN(8, 1);
