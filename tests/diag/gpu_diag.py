@@ -1,7 +1,7 @@
 """GPU diagnostic (not a test): per-layer relative error of the HIP U-Net against the CPU oracle."""
 import json, os, sys, time, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import audiodiffuser_amd as A
 from gpu_helpers import tap_errors, golden_inputs

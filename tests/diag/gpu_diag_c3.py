@@ -1,6 +1,6 @@
 """GPU diagnostic: per-layer error of config 3 (64 ch, attention from the 16x level) at L=4096 in bf16 and fp32."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import audiodiffuser_amd as A

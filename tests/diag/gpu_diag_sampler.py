@@ -1,6 +1,6 @@
 """GPU diagnostic: denoise + sampler parity against the golden fixtures (reference outputs)."""
 import os, sys, time, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import audiodiffuser_amd as A

@@ -2,7 +2,7 @@
 forward pass (C2, B=8, L=16384); `cmp FILE1 FILE2` prints the relative difference per tap.
 Run `save` twice in separate processes with different ADF_GEMM_* environment variables."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 

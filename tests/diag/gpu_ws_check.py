@@ -1,6 +1,6 @@
 """Compare the warp-specialised GEMM path against the oracle at a size where it is selected (tiles >= 256)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import audiodiffuser_amd as A

@@ -225,7 +225,7 @@ def test_pipelined_dma_gemm_route_matches_plain_routes(tmp_path, batch, pp):
     for mode in ("0", pp):
         path = str(tmp_path / f"pp{mode}.pt")
         env = dict(os.environ, ADF_GEMM_PP=mode, B=str(batch))
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[mode] = torch.load(path)
