@@ -316,3 +316,22 @@ def test_dpm2_family_vs_reference_golden(golden, graph):
     # without injected noise the ancestral sampler draws its own and still returns clamped, finite audio
     y = A.ADPM2Sampler(num_steps=6)(noise, fn=d.denoise_fn, net=net, sigmas=A.KarrasSchedule(0.002, 80.0, 7.0, 6)())
     assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
+
+
+# ---- shape sweep: odd batches / other lengths through whatever routes the launcher picks ---------------------------
+@pytest.mark.parametrize("B,L", [(1, 16384), (3, 4096), (5, 2048), (96, 1024), (33, 3072)])
+def test_config2_shape_sweep_vs_oracle(B, L):
+    """BASELINE config 2 network at batch sizes / lengths that are not the bench's (odd tile counts per layer, lengths
+    that are not powers of two, a batch above 64): fp32 against the oracle at the tight bound, bf16 at its own bound."""
+    from oracle import unet1d as O
+    cfg = A.config_c2()
+    x = generate_noise(11, B, L) * 0.6
+    t = torch.linspace(-1.2, 0.6, B)
+    net32, w = make_net(cfg, "fp32")
+    with torch.no_grad():
+        yo = O.unet1d_forward(w, cfg, x, t)
+    y32 = net32(x.cuda(), t.cuda()).cpu()
+    assert rel_err(y32, yo) < FP32_TIGHT
+    net16, _ = make_net(cfg, "bf16")
+    y16 = net16(x.cuda(), t.cuda()).cpu()
+    assert torch.isfinite(y16).all() and rel_err(y16, yo) < BF16_TOL
