@@ -154,6 +154,22 @@ struct Registrar {
         reg_pack(pre + ".weight", w, cout, cin, K, 0, cout, false, 0);
         if (bias) w.bias = reg_f32(pre + ".bias", cout);
     }
+    // Strided Conv1d (kernel f*km + 1, stride f, pad f*(km/2)) folded to a stride-1 conv with km + 1 taps over
+    // f*cin channels: the contiguous [L][cin] input is the same memory as [L/f][f*cin], so the fast stride-1 GEMM
+    // kernels apply unchanged (the folded taps beyond the real kernel length are zero weights)
+    void conv_folded(const std::string& pre, ConvW& w, int cout, int cin, int K, int f) {
+        w.cin = f * cin; w.K = K; w.f = f;
+        w.taps = (K - 1) / f + 1;
+        w.n = cout; w.n_pad = round_up(cout, 32);
+        w.nchunk = ceil_div(f * cin, h->kc);
+        w.w = dalloc(h, ((size_t)w.nchunk * w.taps * w.n_pad + (size_t)kTapGroup * (w.n_pad + 128)) * kRowBytes);
+        if (!w.w) { ok = false; return; }
+        w.cout = cout;
+        Slot s; s.kind = 3; s.dst = w.w; s.numel = (int64_t)cout * cin * K;
+        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = 0; s.n_pad = w.n_pad; s.nchunk = w.nchunk;
+        h->names.push_back(pre + ".weight"); h->slots[pre + ".weight"] = s;
+        w.bias = reg_f32(pre + ".bias", cout);
+    }
     void resblock(const std::string& pre, ResW& r, int cin, int cout, int temb) {
         r.cin = cin; r.cout = cout;
         r.film_off = h->film_total;
@@ -215,7 +231,7 @@ int build_weights(adf_handle* h) {
         DownW& d = h->downs[i];
         d.cin = ch * c.multipliers[i]; d.cout = ch * c.multipliers[i + 1]; d.factor = c.factors[i];
         const std::string pre = "unet.downsamples." + std::to_string(i);
-        R.conv(pre + ".downsample", d.down, d.cout, d.cin, d.factor * c.kernel_multiplier_downsample + 1, true);
+        R.conv_folded(pre + ".downsample", d.down, d.cout, d.cin, d.factor * c.kernel_multiplier_downsample + 1, d.factor);
         d.blocks.resize(c.num_blocks[i]);
         for (int j = 0; j < c.num_blocks[i]; ++j) R.resblock(pre + ".blocks." + std::to_string(j), d.blocks[j], d.cout, d.cout, temb);
         d.attn = c.attentions[i] != 0;
@@ -455,8 +471,12 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         const DownW& d = h->downs[i];
         const int f = d.factor, km = c.kernel_multiplier_downsample;
         Act y = W.new_act(d.cout, x.L / f);
-        GemmArgs g = W.gemm_base(y, x.L, y.L, d.down);
-        g.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, f * km + 1, f, -f * (km / 2), 1, d.down);
+        // Downsample1d (unet1d.py:214-225) as a stride-1 conv over the row-folded view [L/f][f*C] (Registrar::conv_folded)
+        if (x.L % f) return fail(h, "downsample: length not divisible by the factor");
+        Act xv = x;
+        xv.C = x.C * f; xv.L = x.L / f; xv.stats = nullptr;
+        GemmArgs g = W.gemm_base(y, xv.L, y.L, d.down);
+        g.seg[0] = Walker::seg_of(xv, nullptr, nullptr, 1.f, 0, km + 1, 1, -(km / 2), 1, d.down);
         W.run_gemm(g, y, true);
         W.tap("down" + std::to_string(i) + ".conv", y);
         x = y;
@@ -880,7 +900,8 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
     if (sl.kind == 0) {
         if (hipMemcpyAsync(sl.dst, dev, (size_t)numel * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "hipMemcpyAsync failed");
     } else {
-        const char* e = launch_pack_weight(dev, sl.dst, h->bf16, sl.kind == 2 ? 1 : 0, sl.cout, sl.cin, sl.K, sl.f, sl.n_offset, sl.n_pad, sl.nchunk, s);
+        const char* e = launch_pack_weight(dev, sl.dst, h->bf16, sl.kind == 2 ? 1 : (sl.kind == 3 ? 2 : 0), sl.cout, sl.cin, sl.K, sl.f, sl.n_offset,
+                                           sl.n_pad, sl.nchunk, s);
         if (e) return fail(h, e);
     }
     sl.loaded = true;

@@ -1030,7 +1030,14 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
         const int chunk = (int)(r / taps);
         const int ci = chunk * KC + kc;
         float v = 0.f;
-        if (ci < cin) {
+        if (mode == 2) {
+            // strided conv folded to stride 1: the input [L][cin] is read as [L/f][f*cin], channel j*cin + c of folded
+            // row p is x[f*p + j][c], so folded tap t' carries the original taps t'*f + j (zero beyond K)
+            if (ci < f * cin) {
+                const int j = ci / cin, c = ci - j * cin, t = tap * f + j;
+                if (t < K) v = src[((size_t)nl * cin + c) * K + t];
+            }
+        } else if (ci < cin) {
             if (mode == 0) {
                 v = src[((size_t)nl * cin + ci) * K + tap];
             } else {
@@ -1045,10 +1052,11 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
 
 const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, int cout, int cin, int K, int f,
                                int n_offset, int n_pad, int nchunk, hipStream_t s) {
-    const int taps = mode == 0 ? K : 2;
+    const int taps = mode == 0 ? K : (mode == 2 ? (K - 1) / f + 1 : 2);
     if (mode == 1 && K != 2 * f) return "pack_weight: transposed conv needs K == 2*factor";
+    if (mode == 2 && (f < 1 || (K - 1) % f)) return "pack_weight: folded strided conv needs K == factor*k + 1";
     // only the real rows are written; the destination is zero-initialised at allocation (row / K padding)
-    const int n_rows = mode == 0 ? cout : f * cout;
+    const int n_rows = mode == 1 ? f * cout : cout;
     if (n_offset + n_rows > n_pad) return "pack_weight: rows exceed n_pad";
     const int kc = kRowBytesPack / (bf16 ? 2 : 4);
     const long long total = (long long)nchunk * taps * n_rows * kc;
