@@ -1425,16 +1425,18 @@ __global__ void __launch_bounds__(512) conv_gemm_wsd_kernel(const GemmArgs a, in
 //   the four partial accumulators are summed through LDS.  Cuts the serial K-loop length by 4.
 //   Restricted to stride-1 segments with <= 3 taps (3-tap convs and 1x1 ops); flat or per-sample tiles.
 // =====================================================================================================
-constexpr int kKsARows = 40;
-constexpr int kKsWaveLds = (kKsARows + kTapGroup * 32) * kLdsPitch;     // 19.6 KB per wave
+constexpr int ks_a_rows(int mt) { return 32 * mt + 8; }                 // tile rows + taps, rounded to the 8-row staging step
+constexpr int ks_wave_lds(int mt, int nt) { return (ks_a_rows(mt) + kTapGroup * 32 * nt) * kLdsPitch; }   // 19.6 KB (32x32) .. 38 KB (64x64)
 
-template <typename T>
+template <typename T, int MT, int NT>   // tile = (32 MT) x (32 NT); every wave accumulates the whole tile over its K quarter
 __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a) {
-    constexpr int TM = 32, TN = 32, NW = 64;             // NW = threads of one staging group (a wave)
+    constexpr int TM = 32 * MT, TN = 32 * NT, NW = 64;     // NW = threads of one staging group (a wave)
+    constexpr int kKsARows = ks_a_rows(MT);
+    constexpr int kKsWaveLds = ks_wave_lds(MT, NT);
     constexpr int EPC = Elem<T>::kPerChunk;
     constexpr int KC = kRowBytes / (int)sizeof(T);
-    constexpr int A_CH = (kKsARows * 8) / NW;              // 5
-    constexpr int W_CH = (kTapGroup * TN * 8) / NW;        // 12
+    constexpr int A_CH = (kKsARows * 8) / NW;              // 5 / 9
+    constexpr int W_CH = (kTapGroup * TN * 8) / NW;        // 12 / 24
     constexpr bool kBf16 = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1465,9 +1467,13 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
     const int nit = nit0 + (a.nseg > 1 ? a.seg[1].nchunk : 0);
     const int it_begin = (nit * wave) / 4, it_end = (nit * (wave + 1)) / 4;
 
-    f32x16_t acc;
+    f32x16_t acc[MT][NT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     u32x4_t ra[A_CH], rw[W_CH];
     f32x4_t abq[EPC / 2];
     float raw_scale = 1.0f;
@@ -1575,33 +1581,56 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
         const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
         const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
         const int segrows = (seg - 1) * sg.stride + sg.taps;
-        const int j = a.flat ? r / seg : 0;
-        const int abase = j * segrows + (r - j * seg) * sg.stride;
+        int abase[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int ti = i * 32 + r;
+            const int j = a.flat ? ti / seg : 0;
+            abase[i] = j * segrows + (ti - j * seg) * sg.stride;
+        }
         for (int tap = 0; tap < sg.taps; ++tap) {
-            const int arow = abase + sg.off0 + tap * sg.step - off_min;
-            const int wrow = tap * TN + r;
+            const int aoff = sg.off0 + tap * sg.step - off_min;
             if constexpr (kBf16) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t fa_ = *(const bf16x8_t*)(ldsA + lds_swz(arow, ks * 2 + h));
-                    const bf16x8_t fb_ = *(const bf16x8_t*)(ldsW + lds_swz(wrow, ks * 2 + h));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_, fb_, acc, 0, 0, 0);
+                    bf16x8_t fa_[MT], fb_[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa_[i] = *(const bf16x8_t*)(ldsA + lds_swz(abase[i] + aoff, ks * 2 + h));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb_[j] = *(const bf16x8_t*)(ldsW + lds_swz(tap * TN + j * 32 + r, ks * 2 + h));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const float4 a0 = *(const float4*)(ldsA + lds_swz(arow, ks * 4 + 2 * h));
-                    const float4 a1 = *(const float4*)(ldsA + lds_swz(arow, ks * 4 + 2 * h + 1));
-                    const float4 w0 = *(const float4*)(ldsW + lds_swz(wrow, ks * 4 + 2 * h));
-                    const float4 w1 = *(const float4*)(ldsW + lds_swz(wrow, ks * 4 + 2 * h + 1));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w0.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w0.w, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w1.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w1.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w1.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w1.w, acc, 0, 0, 0);
+                    float4 a0[MT], a1[MT], w0[NT], w1[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        a0[i] = *(const float4*)(ldsA + lds_swz(abase[i] + aoff, ks * 4 + 2 * h));
+                        a1[i] = *(const float4*)(ldsA + lds_swz(abase[i] + aoff, ks * 4 + 2 * h + 1));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        w0[j] = *(const float4*)(ldsW + lds_swz(tap * TN + j * 32 + r, ks * 4 + 2 * h));
+                        w1[j] = *(const float4*)(ldsW + lds_swz(tap * TN + j * 32 + r, ks * 4 + 2 * h + 1));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].x, w0[j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].y, w0[j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].z, w0[j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].w, w0[j].w, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].x, w1[j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].y, w1[j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].z, w1[j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].w, w1[j].w, acc[i][j], 0, 0, 0);
+                        }
                 }
             }
         }
@@ -1626,83 +1655,93 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
 
     // ---- cross-wave reduction + epilogue ------------------------------------------------------------------
     __syncthreads();
-    float* part = (float*)smem;                            // [4][32][32] fp32 partial tiles (16 KB)
+    float* part = (float*)smem;                            // [4][TM][TN] fp32 partial tiles (16 KB .. 64 KB, over the staging area)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        part[(wave * 32 + row) * 32 + r] = acc[e];
-    }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                part[(wave * TM + row) * TN + j * 32 + r] = acc[i][j][e];
+            }
     __syncthreads();
-    constexpr int CPR = TN / EPC;                          // chunks per row: 4 (bf16) / 8 (fp32)
-    constexpr int NCH = TM * CPR;                          // 128 / 256 chunks in the tile
+    constexpr int CPR = TN / EPC;                          // chunks per tile row
+    constexpr int NCH = TM * CPR;                          // 16-byte chunks in the tile
+    constexpr int NPASS = (NCH + 255) / 256;               // 1 (up to 256 chunks) .. 4 (64x64 fp32)
     T* out = (T*)a.out;
     const T* res = (const T*)a.res;
-    const bool active = tid < NCH;
-    const int row = tid / CPR, cc = tid - (tid / CPR) * CPR;
-    const int n = n0 + cc * EPC;
-    int bb, m;
-    bool ok;
     const long long rows_total = (long long)a.B * a.mrows;
-    if (a.flat) {
-        const long long R = R0 + row;
-        ok = R < rows_total;
-        bb = (int)(R / a.mrows);
-        m = (int)(R - (long long)bb * a.mrows);
-    } else {
-        bb = b0; m = m0 + row;
-        ok = m < a.mrows;
-    }
-    ok = ok && active && n < a.n;
-    float s1 = 0.f, s2 = 0.f;
-    if (active) {
-        float v[EPC];
+    const bool want_stats = a.stats != nullptr;
+    const int gs = want_stats ? a.out_c / a.stats_groups : EPC;
+    const int tpg = gs / EPC;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int e = 0; e < EPC; e += 4) {
-                const float4 q = *(const float4*)(part + (w * 32 + row) * 32 + cc * EPC + e);
-                v[e] += q.x; v[e + 1] += q.y; v[e + 2] += q.z; v[e + 3] += q.w;
-            }
-        if (ok) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const int bi = (n + e) % a.bias_mod;
-                float bsum = 0.f;
-                if (a.bias0) bsum += a.bias0[bi];
-                if (a.bias1) bsum += a.bias1[bi];
-                v[e] += bsum;
-            }
-            const unsigned off = (unsigned)((bb * a.out_rows + m) * a.out_c + n);
-            if (res) {
-                float rr[EPC];
-                unpack16<T>(*(const u32x4_t*)(res + off), rr);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
-            }
-            if (a.gelu) {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
-            }
-            *(u32x4_t*)(out + off) = pack16<T>(v);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int idx = tid + ps * 256;
+        const bool active = idx < NCH;
+        const int row = idx / CPR, cc = idx - (idx / CPR) * CPR;
+        const int n = n0 + cc * EPC;
+        int bb, m;
+        bool ok;
+        if (a.flat) {
+            const long long R = R0 + row;
+            ok = R < rows_total;
+            bb = (int)(R / a.mrows);
+            m = (int)(R - (long long)bb * a.mrows);
+        } else {
+            bb = b0; m = m0 + row;
+            ok = m < a.mrows;
         }
-    }
-    if (a.stats != nullptr && tid < NCH) {      // wave-uniform: NCH is a multiple of 64
-        // a wave covers 64 / CPR consecutive rows, all inside one sample (seg is a multiple of that)
-        const int gs = a.out_c / a.stats_groups;
-        const int tpg = gs / EPC;
-        for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        for (int o = CPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (lane < CPR && (cc & (tpg - 1)) == 0 && n < a.n) {
-            const int frow = (tid >> 6) * (64 / CPR);       // first tile row of this wave
-            const int sb = a.flat ? (int)((R0 + frow) / a.mrows) : b0;
-            if (sb < a.B) {
-                double* sp = a.stats + ((size_t)sb * a.stats_groups + n / gs) * 2;
-                atomicAdd(sp, (double)s1);
-                atomicAdd(sp + 1, (double)s2);
+        ok = ok && active && n < a.n;
+        float s1 = 0.f, s2 = 0.f;
+        if (active) {
+            float v[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4) {
+                    const float4 q = *(const float4*)(part + (w * TM + row) * TN + cc * EPC + e);
+                    v[e] += q.x; v[e + 1] += q.y; v[e + 2] += q.z; v[e + 3] += q.w;
+                }
+            if (ok) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int bi = (n + e) % a.bias_mod;
+                    float bsum = 0.f;
+                    if (a.bias0) bsum += a.bias0[bi];
+                    if (a.bias1) bsum += a.bias1[bi];
+                    v[e] += bsum;
+                }
+                const unsigned off = (unsigned)((bb * a.out_rows + m) * a.out_c + n);
+                if (res) {
+                    float rr[EPC];
+                    unpack16<T>(*(const u32x4_t*)(res + off), rr);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+                }
+                if (a.gelu) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
+                }
+                *(u32x4_t*)(out + off) = pack16<T>(v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+            }
+        }
+        if (want_stats && (tid & ~63) + ps * 256 < NCH) {      // wave-uniform: NCH is a multiple of 64
+            // a wave covers 64 / CPR consecutive rows, all inside one sample (seg is a multiple of that)
+            for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            for (int o = CPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (lane < CPR && (cc & (tpg - 1)) == 0 && n < a.n) {
+                const int frow = ((tid >> 6) * 64 + ps * 256) / CPR;     // first tile row of this wave in this pass
+                const int sb = a.flat ? (int)((R0 + frow) / a.mrows) : b0;
+                if (sb < a.B) {
+                    double* sp = a.stats + ((size_t)sb * a.stats_groups + n / gs) * 2;
+                    atomicAdd(sp, (double)s1);
+                    atomicAdd(sp + 1, (double)s2);
+                }
             }
         }
     }

@@ -147,18 +147,19 @@ const void* pp_identity(int n, hipStream_t stream, const char** err) {
     return d;
 }
 
-template <typename T>
+template <typename T, int MT, int NT>
 const char* launch_ksplit(const GemmArgs& a, hipStream_t stream) {
-    constexpr int lds = 4 * kKsWaveLds;
+    constexpr int lds = 4 * ks_wave_lds(MT, NT);
+    constexpr int TM = 32 * MT, TN = 32 * NT;
     static bool attr_set = false;
-    auto kern = conv_gemm_ksplit_kernel<T>;
+    auto kern = conv_gemm_ksplit_kernel<T, MT, NT>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, ksplit) failed";
         attr_set = true;
     }
-    const int tiles_n = (a.n_pad + 31) / 32;
-    const long long tiles_m = a.flat ? ((long long)a.B * a.mrows + 31) / 32 : (long long)((a.mrows + 31) / 32) * a.B;
+    const int tiles_n = (a.n_pad + TN - 1) / TN;
+    const long long tiles_m = a.flat ? ((long long)a.B * a.mrows + TM - 1) / TM : (long long)((a.mrows + TM - 1) / TM) * a.B;
     const long long blocks = tiles_m * tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return "conv_gemm_ksplit: bad grid";
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -270,22 +271,28 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         for (int s = 0; s < a.nseg; ++s) {
             const GemmSeg& g = a.seg[s];
             if (g.stride != 1 || g.taps > kTapGroup) ks_ok = false;
-            if ((32 / ks_seg) * ((ks_seg - 1) + g.taps) > kKsARows) ks_ok = false;
+            if ((32 / ks_seg) * ((ks_seg - 1) + g.taps) > ks_a_rows(1)) ks_ok = false;
             nit_total += g.nchunk;
         }
         if (ks_ok && nit_total >= 4) {
+            // 64 x 64 tiles when they still give >= 128 blocks: every tile row re-reads all weights and every tile column
+            // all activations (from L2), so the bytes a CU pulls halve against 32 x 32 (ADF_GEMM_KSPLIT=32 forces the small tile)
+            const bool big = use_ks != 32 && !ks_flat && a.mrows % 64 == 0 && a.n_pad % 64 == 0 &&
+                             (long long)a.B * (a.mrows / 64) * (a.n_pad / 64) >= 128;
+            const int tile = big ? 64 : 32;
             a.flat = ks_flat;
-            a.seg_rows = ks_seg;
+            a.seg_rows = big ? 64 : ks_seg;
             if (a_in.stats) {
                 const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
-                const int rows_per_wave = 64 / (32 / epc);
-                const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= 32 &&
-                                (ks_seg % rows_per_wave == 0);
+                const int rows_per_wave = 64 / (tile / epc);
+                const bool ok = gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= epc && gs <= tile &&
+                                (a.seg_rows % rows_per_wave == 0);
                 a.stats = ok ? a_in.stats : nullptr;
                 if (stats_fused) *stats_fused = ok;
             }
-            trace_route("ksplit", a, 32, 32);
-            return dtype_bf16 ? launch_ksplit<bf16_t>(a, stream) : launch_ksplit<float>(a, stream);
+            trace_route("ksplit", a, tile, tile);
+            if (big) return dtype_bf16 ? launch_ksplit<bf16_t, 2, 2>(a, stream) : launch_ksplit<float, 2, 2>(a, stream);
+            return dtype_bf16 ? launch_ksplit<bf16_t, 1, 1>(a, stream) : launch_ksplit<float, 1, 1>(a, stream);
         }
     }
     {

@@ -335,3 +335,13 @@ def test_config2_shape_sweep_vs_oracle(B, L):
     net16, _ = make_net(cfg, "bf16")
     y16 = net16(x.cuda(), t.cuda()).cpu()
     assert torch.isfinite(y16).all() and rel_err(y16, yo) < BF16_TOL
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
+def test_config2_batch32_every_layer_splitk_64_tiles(dtype, tol):
+    """Batch 32 at full length: the 64-row level has 2048 rows, the size from which the split-K kernel switches to
+    64 x 64 tiles (>= 128 blocks).  Every recorded layer against the oracle."""
+    x = generate_noise(200, 32, 16384) * 0.7
+    errs, y, yo = tap_errors(A.config_c2(), x, torch.linspace(-1.0, 0.5, 32), dtype, 0)
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, bad
