@@ -85,11 +85,12 @@ const char* launch_wsd(const GemmArgs& a, hipStream_t stream) {
 }
 
 
-// Software-pipelined persistent 256 x 128 kernel (adf_gemm_pp.h): one 512-thread block per CU.
+// Persistent LDS-DMA kernel (adf_gemm_pp.h): one 512-thread block per CU, block tile (128 MT) x 128.
+template <int MT>
 const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     static int num_cu = 0;
-    auto kern = conv_gemm_pp_kernel;
+    auto kern = conv_gemm_pp_kernel<MT>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess)
             return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, pp) failed";
@@ -98,7 +99,8 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
             num_cu = 256;
         attr_set = true;
     }
-    const int tiles_m = a.mrows / kPpTM, tiles_n = a.n_pad / kPpTN;
+    constexpr int TM = 128 * MT;
+    const int tiles_m = a.mrows / TM, tiles_n = a.n_pad / kPpTN;
     int tm_shift = 0, tn_shift = 0;
     while ((1 << tm_shift) < tiles_m) ++tm_shift;
     while ((1 << tn_shift) < tiles_n) ++tn_shift;
@@ -111,11 +113,11 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
 
 // shapes the pipelined kernel is written for (see the header of adf_gemm_pp.h); an identity residual counts as a
 // second segment
-bool pp_eligible(const GemmArgs& a) {
+bool pp_eligible(const GemmArgs& a, int tm) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (a.scatter_f || a.gelu || a.mrows % kPpTM || a.lin != a.mrows || a.out_rows != a.mrows) return false;
+    if (a.scatter_f || a.gelu || a.mrows % tm || a.lin != a.mrows || a.out_rows != a.mrows) return false;
     if (a.n != a.n_pad || a.out_c != a.n || a.n_pad % kPpTN || a.n_pad > kPpMaxN) return false;
-    if (!pow2(a.mrows / kPpTM) || !pow2(a.n_pad / kPpTN)) return false;
+    if (!pow2(a.mrows / tm) || !pow2(a.n_pad / kPpTN)) return false;
     if (a.res && a.nseg > 1) return false;
     int nb = a.res ? a.n / 64 : 0;
     for (int s = 0; s < a.nseg; ++s) {
@@ -302,9 +304,17 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         // ADF_GEMM_PP=0 disables it, =2 also takes identity-residual layers and >= 128 tiles (used by the tests).
         static int use_pp = -1;
         if (use_pp < 0) { const char* e = getenv("ADF_GEMM_PP"); use_pp = e ? atoi(e) : 1; }
-        if (use_pp && dtype_bf16 && !flat && tm == 128 && pp_eligible(a)) {
-            const long long tiles = (long long)a.B * (a.mrows / kPpTM) * (a.n_pad / kPpTN);
-            const bool take = use_pp >= 2 ? tiles >= 128 : (tiles >= 256 && !a.res);
+        // tile height: 256 rows when that gives every CU a tile, else 128 rows (the L = 256 level at batch 64)
+        int ptm = 0;
+        if (use_pp && dtype_bf16 && !flat && tm == 128) {
+            const long long t256 = pp_eligible(a, 256) ? (long long)a.B * (a.mrows / 256) * (a.n_pad / kPpTN) : 0;
+            const long long t128 = pp_eligible(a, 128) ? (long long)a.B * (a.mrows / 128) * (a.n_pad / kPpTN) : 0;
+            const long long need = use_pp >= 2 ? 128 : 256;
+            if (t256 >= need) ptm = 256;
+            else if (t128 >= need && use_pp != 3) ptm = 128;       // ADF_GEMM_PP=3: 256-row tiles only (A/B)
+        }
+        if (ptm) {
+            const bool take = use_pp == 2 || !a.res;
             if (take) {
                 if (a_in.stats) {
                     const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
@@ -323,8 +333,8 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                     a.nseg = 2;
                     a.res = nullptr;
                 }
-                trace_route("pp", a, 256, 128);
-                return launch_pp(a, stream);
+                trace_route("pp", a, ptm, 128);
+                return ptm == 256 ? launch_pp<2>(a, stream) : launch_pp<1>(a, stream);
             }
         }
     }

@@ -35,7 +35,7 @@
 
 namespace adf {
 
-constexpr int kPpTM = 256, kPpTN = 128;
+constexpr int kPpTM = 256, kPpTN = 128;                    // kPpTM: the larger of the two tile heights (MT = 2); MT = 1 gives 128
 constexpr int kPpRow = 128;                                 // bytes of K per staged row (64 bf16)
 constexpr int kPpAStage = 33 * 1024;                        // 32 pieces of 8 rows + the halo piece (rows 256, 257)
 constexpr int kPpAStages = 3;
@@ -86,8 +86,14 @@ struct PpBlk {
     int tseq, last;       // tile sequence number; last = the block is the last K block of its tile
 };
 
+// MT = 32-row accumulator tiles per wave: block tile (128 MT) x 128.  MT = 1 serves the levels whose 256-row tile count
+// would leave CUs idle (L = 256 at batch 64): half the MFMAs per sub-step, but still far less per-step latency than
+// the plain kernel.
+template <int MT>
 __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int tiles_total, int tm_shift, int tn_shift) {
     typedef bf16_t T;
+    constexpr int TM = 128 * MT;                    // rows of the block tile
+    constexpr int HP = TM / 8;                      // index of the halo piece (rows TM, TM + 1) inside an A stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsScr = smem + kPpOffScr;
     char* const ldsTab = smem + kPpOffTab;
@@ -122,15 +128,18 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         const int tml = t >> tn_shift;
         n0 = (t & ((1 << tn_shift) - 1)) * kPpTN;
         b0 = tml >> tm_shift;
-        m0 = (tml & ((1 << tm_shift) - 1)) * kPpTM;
+        m0 = (tml & ((1 << tm_shift) - 1)) * TM;
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // wait until at most n of this wave's DMA instructions (the youngest ones) are still in flight
     auto wait_dma = [&](int n) __attribute__((always_inline)) {
         if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // issue_a never returns more than 6
     };
     auto desc = [&](int tseq, int blk) __attribute__((always_inline)) -> PpBlk {
         const bool s1 = blk >= nb0;
@@ -184,15 +193,15 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         const char* g0 = d.asrc + ((long long)d.rowbase + p0) * (long long)d.rowbytes + colbytes;
         const unsigned step = 64u * d.rowbytes;
         int n = 0;
-        if (part < 0) { pp_dma16x4(p0 < 0 ? g0 + d.rowbytes : g0, g0 + step, step, ldsA); n = 4; }
-        if (part == 0) { pp_dma16(p0 < 0 ? g0 + d.rowbytes : g0, ldsA); pp_dma16(g0 + step, ldsA + 8192u); n = 2; }
-        if (part == 1) { pp_dma16(g0 + 2 * step, ldsA + 16384u); pp_dma16(g0 + 3 * step, ldsA + 24576u); n = 2; }
+        if (part < 0 && MT == 2) { pp_dma16x4(p0 < 0 ? g0 + d.rowbytes : g0, g0 + step, step, ldsA); n = 4; }
+        if (part == 0 || (part < 0 && MT == 1)) { pp_dma16(p0 < 0 ? g0 + d.rowbytes : g0, ldsA); pp_dma16(g0 + step, ldsA + 8192u); n = 2; }
+        if (part == 1 && MT == 2) { pp_dma16(g0 + 2 * step, ldsA + 16384u); pp_dma16(g0 + 3 * step, ldsA + 24576u); n = 2; }
         if (part < 0 || part == 2) {
             if (wave == 0 && d.taps == 3) {
-                const int p = d.p_lo + kPpTM + lrow;
+                const int p = d.p_lo + TM + lrow;
                 const bool ok = p >= 0 && p < a.lin;
                 const unsigned off = ok ? (d.rowbase + (unsigned)p) * d.rowbytes + colbytes : 0u;
-                if (lane < 16) pp_dma16(d.asrc + off, (unsigned)(st * kPpAStage) + 32u * 1024u);
+                if (lane < 16) pp_dma16(d.asrc + off, (unsigned)(st * kPpAStage) + (unsigned)HP * 1024u);
                 n += 1;
             }
             if (use_tab && d.last && d.tseq + 1 < ntiles && (unsigned)wave * 1024u < (unsigned)ctot0 * 8u) {
@@ -219,11 +228,11 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     // outside the sample.  Raw blocks only need the zero fill (sample-edge tiles of a 3-tap block).
     auto transform = [&](const PpBlk& d, int st) __attribute__((always_inline)) {
         char* const ldsA = smem + st * kPpAStage + wave * 1024 + lane_lds;
-        char* const ldsH = smem + st * kPpAStage + 32 * 1024 + lane_lds;
+        char* const ldsH = smem + st * kPpAStage + HP * 1024 + lane_lds;
         const bool halo = wave == 0 && d.taps == 3;
         const int p0 = d.p_lo + srow;
-        const int ph = d.p_lo + kPpTM + lrow;
-        const bool edge = d.taps == 3 && (d.p_lo < 0 || d.p_lo + kPpTM + 2 > a.lin);    // uniform: a halo row is padding
+        const int ph = d.p_lo + TM + lrow;
+        const bool edge = d.taps == 3 && (d.p_lo < 0 || d.p_lo + TM + 2 > a.lin);    // uniform: a halo row is padding
         if (d.tabofs >= 0 || d.act || d.scale != 1.0f) {                   // uniform
             f32x2_t fa2[4], fb2[4];
             if (d.tabofs >= 0) {
@@ -267,16 +276,17 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 for (int e = 0; e < 4; ++e) { f[2 * e] = v2[e].x; f[2 * e + 1] = v2[e].y; }
                 return pack16<T>(f);
             };
-            u32x4_t raw[4];
+            constexpr int NU = 2 * MT;                                      // this wave's pieces of the block
+            u32x4_t raw[NU];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) raw[i] = *(const u32x4_t*)(ldsA + i * 8192);
+            for (int i = 0; i < NU; ++i) raw[i] = *(const u32x4_t*)(ldsA + i * 8192);
             if (d.act) {                                                    // uniform: two straight-line versions
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::true_type{});
+                for (int i = 0; i < NU; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::true_type{});
                 if (halo && lane < 16) *(u32x4_t*)ldsH = math(*(const u32x4_t*)ldsH, std::true_type{});
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::false_type{});
+                for (int i = 0; i < NU; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::false_type{});
                 if (halo && lane < 16) *(u32x4_t*)ldsH = math(*(const u32x4_t*)ldsH, std::false_type{});
             }
         }
@@ -288,7 +298,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     };
 
     // ---- accumulators and fragment addresses -------------------------------------------------------------------
-    f32x16_t acc[2][2];
+    f32x16_t acc[MT][2];
     {
         int b0, m0, n0;
         geom(0, b0, m0, n0);
@@ -296,7 +306,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
         for (int j = 0; j < 2; ++j) bias_r[j] = ldsBias[n0 + wn * 64 + j * 32 + r];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -307,7 +317,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     unsigned abase[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int row = wm * 64 + r + t, f = (row >> 1) & 7;
+        const int row = wm * 32 * MT + r + t, f = (row >> 1) & 7;
         abase[t] = (unsigned)(row * kPpRow + ((h ^ (f & 1)) << 4) + ((f >> 1) << 5));
     }
     const int fw = (r >> 1) & 7;
@@ -319,24 +329,22 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         const unsigned ab = abase[TAP];
         const char* pa = smem + stA * kPpAStage;
         const char* pw = smem + kPpOffW + stW * kPpWStage;
-        bf16x8_t fa[2][2], fb[2][2];
+        bf16x8_t fa[2][MT], fb[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            fa[0][i] = *(const bf16x8_t*)(pa + ab + i * 32 * kPpRow);
-            fb[0][i] = *(const bf16x8_t*)(pw + wbase + i * 32 * kPpRow);
-        }
+        for (int i = 0; i < MT; ++i) fa[0][i] = *(const bf16x8_t*)(pa + ab + i * 32 * kPpRow);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8_t*)(pw + wbase + j * 32 * kPpRow);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < 4) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    fa[nxt][i] = *(const bf16x8_t*)(pa + (ab ^ (unsigned)((ks + 1) << 5)) + i * 32 * kPpRow);
-                    fb[nxt][i] = *(const bf16x8_t*)(pw + (wbase ^ (unsigned)((ks + 1) << 5)) + i * 32 * kPpRow);
-                }
+                for (int i = 0; i < MT; ++i) fa[nxt][i] = *(const bf16x8_t*)(pa + (ab ^ (unsigned)((ks + 1) << 5)) + i * 32 * kPpRow);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[nxt][j] = *(const bf16x8_t*)(pw + (wbase ^ (unsigned)((ks + 1) << 5)) + j * 32 * kPpRow);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
@@ -359,13 +367,13 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         const int gs = stats_here ? a.out_c / a.stats_groups : 8;
         const int tpg = gs / 8;
         const int n = n0 + wn * 64 + cc * 8;
-        const int mw0 = m0 + wm * 64;
+        const int mw0 = m0 + wm * 32 * MT;
         f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
         float nb_[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) nb_[j] = ldsBias[next_n0 + wn * 64 + j * 32 + r];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int p4 = 0; p4 < 4; ++p4) {
 #pragma unroll
