@@ -164,23 +164,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         return d;
     };
 
-    // ---- block prologue (ordinary loads; the DMA pipeline starts after it) ---------------------------------
-    for (int n = tid; n < a.n_pad; n += 512) {
-        float bv = 0.f;
-        if (n < a.n) {
-            const int bi = n % a.bias_mod;
-            if (a.bias0) bv += a.bias0[bi];
-            if (a.bias1) bv += a.bias1[bi];
-        }
-        ldsBias[n] = bv;
-    }
-    if (use_tab) {
-        int b0, m0, n0;
-        geom(0, b0, m0, n0);
-        if (tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b0 * ctot0 + tid * 2) * 2);
-    }
-    __syncthreads();
-
     // ---- DMA of the activations of K block d into ring stage st: 4 pieces per wave (+ the halo piece in wave 0
     // of a 3-tap block).  With the last block of a tile goes the affine table of the NEXT tile (two blocks before
     // its first use is prepared).  Returns the number of DMA instructions this wave issued (0 / 4 / 5 / 6).
@@ -299,19 +282,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 
     // ---- accumulators and fragment addresses -------------------------------------------------------------------
     f32x16_t acc[MT][2];
-    {
-        int b0, m0, n0;
-        geom(0, b0, m0, n0);
-        float bias_r[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bias_r[j] = ldsBias[n0 + wn * 64 + j * 32 + r];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_r[j];
-    }
     // fragment chunk (ks*2 + h) of staged row R sits at byte R*128 + (((ks*2 + h) ^ f) << 4), f = (R >> 1) & 7
     //   = (R*128 + ((h ^ (f & 1)) << 4) + ((f >> 1) << 5)) ^ (ks << 5): one base per tap, XOR selects the 16-channel sub-step
     unsigned abase[3];
@@ -434,7 +404,37 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     (void)issue_a(dc, 0, -1);
     if (GB > 1) (void)issue_a(d1, 1, -1);
     issue_w(dc.w, 0);
+    // ---- bias vector and the first tile's affine table -> LDS with ordinary loads, issued while the first DMAs fly
+    // (their latency and the DMA latency overlap; the compiler's waits for these loads also cover the older DMAs)
+    for (int n = tid; n < a.n_pad; n += 512) {
+        float bv = 0.f;
+        if (n < a.n) {
+            const int bi = n % a.bias_mod;
+            if (a.bias0) bv += a.bias0[bi];
+            if (a.bias1) bv += a.bias1[bi];
+        }
+        ldsBias[n] = bv;
+    }
+    if (use_tab) {
+        int b0, m0, n0;
+        geom(0, b0, m0, n0);
+        if (tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b0 * ctot0 + tid * 2) * 2);
+    }
     wait_dma(0);
+    __syncthreads();
+    {
+        int b0, m0, n0;
+        geom(0, b0, m0, n0);
+        float bias_r[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias_r[j] = ldsBias[n0 + wn * 64 + j * 32 + r];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_r[j];
+    }
     transform(dc, 0);
     lds_barrier();
 
