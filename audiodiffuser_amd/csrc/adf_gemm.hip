@@ -124,7 +124,7 @@ bool pp_eligible(const GemmArgs& a, int tm) {
         const GemmSeg& g = a.seg[s];
         if (g.stride != 1 || g.step != 1) return false;
         if (!((g.taps == 3 && g.off0 == -1) || (g.taps == 1 && g.off0 == 0))) return false;
-        if (g.c0 % 64 || g.c1 % 64 || g.c0 + g.c1 > kPpMaxCin) return false;
+        if (g.c0 % 64 || g.c1 % 64 || (g.ab && g.c0 + g.c1 > kPpMaxCin)) return false;   // the LDS affine table holds kPpMaxCin channels
         if (s == 1 && (g.ab || g.act)) return false;
         nb += (g.c0 + g.c1) / 64;
     }
