@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -365,7 +366,9 @@ struct Walker {
         if (ctot != r.cin) check("resblock: channel mismatch");
         double* s0 = ensure_stats(x);
         double* s1 = skip ? ensure_stats(*skip) : nullptr;
-        const bool short_level = x.L <= 64 && (x.L & (x.L - 1)) == 0;
+        static int short_max = -1;       // ADF_SHORT_LEVEL: longest level that materialises silu(GN(x)) for flat GEMM tiles
+        if (short_max < 0) { const char* e = getenv("ADF_SHORT_LEVEL"); short_max = e ? atoi(e) : 32; }
+        const bool short_level = x.L <= short_max && (x.L & (x.L - 1)) == 0;
         float* ab1 = (float*)alloc((size_t)B * ctot * 2 * 4);
         GnFinalizeArgs f1;
         memset(&f1, 0, sizeof(f1));
