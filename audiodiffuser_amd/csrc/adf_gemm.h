@@ -952,473 +952,6 @@ __global__ void __launch_bounds__(512) conv_gemm_ws_kernel(const GemmArgs a, int
 }
 
 // =====================================================================================================
-// Weight-STREAMING warp-specialised persistent variant for large layers whose weights do not fit in LDS.
-//   Same roles, activation path, step structure and wave-local epilogue as conv_gemm_ws_kernel; the weights of
-//   each K iteration are brought in by the producer waves with LDS-DMA (global_load_lds_dwordx4: no VGPR
-//   transit, hand-counted vmcnt) into a 2-slot ring of 3 tap slabs (16 KB each, 128-byte rows).  The DMA image
-//   is linear, so the bank-conflict-free layout is obtained by swizzling the per-lane SOURCE address
-//   (chunk ^ ((row>>1)&7)) and applying the same XOR on the consumers' ds_read_b128 addresses.
-//   step g: producers [DMA W(g) -> slot g&1] [wait A(g)] [prologue + store A(g)] [issue A(g+2)] [wait DMA] barrier;
-//           consumers compute K iteration g-1 from stage / slot (g-1)&1.
-//   Supports stride-1 segments with 3 taps (conv) or 1 tap (the 1x1 residual segment); TN = 128.
-// =====================================================================================================
-template <typename T>
-__global__ void __launch_bounds__(512) conv_gemm_wsd_kernel(const GemmArgs a, int tiles_m_total, int blocks_per_n) {
-    constexpr int NT = 2, WN = 2;
-    constexpr int WM = 4 / WN;
-    constexpr int MT = 4 / WM;                              // TM = 128 = WM * MT * 32
-    constexpr int TM = 128, TN = NT * WN * 32, NTHR = 256;  // NTHR = threads of ONE role
-    constexpr int EPC = Elem<T>::kPerChunk;
-    constexpr int KC = kRowBytes / (int)sizeof(T);
-    constexpr int A_CH = (kWsARows * 8 + NTHR - 1) / NTHR;
-    constexpr bool kBf16 = sizeof(T) == 2;
-    constexpr int ASTAGE = kWsARows * kLdsPitch;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NTHR;   // scalar role branch
-    const int tid = threadIdx.x & (NTHR - 1), lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (a.n_pad + TN - 1) / TN;
-    const int tiles_m = (a.mrows + TM - 1) / TM;
-    const int nit0 = a.seg[0].nchunk;                       // one K iteration = one chunk with ALL its taps
-    const int nit = nit0 + (a.nseg > 1 ? a.seg[1].nchunk : 0);
-    const int tn_i = (int)blockIdx.x % tiles_n;
-    const int slot = (int)blockIdx.x / tiles_n;
-    const int n0 = tn_i * TN;
-    const int my_tiles = slot < tiles_m_total ? (tiles_m_total - 1 - slot) / blocks_per_n + 1 : 0;
-    const int G = my_tiles * nit;
-    // LDS carve-up: [weight ring: 2 slots x 3 tap slabs x 16 KB][A stage 0][A stage 1][scratch]
-    constexpr int SLAB = TN * kRowBytes;                    // one tap of one K chunk, 128-byte rows, XOR-swizzled
-    char* ldsRing = smem;
-    char* ldsA0 = smem + 6 * SLAB;
-    char* scratch = ldsA0 + 2 * ASTAGE;
-    auto tile_geom = [&](int tseq, int& b0, int& m0) {
-        const int t = slot + tseq * blocks_per_n;
-        b0 = t / tiles_m;
-        m0 = (t - b0 * tiles_m) * TM;
-    };
-
-    // both roles execute the same, even number of steps: 2 * ceil((G + 1) / 2)
-    const int npairs = (G + 2) / 2;
-
-    if (producer) {
-        // ================================ producers ==================================================
-        const int c16 = tid & 7;
-        const int lds_row0 = tid >> 3;
-        struct Regs { u32x4_t ra[A_CH]; f32x4_t abq[EPC / 2]; float raw_scale; unsigned avalid; };
-        Regs R0s, R1s;
-        int arow_idx[A_CH];
-        int abq_b0 = 0;
-        auto load_a = [&](int q, Regs& R) {
-            const int tseq = q / nit, it = q - tseq * nit;
-            const bool s1 = it >= nit0;
-            const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
-            const int chunk = s1 ? it - nit0 : it;
-            if (chunk == 0) {
-                int b0, m0;
-                tile_geom(tseq, b0, m0);
-                const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
-                const int nrows = (TM - 1) * sg.stride + sg.taps;
-                const int p_lo = m0 * sg.stride + off_min;
-#pragma unroll
-                for (int i = 0; i < A_CH; ++i) {
-                    const int row = (tid + i * NTHR) >> 3;
-                    const int p = p_lo + row;
-                    const bool ok = row < nrows && p >= 0 && p < a.lin;
-                    arow_idx[i] = ok ? b0 * a.lin + p : -1;
-                }
-                abq_b0 = b0;
-            }
-            const int ctot = sg.c0 + sg.c1;
-            const int cidx = chunk * KC + c16 * EPC;
-            const bool cvalid = cidx < ctot;
-            const bool from1 = sg.c1 > 0 && cidx >= sg.c0;
-            const char* src0u = uniform_ptr(sg.src0);
-            const char* src1u = uniform_ptr(sg.src1);
-            const char* src = from1 ? src1u : src0u;
-            const int c0u = __builtin_amdgcn_readfirstlane(sg.c0), c1u = __builtin_amdgcn_readfirstlane(sg.c1);
-            const unsigned rowbytes = (unsigned)(from1 ? c1u : c0u) * (unsigned)sizeof(T);
-            const unsigned colbytes = (unsigned)(from1 ? cidx - c0u : cidx) * (unsigned)sizeof(T);
-            R.avalid = 0;
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
-                const bool ok = cvalid && arow_idx[i] >= 0;
-                const unsigned off = (ok ? (unsigned)arow_idx[i] : 0u) * rowbytes + (ok ? colbytes : 0u);
-                const char* ptr = src + off;
-                ADF_GLOAD16(R.ra[i], ptr);
-                R.avalid |= (ok ? 1u : 0u) << i;
-            }
-            const float* abp = sg.ab ? sg.ab + (cvalid ? (unsigned)(abq_b0 * ctot + cidx) * 2u : 0u) : (const float*)sg.w;
-#pragma unroll
-            for (int e = 0; e < EPC / 2; ++e) { const float* pe = abp + e * 4; ADF_GLOAD16(R.abq[e], pe); }
-            R.raw_scale = from1 ? sg.scale1 : 1.0f;
-        };
-        // weights of K iteration q -> ring slot: every producer wave DMAs a quarter (32 rows) of each tap slab.
-        // Lane l of an instruction lands at LDS byte l*16 of an 8-row block, i.e. (row, physical chunk l&7); it
-        // fetches logical chunk (l&7) ^ ((row>>1)&7), so the linear LDS image is the swizzled layout the
-        // consumers read conflict-free.
-        const unsigned ring0 = (unsigned)(size_t)ldsRing;
-        auto dma_w = [&](int q, int slot) {
-            const int it = q % nit;
-            const bool s1 = it >= nit0;
-            const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
-            const int chunk = s1 ? it - nit0 : it;
-            const int taps = __builtin_amdgcn_readfirstlane(sg.taps);
-            const char* wp = uniform_ptr(sg.w) + (size_t)(chunk * taps) * a.n_pad * kRowBytes;
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                if (tap < taps) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int rowblk = wave * 32 + kk * 8;
-                        const int row = rowblk + (lane >> 3);
-                        const int logical = (lane & 7) ^ ((row >> 1) & 7);
-                        const int nn = (n0 + row) < a.n_pad ? (n0 + row) : a.n_pad - 1;
-                        const char* g = wp + ((size_t)tap * a.n_pad + nn) * kRowBytes + logical * 16;
-                        const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)(((slot * 3 + tap) * TN + rowblk) * kRowBytes));
-                        unsigned keep;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-                    }
-                }
-            }
-        };
-        // hand-counted waits (this wave's VMEM ops complete in issue order).  Before consuming register set R:
-        // still allowed in flight = the other set's loads + the weight DMAs just issued for this step.
-        auto wait_set = [&](Regs& R, int taps) {
-            static_assert(A_CH == 5, "wait_set is written for 5 activation chunks per producer thread");
-            if constexpr (EPC == 8) {
-                if (taps == 3)
-                    asm volatile("s_waitcnt vmcnt(21)" : "+v"(R.ra[0]), "+v"(R.ra[1]), "+v"(R.ra[2]), "+v"(R.ra[3]), "+v"(R.ra[4]),
-                                 "+v"(R.abq[0]), "+v"(R.abq[1]), "+v"(R.abq[2]), "+v"(R.abq[3]) : : "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(13)" : "+v"(R.ra[0]), "+v"(R.ra[1]), "+v"(R.ra[2]), "+v"(R.ra[3]), "+v"(R.ra[4]),
-                                 "+v"(R.abq[0]), "+v"(R.abq[1]), "+v"(R.abq[2]), "+v"(R.abq[3]) : : "memory");
-            } else {
-                if (taps == 3)
-                    asm volatile("s_waitcnt vmcnt(19)" : "+v"(R.ra[0]), "+v"(R.ra[1]), "+v"(R.ra[2]), "+v"(R.ra[3]), "+v"(R.ra[4]),
-                                 "+v"(R.abq[0]), "+v"(R.abq[1]) : : "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(11)" : "+v"(R.ra[0]), "+v"(R.ra[1]), "+v"(R.ra[2]), "+v"(R.ra[3]), "+v"(R.ra[4]),
-                                 "+v"(R.abq[0]), "+v"(R.abq[1]) : : "memory");
-            }
-        };
-        // before the step's barrier: everything except the activation loads just issued must have landed
-        auto wait_dma = [&]() {
-            if constexpr (EPC == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        };
-        auto taps_of = [&](int q) {
-            const int it = q % nit;
-            return __builtin_amdgcn_readfirstlane(it >= nit0 ? a.seg[1].taps : a.seg[0].taps);
-        };
-        auto store_a = [&](int q, Regs& R, char* ldsA) {
-            const int it = q % nit;
-            const bool s1 = it >= nit0;
-            const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
-            const int nrows = (TM - 1) * sg.stride + sg.taps;
-            const bool act = sg.act != 0;
-            const bool use_ab = sg.ab != nullptr;
-            f32x2_t fa2[EPC / 2], fb2[EPC / 2], za2[EPC / 2], zb2[EPC / 2];
-#pragma unroll
-            for (int e = 0; e < EPC / 2; ++e) {
-                fa2[e] = use_ab ? f32x2_t{R.abq[e].x, R.abq[e].z} : f32x2_t{R.raw_scale, R.raw_scale};
-                fb2[e] = use_ab ? f32x2_t{R.abq[e].y, R.abq[e].w} : f32x2_t{0.f, 0.f};
-                za2[e] = fa2[e] * -1.4426950408889634f;
-                zb2[e] = fb2[e] * -1.4426950408889634f;
-            }
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
-                const int row = lds_row0 + i * (NTHR / 8);
-                if (row < nrows) {
-                    u32x4_t qv = u32x4_t{0u, 0u, 0u, 0u};
-                    if ((R.avalid >> i) & 1u) {
-                        float f[EPC];
-                        unpack16<T>(R.ra[i], f);
-                        if (act) {
-#pragma unroll
-                            for (int e = 0; e < EPC / 2; ++e) {
-                                const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
-                                const f32x2_t v2 = x2 * fa2[e] + fb2[e];
-                                const f32x2_t z2 = x2 * za2[e] + zb2[e];
-                                f32x2_t d2 = {__builtin_amdgcn_exp2f(z2.x), __builtin_amdgcn_exp2f(z2.y)};
-                                d2 = d2 + 1.0f;
-                                const f32x2_t r2 = {__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
-                                const f32x2_t y2 = v2 * r2;
-                                f[2 * e] = y2.x; f[2 * e + 1] = y2.y;
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < EPC / 2; ++e) {
-                                const f32x2_t x2 = {f[2 * e], f[2 * e + 1]};
-                                const f32x2_t v2 = x2 * fa2[e] + fb2[e];
-                                f[2 * e] = v2.x; f[2 * e + 1] = v2.y;
-                            }
-                        }
-                        qv = pack16<T>(f);
-                    }
-                    *(u32x4_t*)(ldsA + lds_swz(row, c16)) = qv;
-                }
-            }
-        };
-        // Straight-line even/odd step pairs with unconditional loads (iteration index clamped to G-1): the
-        // compiler then knows exactly which loads are outstanding and keeps two K steps in flight (a runtime
-        // even/odd branch or conditional loads make it drain vmcnt(0) every step).
-        if (G > 0) {
-            const int qmax = G - 1;
-            load_a(0, R0s);
-            load_a(qmax < 1 ? qmax : 1, R1s);
-            for (int pr = 0; pr < npairs; ++pr) {
-                const int g = 2 * pr;
-                const int qe = g < qmax ? g : qmax, qo = g + 1 < qmax ? g + 1 : qmax;
-                dma_w(qe, 0);
-                wait_set(R0s, taps_of(qe));
-                store_a(qe, R0s, ldsA0);                             // a step >= G writes a stage nobody reads again
-                load_a(g + 2 < qmax ? g + 2 : qmax, R0s);
-                wait_dma();
-                __syncthreads();
-                dma_w(qo, 1);
-                wait_set(R1s, taps_of(qo));
-                store_a(qo, R1s, ldsA0 + ASTAGE);
-                load_a(g + 3 < qmax ? g + 3 : qmax, R1s);
-                wait_dma();
-                __syncthreads();
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours may be in flight when the wave ends
-        } else {
-            for (int pr = 0; pr < npairs; ++pr) { __syncthreads(); __syncthreads(); }
-        }
-        return;
-    }
-
-    // ==================================== consumers ====================================================
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    float bias_r[NT];        // bias of this lane's output column(s): the block's N tile never changes
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int nb = n0 + (wn * NT + j) * 32 + r;
-        bias_r[j] = 0.f;
-        if (nb < a.n) {
-            const int bi = nb % a.bias_mod;
-            if (a.bias0) bias_r[j] += a.bias0[bi];
-            if (a.bias1) bias_r[j] += a.bias1[bi];
-        }
-    }
-    f32x16_t acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_r[j];
-
-    for (int g = 0; g < 2 * npairs; ++g) {
-        if (g >= 1 && g <= G) {
-            const int q = g - 1;
-            const int tseq = q / nit, it = q - tseq * nit;
-            const char* ldsA = ldsA0 + ((q & 1) ? ASTAGE : 0);
-            // geometry of the wave-local epilogue (see below) -- needed here to prefetch the identity residual
-            constexpr int WCOLS = NT * 32;                       // columns owned by the wave
-            constexpr int CPW = WCOLS / EPC;                     // 16-byte chunks per row
-            constexpr int RPP = 64 / CPW;                        // rows handled by the 64 lanes at once
-            constexpr int NSUB = RPP >= 8 ? 1 : 8 / RPP;         // sub-steps per 8-row pass
-            constexpr int NRES = MT * 4 * NSUB;
-            u32x4_t rres[NRES];
-            const int cc = lane % CPW, rsub = lane / CPW;        // this lane's chunk column / row inside a sub-step
-            const int ncol0 = n0 + wn * WCOLS;
-            if (it == nit - 1 && a.res != nullptr) {             // wave-uniform
-                int b0, m0;
-                tile_geom(tseq, b0, m0);
-                const T* res = (const T*)a.res;
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int p4 = 0; p4 < 4; ++p4)
-#pragma unroll
-                        for (int sb = 0; sb < NSUB; ++sb) {
-                            const int prow = sb * RPP + rsub;
-                            const int m = m0 + (wm * MT + i) * 32 + 8 * p4 + prow;
-                            const int n = ncol0 + cc * EPC;
-                            const bool ok = prow < 8 && m < a.mrows && n < a.n;
-                            const unsigned off = ok ? (unsigned)((b0 * a.out_rows + m) * a.out_c + n) : 0u;
-                            rres[(i * 4 + p4) * NSUB + sb] = *(const u32x4_t*)(res + off);
-                        }
-            }
-            {
-                const bool s1 = it >= nit0;
-                const GemmSeg& sg = s1 ? a.seg[1] : a.seg[0];
-                const int chunk = s1 ? it - nit0 : it;
-                const char* ldsW = ldsRing + (size_t)((q & 1) * 3) * SLAB;   // slot of this K iteration
-                (void)chunk;
-                const int off_min = sg.step > 0 ? sg.off0 : sg.off0 - (sg.taps - 1);
-                int abase[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) abase[i] = ((wm * MT + i) * 32 + r) * sg.stride;
-                bool pipelined = false;
-                if constexpr (kBf16) {
-                    const int aoff0 = sg.off0 - off_min, astep = sg.step;
-                    auto addrA = [&](int tap, int i, int c16) { return ldsA + lds_swz(abase[i] + aoff0 + tap * astep, c16); };
-                    auto addrW = [&](int tap, int j, int c16) {
-                        const int wr = (wn * NT + j) * 32 + r;
-                        return ldsW + (size_t)tap * SLAB + wr * kRowBytes + ((c16 ^ ((wr >> 1) & 7)) << 4);
-                    };
-                    if (sg.taps == 3) { mfma_chunk_bf16<3, MT, NT>(acc, h, addrA, addrW); pipelined = true; }
-                    else if (sg.taps == 1) { mfma_chunk_bf16<1, MT, NT>(acc, h, addrA, addrW); pipelined = true; }
-                }
-                for (int tap = 0; tap < (pipelined ? 0 : sg.taps); ++tap) {
-                    const int aoff = sg.off0 + tap * sg.step - off_min;
-                    int arow[MT], wrow[NT];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) arow[i] = abase[i] + aoff;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) wrow[j] = (wn * NT + j) * 32 + r;      // row inside the tap slab
-                    const char* ldsWt = ldsW + (size_t)tap * SLAB;
-                    if constexpr (kBf16) {
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {
-                            bf16x8_t fa_[MT], fb_[NT];
-#pragma unroll
-                            for (int i = 0; i < MT; ++i) fa_[i] = *(const bf16x8_t*)(ldsA + lds_swz(arow[i], ks * 2 + h));
-#pragma unroll
-                            for (int j = 0; j < NT; ++j) fb_[j] = *(const bf16x8_t*)(ldsWt + wrow[j] * kRowBytes + (((ks * 2 + h) ^ ((wrow[j] >> 1) & 7)) << 4));
-#pragma unroll
-                            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                                for (int j = 0; j < NT; ++j)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            float4 fa_[MT][2], fb_[NT][2];
-#pragma unroll
-                            for (int i = 0; i < MT; ++i) {
-                                fa_[i][0] = *(const float4*)(ldsA + lds_swz(arow[i], ks * 4 + 2 * h));
-                                fa_[i][1] = *(const float4*)(ldsA + lds_swz(arow[i], ks * 4 + 2 * h + 1));
-                            }
-#pragma unroll
-                            for (int j = 0; j < NT; ++j) {
-                                fb_[j][0] = *(const float4*)(ldsWt + wrow[j] * kRowBytes + (((ks * 4 + 2 * h) ^ ((wrow[j] >> 1) & 7)) << 4));
-                                fb_[j][1] = *(const float4*)(ldsWt + wrow[j] * kRowBytes + (((ks * 4 + 2 * h + 1) ^ ((wrow[j] >> 1) & 7)) << 4));
-                            }
-#pragma unroll
-                            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                                for (int j = 0; j < NT; ++j) {
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].x, fb_[j][0].x, acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].y, fb_[j][0].y, acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].z, fb_[j][0].z, acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][0].w, fb_[j][0].w, acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].x, fb_[j][1].x, acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].y, fb_[j][1].y, acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].z, fb_[j][1].z, acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][1].w, fb_[j][1].w, acc[i][j], 0, 0, 0);
-                                }
-                        }
-                    }
-                }
-            }
-            if (it == nit - 1) {
-                // ---------------- wave-local epilogue of this tile (no workgroup barrier) ----------------
-                // The wave owns rows [wm*MT*32, +MT*32) x cols [wn*NT*32, +NT*32) of the tile.  Pass (i, p4):
-                // accumulator registers 4*p4..4*p4+3 of both lane halves are rows 8*p4 .. 8*p4+7 of m-tile i;
-                // they go through the wave's private scratch and leave as 16-byte channel chunks.  The bias is
-                // already in the accumulators (they are re-initialised with it), offsets advance incrementally.
-                int b0, m0;
-                tile_geom(tseq, b0, m0);
-                float* sc = (float*)(scratch + wave * 2048);         // [8][WCOLS<=64] fp32
-                float* scw = sc + (4 * h) * WCOLS + r;               // this lane's write base
-                const float* scr = sc + (rsub < 8 ? rsub : 7) * WCOLS + cc * EPC;   // and read base (sub-step 0)
-                T* out = (T*)a.out;
-                const bool has_res = a.res != nullptr;
-                const bool stats_here = a.stats != nullptr;
-                const int gs = stats_here ? a.out_c / a.stats_groups : EPC;
-                const int tpg = gs / EPC;
-                const int n = ncol0 + cc * EPC;
-                const int mw0 = m0 + wm * MT * 32;                   // first row owned by the wave
-                const bool full = !a.scatter_f && (mw0 + MT * 32 <= a.mrows) && (ncol0 + WCOLS <= a.n) && (RPP <= 8 || rsub < 8);
-                f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                    for (int p4 = 0; p4 < 4; ++p4) {
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-#pragma unroll
-                            for (int e4 = 0; e4 < 4; ++e4) {
-                                const int e = 4 * p4 + e4;
-                                scw[e4 * WCOLS + j * 32] = acc[i][j][e];
-                                acc[i][j][e] = bias_r[j];
-                            }
-                        // same-wave LDS traffic is processed in order; only the compiler must not reorder it
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int sb = 0; sb < NSUB; ++sb) {
-                            const int prow = sb * RPP + rsub;        // row inside the 8-row pass
-                            const int m = mw0 + i * 32 + 8 * p4 + prow;
-                            bool ok = true;
-                            unsigned off;
-                            if (full) {
-                                off = (unsigned)((b0 * a.out_rows + m) * a.out_c + n);
-                            } else {
-                                ok = prow < 8 && m < a.mrows && n < a.n;
-                                if (a.scatter_f) {
-                                    const int phase = n / a.out_c, co = n - phase * a.out_c;
-                                    const int orow = m * a.scatter_f + phase - a.scatter_pad;
-                                    ok = ok && orow >= 0 && orow < a.out_rows;
-                                    off = (unsigned)((b0 * a.out_rows + orow) * a.out_c + co);
-                                } else {
-                                    off = (unsigned)((b0 * a.out_rows + m) * a.out_c + n);
-                                }
-                            }
-                            float v[EPC];
-#pragma unroll
-                            for (int e = 0; e < EPC; e += 4) {
-                                const float4 qv = *(const float4*)(scr + sb * RPP * WCOLS + e);
-                                v[e] = qv.x; v[e + 1] = qv.y; v[e + 2] = qv.z; v[e + 3] = qv.w;
-                            }
-                            if (has_res) {
-                                float rr[EPC];
-                                unpack16<T>(rres[(i * 4 + p4) * NSUB + sb], rr);
-#pragma unroll
-                                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
-                            }
-                            if (a.gelu) {
-#pragma unroll
-                                for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
-                            }
-                            if (ok) {
-                                *(u32x4_t*)(out + off) = pack16<T>(v);
-#pragma unroll
-                                for (int e = 0; e < EPC; e += 2) {
-                                    const f32x2_t v2 = {v[e], v[e + 1]};
-                                    s1v += v2;
-                                    s2v += v2 * v2;
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-                if (stats_here) {
-                    float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
-                    for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                    for (int o = CPW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                    if (lane < CPW && (cc & (tpg - 1)) == 0 && n < a.n) {
-                        double* sp = a.stats + ((size_t)b0 * a.stats_groups + (a.scatter_f ? n % a.out_c : n) / gs) * 2;
-                        atomicAdd(sp, (double)s1);
-                        atomicAdd(sp + 1, (double)s2);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// =====================================================================================================
 // Intra-block split-K variant for the short levels (L <= 64: few rows, long K, latency-bound).
 //   One block = one 32 x 32 output tile; its 4 waves each walk a quarter of the K iterations with a PRIVATE
 //   staging region and only wave-level synchronisation (a wave's LDS traffic is processed in order), then

@@ -206,7 +206,7 @@ def test_config3_attention_at_1024_tokens_vs_oracle():
 @pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
 def test_config2_batch8_every_layer_large_tile_routes(dtype, tol):
     """BASELINE config 2 at batch 8, full length: >= 256 row tiles per layer, the size from which the launcher picks
-    the persistent weight-stationary / weight-streaming GEMM kernels.  Every recorded layer against the oracle."""
+    the persistent weight-stationary / LDS-DMA GEMM kernels.  Every recorded layer against the oracle."""
     x = generate_noise(0, 8, 16384) * 0.7
     errs, y, yo = tap_errors(A.config_c2(), x, torch.linspace(-1.0, 0.5, 8), dtype, 0)
     bad = {k: v for k, v in errs.items() if not v < tol}
