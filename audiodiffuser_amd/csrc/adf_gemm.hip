@@ -241,7 +241,9 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         static int use_ks = -1;
         if (use_ks < 0) { const char* e = getenv("ADF_GEMM_KSPLIT"); use_ks = e ? atoi(e) : 1; }
         int nit_total = 0;
-        bool ks_ok = use_ks && !a.scatter_f && (long long)a.B * a.mrows <= 4096;
+        static long long ks_rows = -1;      // ADF_GEMM_KSPLIT_ROWS: largest B * rows the split-K kernel takes
+        if (ks_rows < 0) { const char* e = getenv("ADF_GEMM_KSPLIT_ROWS"); ks_rows = e ? atoll(e) : 4096; }
+        bool ks_ok = use_ks && !a.scatter_f && (long long)a.B * a.mrows <= ks_rows;
         const int ks_flat = (can_flat && a.mrows < 32 && 32 % a.mrows == 0) ? 1 : 0;
         const int ks_seg = ks_flat ? a.mrows : 32;
         if (!ks_flat && !raw && a.mrows < 32) ks_ok = false;     // per-sample tiles of a tiny sample: leave to the plain kernel
