@@ -12,7 +12,9 @@ from typing import Optional
 from .config import UNet1dConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libadf_hip.so")
+# ADF_HIP_LIB: experiment switch only -- another build of the SAME HIP library (tools/build_variant.sh), so that two
+# builds can be timed inside one gpurun call; there is no non-HIP implementation to point it at.
+LIB_PATH = os.environ.get("ADF_HIP_LIB") or os.path.join(HERE, "libadf_hip.so")
 ADF_MAX_LAYERS = 12
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_SEPARATE_GN_STATS = 1

@@ -15,6 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadf_hip.so")
 SOURCES = ["adf_gemm.hip", "adf_kernels.hip", "adf_api.hip"]
+# adf_gemm.hip: the SLP vectoriser would pair the prologue arithmetic that adf_gemm_pp.h places one element per MFMA gap
+# into v_pk_* operations (which are slower beside MFMAs and land in one gap instead of two)
+EXTRA_FLAGS = {"adf_gemm.hip": ["-fno-slp-vectorize"]}
 HEADERS = ["adf_common.h", "adf_gemm.h", "adf_gemm_pp.h", "adf_kernels.h", os.path.join("..", "..", "include", "audiodiffuser_amd.h")]
 ARCH = "gfx950"
 
@@ -48,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + flags + ["-c", s, "-o", o]
+        cmd = [hipcc] + flags + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")

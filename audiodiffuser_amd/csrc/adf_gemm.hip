@@ -5,6 +5,14 @@
 #include <cstdlib>
 #include <vector>
 
+#ifdef ADF_PP_STAMP
+namespace adf { __device__ unsigned long long adf_pp_stamps[8 * 32]; }
+// diagnostic build only: copies the stamps of the last DMA-kernel launch to the host
+extern "C" int adf_debug_pp_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adf::adf_pp_stamps), sizeof(unsigned long long) * 8 * 32);
+}
+#endif
+
 namespace adf {
 
 namespace {

@@ -35,6 +35,12 @@
 
 namespace adf {
 
+#ifdef ADF_PP_STAMP
+// diagnostic build only (tools/build_variant.sh stamp -DADF_PP_STAMP; tools/pp_stamps.py): s_memtime of every wave of
+// thread block 0 at the phase boundaries of one steady-state K block; the product build contains none of this
+extern __device__ unsigned long long adf_pp_stamps[8 * 32];
+#endif
+
 constexpr int kPpTM = 256, kPpTN = 128;                    // kPpTM: the larger of the two tile heights (MT = 2); MT = 1 gives 128
 constexpr int kPpRow = 128;                                 // bytes of K per staged row (64 bf16)
 constexpr int kPpAStage = 33 * 1024;                        // 32 pieces of 8 rows + the halo piece (rows 256, 257)
@@ -52,24 +58,19 @@ constexpr int kPpLds = kPpOffBias + kPpBias;                // 160,768 B
 constexpr int kPpMaxCin = kPpTab / 8;
 constexpr int kPpMaxN = kPpBias / 4;
 
-// One LDS-DMA piece: the active lanes copy 16 B each from `gsrc` to LDS byte address lds_dst + 16 * lane.
+// One LDS-DMA piece: the active lanes copy 16 B each from `base + voff` (uniform 64-bit base in SGPRs, 32-bit lane
+// offset: no per-lane 64-bit address arithmetic) to LDS byte address lds_dst + 16 * lane.
 // (Dynamic LDS starts at byte 0: the kernel has no static __shared__.)
-__device__ __forceinline__ void pp_dma16(const char* gsrc, unsigned lds_dst) {
+__device__ __forceinline__ void pp_dma16(const char* base, unsigned voff, unsigned lds_dst) {
     unsigned keep;
+#ifdef ADF_PP_VADDR
+    const char* g = base + voff;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-// Four pieces with one M0 set-up: piece 0 copies from g0, piece i > 0 from g1 + (i-1) * gstep; piece i lands at lds_dst + i * 8 KB.
-__device__ __forceinline__ void pp_dma16x4(const char* g0, const char* g1, unsigned gstep, unsigned lds_dst) {
-    unsigned keep;
-    const char* g2 = g1 + gstep;
-    const char* g3 = g2 + gstep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_dst) : "memory", "scc");
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+#else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(voff), "s"(lds_dst) : "memory");
+#endif
 }
 
 // wave-uniform description of one K block (64 channels of one segment) of one tile
@@ -103,6 +104,15 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
+#ifdef ADF_PP_DBG
+    // timing knock-outs of a diagnostic build (tools/build_variant.sh dbg -DADF_PP_DBG; ADF_GEMM_DBG=bits): 1 no stores,
+    // 2 no prologue math, 4 no MFMA, 32 no weight DMA, 64 no activation DMA, 128 no barriers, 256 no fragment reads,
+    // 512 no epilogue, 1024 no descriptor updates.
+    // Results are wrong by construction; the product build folds every test away.
+    const int dbg = a.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
     const bool early = (wave & 4) == 0;            // waves w and w+4 share a SIMD: they run prologue and MFMAs in opposite order
     const int lrow = lane >> 3;                     // row inside an 8-row DMA piece
     // logical 16-byte chunk stored at this lane's slot: slot ^ ((row >> 1) & 7), row = 8 * piece + lrow, piece = wave + 8 i
@@ -130,7 +140,10 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         b0 = tml >> tm_shift;
         m0 = (tml & ((1 << tm_shift) - 1)) * TM;
     };
-    auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto lds_barrier = [&]() __attribute__((always_inline)) {
+        if (dbg & 128) return;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
     // wait until at most n of this wave's DMA instructions (the youngest ones) are still in flight
     auto wait_dma = [&](int n) __attribute__((always_inline)) {
         if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -169,22 +182,32 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     // its first use is prepared).  Returns the number of DMA instructions this wave issued (0 / 4 / 5 / 6).
     // part: 0 = pieces 0-1, 1 = pieces 2-3, 2 = halo + table, -1 = everything (pipeline fill)
     auto issue_a = [&](const PpBlk& d, int st, int part) __attribute__((always_inline)) -> int {
+        if (dbg & 64) return 0;
         const unsigned colbytes = (unsigned)chunk * 16u;
-        const int p0 = d.p_lo + srow;                                       // input position of this lane's row, unit 0
         const unsigned ldsA = (unsigned)(st * kPpAStage) + (unsigned)wave * 1024u;
-        // only the first row of a tile (unit 0, p = -1) can be padding here; that lane fetches row 0 instead and is zeroed later
-        const char* g0 = d.asrc + ((long long)d.rowbase + p0) * (long long)d.rowbytes + colbytes;
+        // uniform base = row p_lo of the tile (may be row -1 of the sample: only wave 0's first row, which then fetches row
+        // 0 instead and is zeroed later); lane offset = staged row * pitch + column bytes
+        const char* const base = d.asrc + ((long long)d.rowbase + d.p_lo) * (long long)d.rowbytes;
+        unsigned voff = (unsigned)srow * d.rowbytes + colbytes;
         const unsigned step = 64u * d.rowbytes;
         int n = 0;
-        if (part < 0 && MT == 2) { pp_dma16x4(p0 < 0 ? g0 + d.rowbytes : g0, g0 + step, step, ldsA); n = 4; }
-        if (part == 0 || (part < 0 && MT == 1)) { pp_dma16(p0 < 0 ? g0 + d.rowbytes : g0, ldsA); pp_dma16(g0 + step, ldsA + 8192u); n = 2; }
-        if (part == 1 && MT == 2) { pp_dma16(g0 + 2 * step, ldsA + 16384u); pp_dma16(g0 + 3 * step, ldsA + 24576u); n = 2; }
+        if (part <= 0) {
+            const unsigned v0 = (d.p_lo < 0 && srow == 0) ? voff + d.rowbytes : voff;
+            pp_dma16(base, v0, ldsA);
+            pp_dma16(base + step, voff, ldsA + 8192u);
+            n = 2;
+        }
+        if (MT == 2 && (part < 0 || part == 1)) {
+            pp_dma16(base + 2 * step, voff, ldsA + 16384u);
+            pp_dma16(base + 3 * step, voff, ldsA + 24576u);
+            n += 2;
+        }
         if (part < 0 || part == 2) {
             if (wave == 0 && d.taps == 3) {
-                const int p = d.p_lo + TM + lrow;
-                const bool ok = p >= 0 && p < a.lin;
-                const unsigned off = ok ? (d.rowbase + (unsigned)p) * d.rowbytes + colbytes : 0u;
-                if (lane < 16) pp_dma16(d.asrc + off, (unsigned)(st * kPpAStage) + (unsigned)HP * 1024u);
+                // rows TM, TM + 1 of the tile; past the end of the sample both lanes rows fetch row TM (zeroed later)
+                const bool hi_ok = d.p_lo + TM + 1 < a.lin;
+                const unsigned vh = (hi_ok ? (unsigned)lrow * d.rowbytes : 0u) + colbytes;
+                if (lane < 16) pp_dma16(base + (unsigned)TM * d.rowbytes, vh, (unsigned)(st * kPpAStage) + (unsigned)HP * 1024u);
                 n += 1;
             }
             if (use_tab && d.last && d.tseq + 1 < ntiles && (unsigned)wave * 1024u < (unsigned)ctot0 * 8u) {
@@ -192,7 +215,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 geom(d.tseq + 1, b0, m0, n0);
                 const unsigned boff = (unsigned)wave * 1024u + lane_lds;
                 if (boff < (unsigned)ctot0 * 8u)
-                    pp_dma16(uniform_ptr(a.seg[0].ab) + ((size_t)b0 * ctot0) * 8 + boff,
+                    pp_dma16(uniform_ptr(a.seg[0].ab) + ((size_t)b0 * ctot0) * 8, boff,
                              (unsigned)(kPpOffTab + ((d.tseq + 1) & 1) * kPpTab) + (unsigned)wave * 1024u);
                 n += 1;
             }
@@ -202,81 +225,88 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     // ---- DMA of one weight slab (tap slab at wsrc) into W stage st: 2 pieces per wave ---------------------
     const unsigned wlane = (unsigned)srow * (unsigned)kRowBytes + (unsigned)chunk * 16u;
     auto issue_w = [&](const char* wsrc, int st) __attribute__((always_inline)) {
+        if (dbg & 32) return;
         const unsigned ldsW = (unsigned)(kPpOffW + st * kPpWStage) + (unsigned)wave * 1024u;
-        pp_dma16(wsrc + wlane, ldsW);
-        pp_dma16(wsrc + wlane + 64 * kRowBytes, ldsW + 8192u);
+        pp_dma16(wsrc, wlane, ldsW);
+        pp_dma16(wsrc + 64 * kRowBytes, wlane, ldsW + 8192u);
     };
 
     // ---- fused prologue of K block d, in place on the chunks this wave fetched (stage st); zero padding for rows
     // outside the sample.  Raw blocks only need the zero fill (sample-edge tiles of a 3-tap block).
-    auto transform = [&](const PpBlk& d, int st) __attribute__((always_inline)) {
+    // The work is cut into 8-byte halves of the wave's pieces and done in three parts (P = 0, 1, 2: one per sub-step
+    // of the block that computes meanwhile; P = -1: everything) so that every sub-step has vector work for one wave
+    // of a SIMD to do while its partner runs MFMAs; halo piece and zero fill go with the last part.
+    auto transform = [&](const PpBlk& d, int st, auto partc) __attribute__((always_inline)) {
+        constexpr int P = decltype(partc)::value;
+        constexpr int NH = 4 * MT;                                          // 8-byte halves of this wave's pieces
+        constexpr int B1 = (NH * 3 + 7) / 8, B2 = (NH * 6 + 7) / 8;
+        constexpr int H0 = P <= 0 ? 0 : (P == 1 ? B1 : B2);
+        constexpr int H1 = P < 0 ? NH : (P == 0 ? B1 : (P == 1 ? B2 : NH));    // (P = 3 never gets here)
+        constexpr bool kTail = P < 0 || P >= 2;                             // P = 3: only the zero fill
         char* const ldsA = smem + st * kPpAStage + wave * 1024 + lane_lds;
         char* const ldsH = smem + st * kPpAStage + HP * 1024 + lane_lds;
         const bool halo = wave == 0 && d.taps == 3;
-        const int p0 = d.p_lo + srow;
-        const int ph = d.p_lo + TM + lrow;
-        const bool edge = d.taps == 3 && (d.p_lo < 0 || d.p_lo + TM + 2 > a.lin);    // uniform: a halo row is padding
-        if (d.tabofs >= 0 || d.act || d.scale != 1.0f) {                   // uniform
-            f32x2_t fa2[4], fb2[4];
+        if (P != 3 && !(dbg & 2) && (d.tabofs >= 0 || d.act || d.scale != 1.0f)) {       // uniform
+            float fa[8], fb[8];
             if (d.tabofs >= 0) {
                 const f32x4_t* tp = (const f32x4_t*)(ldsTab + d.tabofs + chunk * 64);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const f32x4_t t = tp[e];
-                    fa2[e] = f32x2_t{t.x, t.z};
-                    fb2[e] = f32x2_t{t.y, t.w};
+                    fa[2 * e] = t.x; fb[2 * e] = t.y; fa[2 * e + 1] = t.z; fb[2 * e + 1] = t.w;
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { fa2[e] = f32x2_t{d.scale, d.scale}; fb2[e] = f32x2_t{0.f, 0.f}; }
+                for (int e = 0; e < 8; ++e) { fa[e] = d.scale; fb[e] = 0.f; }
             }
-            // 8-wide stages (all exps, then all adds, then all rcps ...) so the transcendentals of a chunk pipeline
-            // instead of forming one serial dependency chain per pair
-            auto math = [&](const u32x4_t& raw, auto actc) __attribute__((always_inline)) -> u32x4_t {
+            // staged (all exps, then all adds, then all rcps ...) so the transcendentals pipeline instead of forming
+            // one serial dependency chain per element
+            auto math4 = [&](const u32x2_t& raw, int sub, auto actc) __attribute__((always_inline)) -> u32x2_t {
                 constexpr bool kAct = decltype(actc)::value;
-                float f[8];
-                unpack16<T>(raw, f);
-                f32x2_t v2[4];
+                float v[4];
+                v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+                v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v2[e] = f32x2_t{f[2 * e], f[2 * e + 1]} * fa2[e] + fb2[e];
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fa[4 * sub + e], fb[4 * sub + e]);
                 if constexpr (kAct) {
-                    float ex[8];
+                    float ex[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x2_t z2 = v2[e] * -1.4426950408889634f;
-                        ex[2 * e] = z2.x; ex[2 * e + 1] = z2.y;
-                    }
+                    for (int e = 0; e < 4; ++e) ex[e] = __builtin_amdgcn_exp2f(v[e] * -1.4426950408889634f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ex[e] = __builtin_amdgcn_exp2f(ex[e]);
+                    for (int e = 0; e < 4; ++e) ex[e] = __builtin_amdgcn_rcpf(ex[e] + 1.0f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ex[e] += 1.0f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ex[e] = __builtin_amdgcn_rcpf(ex[e]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v2[e] = v2[e] * f32x2_t{ex[2 * e], ex[2 * e + 1]};
+                    for (int e = 0; e < 4; ++e) v[e] *= ex[e];
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { f[2 * e] = v2[e].x; f[2 * e + 1] = v2[e].y; }
-                return pack16<T>(f);
+                u32x2_t o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                return o;
             };
-            constexpr int NU = 2 * MT;                                      // this wave's pieces of the block
-            u32x4_t raw[NU];
+            auto run = [&](auto actc) __attribute__((always_inline)) {
+                u32x2_t raw[H1 - H0 > 0 ? H1 - H0 : 1];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) raw[i] = *(const u32x4_t*)(ldsA + i * 8192);
-            if (d.act) {                                                    // uniform: two straight-line versions
+                for (int hh = H0; hh < H1; ++hh) raw[hh - H0] = *(const u32x2_t*)(ldsA + (hh >> 1) * 8192 + (hh & 1) * 8);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::true_type{});
-                if (halo && lane < 16) *(u32x4_t*)ldsH = math(*(const u32x4_t*)ldsH, std::true_type{});
-            } else {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) *(u32x4_t*)(ldsA + i * 8192) = math(raw[i], std::false_type{});
-                if (halo && lane < 16) *(u32x4_t*)ldsH = math(*(const u32x4_t*)ldsH, std::false_type{});
-            }
+                for (int hh = H0; hh < H1; ++hh)
+                    *(u32x2_t*)(ldsA + (hh >> 1) * 8192 + (hh & 1) * 8) = math4(raw[hh - H0], hh & 1, actc);
+                if (kTail && halo && lane < 16) {
+                    const u32x4_t hr = *(const u32x4_t*)ldsH;
+                    const u32x2_t lo = math4(u32x2_t{hr.x, hr.y}, 0, actc), hi = math4(u32x2_t{hr.z, hr.w}, 1, actc);
+                    *(u32x4_t*)ldsH = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+                }
+            };
+            if (d.act) run(std::true_type{});                               // uniform: two straight-line versions
+            else run(std::false_type{});
         }
-        if (edge) {                                                         // conv zero padding applies to the activated tensor
-            const u32x4_t z = u32x4_t{0u, 0u, 0u, 0u};
-            if (p0 < 0) *(u32x4_t*)ldsA = z;
-            if (halo && lane < 16 && ph >= a.lin) *(u32x4_t*)ldsH = z;
+        if constexpr (kTail) {
+            const int p0 = d.p_lo + srow;
+            const int ph = d.p_lo + TM + lrow;
+            const bool edge = d.taps == 3 && (d.p_lo < 0 || d.p_lo + TM + 2 > a.lin);    // uniform: a halo row is padding
+            if (edge) {                                                     // conv zero padding applies to the activated tensor
+                const u32x4_t z = u32x4_t{0u, 0u, 0u, 0u};
+                if (p0 < 0) *(u32x4_t*)ldsA = z;
+                if (halo && lane < 16 && ph >= a.lin) *(u32x4_t*)ldsH = z;
+            }
         }
     };
 
@@ -294,20 +324,30 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const unsigned wbase = (unsigned)((wn * 64 + r) * kPpRow + ((h ^ (fw & 1)) << 4) + ((fw >> 1) << 5));
     // `between(ks)` runs after the MFMAs of 16-channel group ks have been issued: the DMA instructions of the step are
     // placed there, one or two per group, so the ~100 cycles each of them holds the wave are covered by queued MFMAs
-    auto mfma = [&](auto tapc, int stA, int stW, auto between) __attribute__((always_inline)) {
+    // `gap(q)` (q = 0 .. 8 MT - 1) runs after MFMA q of the sub-step has been issued, fenced so that the compiler keeps it there.
+    auto mfma_gaps = [&](auto tapc, int stA, int stW, auto between, auto gapped, auto gap) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tapc)::value;
+        constexpr bool kGaps = decltype(gapped)::value;
         const unsigned ab = abase[TAP];
         const char* pa = smem + stA * kPpAStage;
         const char* pw = smem + kPpOffW + stW * kPpWStage;
         bf16x8_t fa[2][MT], fb[2][2];
+        if (dbg & 256) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = *(const bf16x8_t*)(pa + ab + i * 32 * kPpRow);
+            for (int i = 0; i < MT; ++i) fa[0][i] = fa[1][i] = bf16x8_t{};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8_t*)(pw + wbase + j * 32 * kPpRow);
+            for (int j = 0; j < 2; ++j) fb[0][j] = fb[1][j] = bf16x8_t{};
+        }
+        if (!(dbg & 256)) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[0][i] = *(const bf16x8_t*)(pa + ab + i * 32 * kPpRow);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8_t*)(pw + wbase + j * 32 * kPpRow);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < 4) {
+            if (ks + 1 < 4 && !(dbg & 256)) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) fa[nxt][i] = *(const bf16x8_t*)(pa + (ab ^ (unsigned)((ks + 1) << 5)) + i * 32 * kPpRow);
 #pragma unroll
@@ -316,17 +356,116 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if (!(dbg & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                    if constexpr (kGaps) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        gap(ks * 2 * MT + i * 2 + j);
+                    }
+                }
             __builtin_amdgcn_sched_barrier(0);
             between(ks);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto mfma = [&](auto tapc, int stA, int stW, auto between) __attribute__((always_inline)) {
+        mfma_gaps(tapc, stA, stW, between, std::false_type{}, [](int) {});
+    };
+
+    // ---- one sub-step with the GroupNorm/FiLM/SiLU prologue of part P of block dn (stage stN) woven into the gaps
+    // between its MFMAs, one element per gap and lane (two for MT = 1), in two stages one gap apart (exp2 of element e
+    // beside the rcp of element e-1) so that no gap holds a serial transcendental chain.  Measured with per-wave
+    // s_memtime stamps (tools/pp_stamps.py): a prologue part placed before or after the MFMAs of its sub-step costs
+    // ~1500 cycles whatever its size (LDS round trips + dependent chains while the partner wave owns the issue
+    // slots), so the vector work has to ride inside the wave's own MFMA stream.  EARLY waves use the first gaps, the
+    // others the last ones; the halo piece (wave 0) goes with the part that has the fewest elements.
+    auto mfma_fused = [&](auto tapc, auto partc, auto earlyc, int stA, int stW, const PpBlk& dn, int stN, auto fuse, auto between)
+                          __attribute__((always_inline)) {
+        constexpr int P = decltype(partc)::value;
+        constexpr bool EARLY = decltype(earlyc)::value;
+        // parts 0 / 1 take the even / odd 8-byte halves of the wave's pieces (MT = 2: of the first three), so each needs
+        // the (a, b) of 4 channels only; part 2 takes the last piece (MT = 2).  The halo chunk (wave 0) is split the same
+        // way over parts 0 / 1 (MT = 2) or goes whole into the otherwise empty part 2 (MT = 1).
+        constexpr int NOWN = P < 2 ? (MT == 2 ? 3 : 2) : (MT == 2 ? 2 : 0);   // own halves of this part
+        auto half_of = [](int idx) constexpr -> int { return P < 2 ? P + 2 * idx : 6 + idx; };
+        constexpr int NHU = !EARLY ? 0 : (MT == 2 ? (P < 2 ? 1 : 0) : (P < 2 ? 0 : 2));   // halo halves of this part (wave 0 is an early wave)
+        constexpr int HH0 = MT == 2 ? P : 0;                                // first of them
+        constexpr bool kHalo = NHU > 0;
+        constexpr int NE = 4 * NOWN, NEH = NE + 4 * NHU;
+        constexpr int GAPS = 8 * MT;
+        static_assert(NEH <= GAPS, "one element per gap");
+        constexpr int G0 = EARLY ? 0 : GAPS - NEH;
+        char* const ldsN = smem + stN * kPpAStage + wave * 1024 + lane_lds;
+        char* const ldsH = smem + stN * kPpAStage + HP * 1024 + lane_lds;
+        const bool halo = kHalo && wave == 0 && dn.taps == 3;               // uniform
+        // `fuse` (uniform) = block dn has a GroupNorm + SiLU prologue; otherwise the gaps stay empty (same code path, so
+        // that the accumulators keep one register assignment across all kinds of sub-steps)
+        float ta[8], tb[8];
+        constexpr int NU = NOWN + NHU;                                      // 8-byte units: own halves, then halo halves
+        u32x2_t raw[NU > 0 ? NU : 1];
+        if (fuse) {
+            const f32x4_t* tp = (const f32x4_t*)(ldsTab + dn.tabofs + chunk * 64);
+#pragma unroll
+            for (int e = (P == 1 ? 2 : 0); e < (P == 0 ? 2 : 4); ++e) {
+                const f32x4_t t = tp[e];
+                ta[2 * e] = t.x; tb[2 * e] = t.y; ta[2 * e + 1] = t.z; tb[2 * e + 1] = t.w;
+            }
+#pragma unroll
+            for (int i = 0; i < NOWN; ++i) raw[i] = *(const u32x2_t*)(ldsN + (half_of(i) >> 1) * 8192 + (half_of(i) & 1) * 8);
+            if (halo) {
+#pragma unroll
+                for (int u = 0; u < NHU; ++u) raw[NOWN + u] = *(const u32x2_t*)(ldsH + (HH0 + u) * 8);
+            }
+        }
+        float vp[2], tq[2], ow[4];                                           // pipeline registers alternate by element parity: no copies
+        auto valid = [&](int e) __attribute__((always_inline)) -> bool { return e >= 0 && e < NEH && (e < NE || halo); };
+        auto chan_of = [&](int e) __attribute__((always_inline)) -> int { return e < NE ? ((half_of(e >> 2) & 1) * 4 + (e & 3)) : (HH0 + ((e - NE) >> 2)) * 4 + (e & 3); };
+        // One gap: stage b of element eb (1 + exp -> rcp -> product; pack + store when its 8-byte unit is complete) beside
+        // stage a of element ea = eb + 1 (unpack, affine, exp2).  The empty asm statements pin the two chains between
+        // them (IR passes move pure arithmetic across sched_barrier) and leave their interleaving to the scheduler.
+        auto gap = [&](int q) __attribute__((always_inline)) {
+            const int ea = q - G0, eb = ea - 1;
+            if (fuse && !(dbg & 2)) {
+                const bool va = valid(ea), vb = valid(eb);
+                float told = 0.f, vold = 0.f, x = 0.f, o = 0.f, v = 0.f, t = 0.f;
+                if (vb) { told = tq[eb & 1]; vold = vp[eb & 1]; asm volatile("" : "+v"(told)); }
+                if (va) {
+                    const unsigned w = (ea & 2) ? raw[ea >> 2].y : raw[ea >> 2].x;
+                    x = __uint_as_float((ea & 1) ? (w & 0xffff0000u) : (w << 16));
+                    asm volatile("" : "+v"(x));
+                }
+                if (vb) o = vold * __builtin_amdgcn_rcpf(told + 1.0f);
+                if (va) {
+                    v = fmaf(x, ta[chan_of(ea)], tb[chan_of(ea)]);
+                    t = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+                }
+                if (vb) asm volatile("" : "+v"(o));
+                if (va) { asm volatile("" : "+v"(t)); vp[ea & 1] = v; tq[ea & 1] = t; }
+                if (vb) {
+                    ow[eb & 3] = o;
+                    if ((eb & 3) == 3) {
+                        u32x2_t pk;
+                        pk.x = pack_bf16x2(ow[0], ow[1]);
+                        pk.y = pack_bf16x2(ow[2], ow[3]);
+                        if (eb < NE) {
+                            const int hh = half_of(eb >> 2);
+                            *(u32x2_t*)(ldsN + (hh >> 1) * 8192 + (hh & 1) * 8) = pk;
+                        } else if (lane < 16) {
+                            *(u32x2_t*)(ldsH + (HH0 + ((eb - NE) >> 2)) * 8) = pk;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        mfma_gaps(tapc, stA, stW, between, std::true_type{}, gap);
+        gap(GAPS);                                                           // stage b of the last elements
+    };
 
     // ---- wave-local epilogue of one finished tile --------------------------------------------------------------
     const int cc = lane & 7, rsub = lane >> 3;              // this lane's 16-byte chunk column / row inside an 8-row pass
     auto epilogue = [&](int tseq, int next_n0) __attribute__((always_inline)) {
+        if (dbg & 512) return;
         int b0, m0, n0;
         geom(tseq, b0, m0, n0);
         float* sc = (float*)(ldsScr + wave * 2048);          // [8][64] fp32
@@ -363,7 +502,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                     const float4 q0 = *(const float4*)(scr), q1 = *(const float4*)(scr + 4);
                     v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
                 }
-                *(u32x4_t*)(out + off) = pack16<T>(v);
+                if (!(dbg & 1)) *(u32x4_t*)(out + off) = pack16<T>(v);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2_t v2 = {v[e], v[e + 1]};
@@ -393,6 +532,11 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const std::integral_constant<int, 0> tap0{};
     const std::integral_constant<int, 1> tap1{};
     const std::integral_constant<int, 2> tap2{};
+    const std::integral_constant<int, 0> part0{};
+    const std::integral_constant<int, 1> part1{};
+    const std::integral_constant<int, 2> part2{};
+    const std::integral_constant<int, -1> part_all{};
+    const std::integral_constant<int, 3> part_tail{};
     int nt = 0, nbk = 0;                                     // (tile, block) cursor of the descriptor stream
     auto next_desc = [&]() __attribute__((always_inline)) -> PpBlk {
         if (++nbk == nb) { nbk = 0; ++nt; }
@@ -435,11 +579,32 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_r[j];
     }
-    transform(dc, 0);
+    transform(dc, 0, part_all);
     lds_barrier();
 
     int stA = 0, stW = 0;
+    // the two waves of a SIMD run their own copy of the loop (EARLY decides where the prologue elements sit among the
+    // MFMA gaps); both copies reach the same barriers
+    auto main_loop = [&](auto earlyc) __attribute__((always_inline)) {
+#ifndef ADF_PP_SPLIT
+    const bool EARLY = earlyc;
+#else
+    constexpr bool EARLY = decltype(earlyc)::value;
+#endif
     for (int g = 0; g < GB; ++g) {
+#ifdef ADF_PP_STAMP
+        // stamps go to the unused tail of the bias area (LDS) and are copied out when the kernel ends
+        const bool stamp_on = bidx == 0 && g == nb + 1 && a.nseg == 1 && a.n_pad <= 128;
+        auto stamp = [&](int id) __attribute__((always_inline)) {
+            if (stamp_on) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) ((unsigned long long*)(smem + kPpOffBias + 512))[wave * 24 + id] = t;
+            }
+        };
+#else
+        auto stamp = [&](int) __attribute__((always_inline)) {};
+#endif
+        stamp(0);
         const bool has1 = g + 1 < GB, has2 = g + 2 < GB;
         const int stA1 = stA == kPpAStages - 1 ? 0 : stA + 1;
         const int stA2 = stA1 == kPpAStages - 1 ? 0 : stA1 + 1;
@@ -449,30 +614,60 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
             epilogue(dc.tseq - 1, n0);
         }
         if (dc.taps == 3) {
-            // ---- tap 0: next slab = tap 1; the activations of block g+2 start their way (in three parts)
+            // The activations of block g+1 are prepared in three parts beside the three sub-steps of block g; the two waves
+            // of a SIMD do (vector part, MFMAs) in opposite order, so one of them always has matrix work for the pipe.
+            // ---- tap 0: next slab = tap 1; the activations of block g+2 start their way
             int nA = 0;
-            mfma(tap0, stA, stW, [&](int ks) __attribute__((always_inline)) {
+            const bool fuse = has1 && d1.tabofs >= 0 && d1.act;               // uniform: the usual case (conv after GroupNorm + SiLU)
+            const bool slow = has1 && !fuse && (d1.tabofs >= 0 || d1.act || d1.scale != 1.0f);   // other prologues: beside the MFMAs
+            auto sub = [&](auto tapc, auto partc, auto between) __attribute__((always_inline)) {
+                if (slow && EARLY) transform(d1, stA1, partc);
+                __builtin_amdgcn_sched_barrier(0);
+                auto call = [&](auto ec) __attribute__((always_inline)) {
+#ifndef ADF_PP_GAPBRANCH
+                    if (fuse) mfma_fused(tapc, partc, ec, stA, stW, d1, stA1, std::true_type{}, between);
+                    else mfma_fused(tapc, partc, ec, stA, stW, d1, stA1, std::false_type{}, between);
+#else
+                    mfma_fused(tapc, partc, ec, stA, stW, d1, stA1, fuse, between);
+#endif
+                };
+#ifndef ADF_PP_SPLIT
+                if (EARLY) call(std::true_type{});
+                else call(std::false_type{});
+#else
+                call(earlyc);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (slow && !EARLY) transform(d1, stA1, partc);
+            };
+            stamp(1);
+            sub(tap0, part0, [&](int ks) __attribute__((always_inline)) {
                 if (ks == 0) issue_w(dc.w + slab, stW ^ 1);
                 else if (has2) nA += issue_a(d2, stA2, ks - 1);
             });
+            stamp(3);
             wait_dma(nA);
+            stamp(4);
             stW ^= 1;
             lds_barrier();
+            stamp(5);
             // ---- tap 1
-            mfma(tap1, stA, stW, [&](int ks) __attribute__((always_inline)) { if (ks == 0) issue_w(dc.w + slab + slab, stW ^ 1); });
+            sub(tap1, part1, [&](int ks) __attribute__((always_inline)) { if (ks == 0) issue_w(dc.w + slab + slab, stW ^ 1); });
+            stamp(8);
             wait_dma(0);
+            stamp(9);
             stW ^= 1;
             lds_barrier();
-            // ---- tap 2: next slab = tap 0 of block g+1, whose activations are prepared beside the MFMAs: the two waves
-            // of a SIMD do it in opposite order
-            if (has1 && early) transform(d1, stA1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma(tap2, stA, stW, [&](int ks) __attribute__((always_inline)) { if (ks == 0 && has1) issue_w(d1.w, stW ^ 1); });
-            __builtin_amdgcn_sched_barrier(0);
-            if (has1 && !early) transform(d1, stA1);
+            stamp(10);
+            // ---- tap 2: next slab = tap 0 of block g+1; zero padding of block g+1 once its last part is in place
+            sub(tap2, part2, [&](int ks) __attribute__((always_inline)) { if (ks == 0 && has1) issue_w(d1.w, stW ^ 1); });
+            if (has1 && !slow) transform(d1, stA1, part_tail);
+            stamp(13);
             wait_dma(0);
+            stamp(14);
             stW ^= 1;
             lds_barrier();
+            stamp(15);
         } else {
             // ---- single-tap block: everything of the next block is needed after this one sub-step
             int nA = 0;
@@ -481,16 +676,28 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 else if (has2) nA += issue_a(d2, stA2, ks - 1);
             });
             wait_dma(nA);
-            if (has1) transform(d1, stA1);
+            if (has1) transform(d1, stA1, part_all);
             stW ^= 1;
             lds_barrier();
         }
         dc = d1; d1 = d2;
-        d2 = next_desc();
+        if (!(dbg & 1024)) d2 = next_desc();
         stA = stA1;
+        stamp(16);
     }
     wait_dma(0);
     epilogue(ntiles - 1, 0);
+    };
+#ifndef ADF_PP_SPLIT
+    main_loop(early);
+#else
+    if (early) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+#endif
+#ifdef ADF_PP_STAMP
+    if (bidx == 0 && a.nseg == 1 && a.n_pad <= 128 && lane < 24)
+        adf_pp_stamps[wave * 32 + lane] = ((const unsigned long long*)(smem + kPpOffBias + 512))[wave * 24 + lane];
+#endif
 }
 
 }  // namespace adf

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: tools/build_variant.sh NAME [extra hipcc flags...]  -> audiodiffuser_amd/build/variants/libadf_hip_NAME.so
+# A second build of the library (e.g. -DADF_PP_STAMP, -fno-slp-vectorize) to A/B against the product build inside one
+# gpurun call: ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_NAME.so python bench.py ...
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/audiodiffuser_amd/build/variants; mkdir -p $out/$name
+objs=""
+for f in adf_api adf_gemm adf_kernels; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $root/audiodiffuser_amd/csrc/$f.hip -o $out/$name/$f.o &
+  objs="$objs $out/$name/$f.o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libadf_hip_$name.so $objs
+echo $out/libadf_hip_$name.so
