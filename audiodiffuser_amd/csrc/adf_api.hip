@@ -701,39 +701,62 @@ int run_edm_alpha(SamplerCtx& c, float** result) {
     return 0;
 }
 
+// DPMSampler.get_lambda / lambd / sigma / inv_lambd (sampler_edm.py:528-556) on host fp32 scalars.  log spacing: the
+// grid holds lambda = -log sigma, a torch.linspace over n + 1 points between the first and the last sigma; otherwise the
+// grid IS the sigma list.
+struct DpmGrid {
+    std::vector<float> g;
+    bool logsp;
+    float lam(float v) const { return logsp ? v : -logf(v); }
+    float sig(float v) const { return logsp ? expf(-v) : v; }
+    float inv(float v) const { return logsp ? v : expf(-v); }
+};
+DpmGrid dpm_grid(const float* sig, int nsig, int n, bool logsp) {
+    DpmGrid r;
+    r.logsp = logsp;
+    if (!logsp) { r.g.assign(sig, sig + nsig); return r; }
+    const float start = -logf(sig[0]), end = -logf(sig[nsig - 1]);
+    const int steps = n + 1;
+    const float step = (end - start) / (float)(steps - 1);
+    r.g.resize(steps);
+    for (int i = 0; i < steps; ++i)                                   // torch.linspace: from the start in the first half, from the end in the second
+        r.g[i] = i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+    return r;
+}
+
 int run_dpm(SamplerCtx& c, float** result) {
     const adf_sampler_desc& d = *c.d;
-    const int steps = d.num_steps - 1;  // log_time_spacing=False: sampler_edm.py:526
+    const bool logsp = d.log_time_spacing != 0;
+    const int steps = logsp ? d.num_steps : d.num_steps - 1;  // sampler_edm.py:526
     const int order = d.order;
     if (order < 1 || order > 3) return c.count_only ? 1 : fail(c.h, "DPMSampler: order must be 1, 2 or 3");
-    if (steps < order || c.nsig < steps + 1) return c.count_only ? 1 : fail(c.h, "DPMSampler: not enough steps / sigmas");
+    if (steps < order || c.nsig < 2 || (!logsp && c.nsig < steps + 1)) return c.count_only ? 1 : fail(c.h, "DPMSampler: not enough steps / sigmas");
+    const DpmGrid G = dpm_grid(c.sig, c.nsig, steps, logsp);
     Plan* p = c.p;
     float* X = c.count_only ? nullptr : p->sb[0];
     float* XN = c.count_only ? nullptr : p->sb[1];
     float* M[3] = {c.count_only ? nullptr : p->sb[6], c.count_only ? nullptr : p->sb[7], c.count_only ? nullptr : p->sb[8]};
     if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    auto lam = [](float s_) { return -logf(s_); };
-    // history: index 0 = most recent
-    float sh[3] = {c.sig[0], 0.f, 0.f};
-    int nh = 1;
-    if (c.den(X, c.sig[0], M[0])) return 1;
+    // history of grid values: index 0 = most recent
+    float sh[3] = {G.g[0], 0.f, 0.f};
+    if (c.den(X, G.sig(G.g[0]), M[0])) return 1;
     for (int step = 1; step <= steps; ++step) {
         const int ord = step < order ? step : std::min(order, steps + 1 - step);
-        const float sc = c.sig[step];
-        const float hcur = lam(sc) - lam(sh[0]);
+        const float sc = G.g[step];
+        const float hcur = G.lam(sc) - G.lam(sh[0]);
         DpmArgs a;
         memset(&a, 0, sizeof(a));
         a.order = ord;
-        a.ratio = sc / sh[0];
+        a.ratio = G.sig(sc) / G.sig(sh[0]);
         a.phi1 = expm1f(-hcur);
         a.m0 = M[0]; a.m1 = M[1]; a.m2 = M[2];
         if (ord == 2) {
-            const float h1 = lam(sh[0]) - lam(sh[1]);
+            const float h1 = G.lam(sh[0]) - G.lam(sh[1]);
             const float r0 = h1 / hcur;
             a.inv_r0 = 1.0f / r0;
         } else if (ord == 3) {
-            const float h1 = lam(sh[1]) - lam(sh[2]);
-            const float h0 = lam(sh[0]) - lam(sh[1]);
+            const float h1 = G.lam(sh[1]) - G.lam(sh[2]);
+            const float h0 = G.lam(sh[0]) - G.lam(sh[1]);
             const float r0 = h0 / hcur, r1 = h1 / hcur;
             a.inv_r0 = 1.0f / r0; a.inv_r1 = 1.0f / r1;
             a.r0_frac = r0 / (r0 + r1);
@@ -741,18 +764,133 @@ int run_dpm(SamplerCtx& c, float** result) {
             a.phi2 = a.phi1 / hcur + 1.0f;
             a.phi3 = a.phi2 / hcur - 0.5f;
         }
-        (void)nh;
         const int last = step == steps;
         if (!c.count_only && c.ck(launch_dpm_update(XN, X, a, last, c.n, c.s))) return 1;
         std::swap(X, XN);
         sh[2] = sh[1]; sh[1] = sh[0]; sh[0] = sc;
-        nh = std::min(nh + 1, 3);
         if (!last) {
             float* oldest = M[2];
             M[2] = M[1]; M[1] = M[0]; M[0] = oldest;
-            if (c.den(X, sc, M[0])) return 1;
+            if (c.den(X, G.sig(sc), M[0])) return 1;
         }
     }
+    *result = X;
+    return 0;
+}
+
+// DPMSampler with multisteps=False, x0_pred=True ("DPM-Solver-fast"): sampler_edm.py:769-805 + :568-622.  Kept as
+// written: with log_time_spacing=False the grid is the whole sigma list but only len(orders) intervals are walked (the
+// run stops early), and the intermediate points add a lambda-space step to a sigma before inv_lambd (:584, :604).
+int run_dpm_single(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const bool logsp = d.log_time_spacing != 0;
+    const int n_eff = logsp ? d.num_steps : d.num_steps - 1;
+    const int order = d.order;
+    if (order < 1 || order > 3) return c.count_only ? 1 : fail(c.h, "DPMSampler: order must be 1, 2 or 3");
+    if (n_eff < 1 || c.nsig < 2) return c.count_only ? 1 : fail(c.h, "DPMSampler: not enough steps / sigmas");
+    std::vector<int> orders;
+    int K;
+    if (order == 3) {
+        K = n_eff / 3 + 1;
+        if (n_eff % 3 == 0) { orders.assign(std::max(K - 2, 0), 3); orders.push_back(2); orders.push_back(1); }
+        else { orders.assign(K - 1, 3); orders.push_back(n_eff % 3); }
+    } else if (order == 2) {
+        K = (n_eff + 1) / 2;
+        orders.assign(n_eff / 2, 2);
+        if (n_eff % 2) orders.push_back(1);
+    } else {
+        K = n_eff;
+        orders.assign(n_eff, 1);
+    }
+    if (!logsp && c.nsig < (int)orders.size() + 1) return c.count_only ? 1 : fail(c.h, "DPMSampler: fewer sigmas than solver intervals");
+    const DpmGrid G = dpm_grid(c.sig, c.nsig, K, logsp);
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* U = c.count_only ? nullptr : p->sb[2];
+    float* E0 = c.count_only ? nullptr : p->sb[6];
+    float* E1 = c.count_only ? nullptr : p->sb[7];
+    float* E2 = c.count_only ? nullptr : p->sb[8];
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    auto comb = [&](float* out, const float* e1, float a, float b, float cc, int clampit) -> int {
+        return c.count_only ? 0 : c.ck(launch_lincomb(out, X, E0, e1, a, b, cc, clampit, c.n, c.s));
+    };
+    for (size_t i = 0; i < orders.size(); ++i) {
+        const float cur = G.g[i], nxt = G.g[i + 1];
+        const float h = G.lam(nxt) - G.lam(cur);
+        const float ratio = G.sig(nxt) / G.sig(cur);
+        const int last = i + 1 == orders.size();
+        if (c.den(X, G.sig(cur), E0)) return 1;
+        if (orders[i] == 1) {
+            if (comb(XN, nullptr, ratio, expm1f(-h), 0.f, last)) return 1;
+        } else if (orders[i] == 2) {
+            const float r1 = 0.5f;
+            const float s1 = G.inv(cur + r1 * h);
+            if (comb(U, nullptr, G.sig(s1) / G.sig(cur), expm1f(-r1 * h), 0.f, 0)) return 1;
+            if (c.den(U, G.sig(s1), E1)) return 1;
+            if (comb(XN, E1, ratio, expm1f(-h), -((float)(1.0 / (2.0 * 0.5)) * expm1f(-h)), last)) return 1;
+        } else {
+            const double r1d = 1.0 / 3.0, r2d = 2.0 / 3.0;
+            const float r1 = (float)r1d, r2 = (float)r2d;
+            const float s1 = G.inv(cur + r1 * h), s2 = G.inv(cur + r2 * h);
+            if (comb(U, nullptr, G.sig(s1) / G.sig(cur), expm1f(-r1 * h), 0.f, 0)) return 1;
+            if (c.den(U, G.sig(s1), E1)) return 1;
+            const float cu2 = (float)(r2d / r1d) * (expm1f(-r2 * h) / (r2 * h) + 1.0f);
+            if (comb(U, E1, G.sig(s2) / G.sig(cur), expm1f(-r2 * h), cu2, 0)) return 1;
+            if (c.den(U, G.sig(s2), E2)) return 1;
+            const float cx3 = (float)(1.0 / r2d) * (expm1f(-h) / h + 1.0f);
+            if (comb(XN, E2, ratio, expm1f(-h), cx3, last)) return 1;
+        }
+        std::swap(X, XN);
+    }
+    *result = X;
+    return 0;
+}
+
+// LMSSampler.linear_multistep_coeff (sampler_edm.py:1149-1160): the integral over [t_i, t_{i+1}] of the Lagrange basis
+// polynomial of node t_{i-j} among t_i .. t_{i-order+1}.  Degree <= 3, so 3-point Gauss-Legendre in double is exact (the
+// reference integrates numerically with scipy quad to 1e-4 relative).
+double lms_coeff(int order, const float* t, int i, int j) {
+    static const double gx[3] = {-0.7745966692414834, 0.0, 0.7745966692414834};
+    static const double gw[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
+    const double a = t[i], b = t[i + 1], half = 0.5 * (b - a), mid = 0.5 * (a + b);
+    double s = 0.0;
+    for (int q = 0; q < 3; ++q) {
+        const double tau = mid + half * gx[q];
+        double prod = 1.0;
+        for (int k = 0; k < order; ++k) {
+            if (k == j) continue;
+            prod *= (tau - (double)t[i - k]) / ((double)t[i - j] - (double)t[i - k]);
+        }
+        s += gw[q] * prod;
+    }
+    return s * half;
+}
+
+// LMSSampler.forward: sampler_edm.py:1162-1190 (num_steps - 1 evaluations, history of `order` derivatives, final clamp)
+int run_lms(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int N = d.num_steps, order = d.order;
+    if (order < 1 || order > 4) return c.count_only ? 1 : fail(c.h, "LMSSampler: order must be 1..4");
+    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "LMSSampler: need at least num_steps (>= 2) sigmas");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* DEN = c.count_only ? nullptr : p->sb[5];
+    float* D[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (!c.count_only) { D[0] = p->sb[1]; D[1] = p->sb[2]; D[2] = p->sb[3]; D[3] = p->sb[4]; }
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    for (int i = 0; i + 1 < N; ++i) {
+        if (c.den(X, c.sig[i], DEN)) return 1;
+        const int cur = std::min(i + 1, order);
+        LmsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.order = cur;
+        for (int j = 0; j < cur; ++j) a.c[j] = (float)lms_coeff(cur, c.sig, i, j);
+        a.dcur = D[i & 3];
+        a.d1 = D[(i + 3) & 3]; a.d2 = D[(i + 2) & 3]; a.d3 = D[(i + 1) & 3];
+        if (!c.count_only && c.ck(launch_lms(X, DEN, c.sig[i], a, c.n, c.s))) return 1;
+    }
+    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
     *result = X;
     return 0;
 }
@@ -841,6 +979,8 @@ int run_sampler(SamplerCtx& c, float** result) {
         case ADF_SAMPLER_EDM: return run_edm(c, result);
         case ADF_SAMPLER_EDM_ALPHA: return run_edm_alpha(c, result);
         case ADF_SAMPLER_DPM_MULTISTEP: return run_dpm(c, result);
+        case ADF_SAMPLER_DPM_SINGLESTEP: return run_dpm_single(c, result);
+        case ADF_SAMPLER_LMS: return run_lms(c, result);
         default: return c.count_only ? 1 : fail(c.h, "unknown sampler kind");
     }
 }

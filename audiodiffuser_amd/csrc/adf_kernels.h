@@ -86,6 +86,12 @@ struct DpmArgs {
 };
 const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st);
 // x_next = x_base + ((x_eval - den) / sigma) * dt  (DPM2 / ancestral DPM2 steps)
+// LMSSampler: newest derivative d = (x - den) / sigma -> dcur; x += c[0]*d + c[1]*d1 + c[2]*d2 + c[3]*d3 (first `order` terms)
+struct LmsArgs { float* dcur; const float* d1; const float* d2; const float* d3; float c[4]; int order; };
+const char* launch_lms(float* x, const float* den, float sigma, const LmsArgs& a, long long n, hipStream_t s);
+// out = (a*x - b*e0) + c*(e1 - e0) (e1 may be null), optionally clamped to [-1, 1]: the single-step DPM-Solver updates
+const char* launch_lincomb(float* out, const float* x, const float* e0, const float* e1, float a, float b, float c, int clampit,
+                           long long n, hipStream_t s);
 const char* launch_dstep(float* x_next, const float* x_base, const float* x_eval, const float* den, float sigma, float dt, long long n,
                          hipStream_t st);
 const char* launch_clamp(float* x, long long n, hipStream_t st);

@@ -142,9 +142,12 @@ class EDMAlphaSampler(nn.Module):
 
 
 class DPMSampler(nn.Module):
-    """DPM-Solver.  The accelerated configuration is the shipped one
-    (configs/experiment/sc09_inference/diffunet_complex_sc09_eval_dpm.yaml:57-64):
-    ``multisteps=True, x0_pred=True, log_time_spacing=False``; other settings raise."""
+    """DPM-Solver with x0 prediction (sampler_edm.py:495-805): the multistep solver (``multisteps=True``; the shipped
+    configuration is configs/experiment/sc09_inference/diffunet_complex_sc09_eval_dpm.yaml:57-64 with
+    ``log_time_spacing=False``) and the single-step "DPM-Solver-fast" (``multisteps=False``), each on the sigma grid
+    itself or on a grid linear in log sigma.  The reference's quirks are kept: without log spacing the single-step run
+    walks only ``len(orders)`` intervals of the sigma list (stops early) and its intermediate points add a
+    lambda-space step to a sigma (:584, :604).  ``x0_pred=False`` raises."""
 
     def __init__(self, cond_scale, order=1, num_steps=10, multisteps=False, x0_pred: bool = True,
                  log_time_spacing: bool = True, use_graph: bool = True):
@@ -155,16 +158,32 @@ class DPMSampler(nn.Module):
         self.num_steps = num_steps if log_time_spacing else num_steps - 1      # sampler_edm.py:526
 
     def _check_supported(self) -> None:
-        if not (self.multisteps and self.x0_pred and not self.log_time_spacing):
-            raise NotImplementedError("only DPMSampler(multisteps=True, x0_pred=True, log_time_spacing=False) is on the "
-                                      "hot path (SURVEY.md 8a16); single-step / eps-pred / log-spaced variants are next-round work")
+        if not self.x0_pred:
+            raise NotImplementedError("DPMSampler(x0_pred=False) (noise prediction) is not on the hot path (SURVEY.md 8f)")
+        if self.order not in (1, 2, 3):
+            raise ValueError("'order' must be '1' or '2' or '3'.")
+
+    def singlestep_orders(self):
+        """sampler_edm.py:770-789."""
+        n, order = self.num_steps, self.order
+        if order == 3:
+            k = n // 3 + 1
+            return ([3] * (k - 2) + [2, 1] if n % 3 == 0 else [3] * (k - 1) + [n % 3]), k
+        if order == 2:
+            return ([2] * (n // 2) if n % 2 == 0 else [2] * (n // 2) + [1]), (n + 1) // 2
+        return [1] * n, n
+
+    def nfe(self) -> int:
+        return self.num_steps if self.multisteps else sum(self.singlestep_orders()[0])
 
     def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
         d = _lib.AdfSamplerDesc()
-        d.kind, d.num_steps = _lib.SAMPLER_DPM_MULTISTEP, self.ctor_num_steps
+        d.kind = _lib.SAMPLER_DPM_MULTISTEP if self.multisteps else _lib.SAMPLER_DPM_SINGLESTEP
+        d.num_steps = self.ctor_num_steps
         d.s_tmin = d.s_tmax = d.s_churn = 0.0
         d.s_noise = 1.0
         d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, int(self.order), sigma_data, int(self.use_graph)
+        d.log_time_spacing = int(bool(self.log_time_spacing))
         return d
 
     @torch.no_grad()
@@ -176,19 +195,52 @@ class DPMSampler(nn.Module):
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
-        # ---- interface-compatibility branch (sampler_edm.py:710-768, :624-690) --------------------
+        # ---- interface-compatibility branch (sampler_edm.py:710-805, :568-690) --------------------
+        call = lambda x, s: fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)
+        if self.log_time_spacing:           # grid of lambda = -log sigma (:546-552); lambd = inv_lambd = identity
+            lam = inv = lambda v: v
+            sig = lambda l: l.neg().exp()
+            grid_of = lambda n: torch.linspace(-sigmas[0].log(), -sigmas[-1].log(), n + 1)
+        else:                               # the grid is the sigma list (:556)
+            lam = lambda v: -v.log()
+            sig = lambda v: v
+            inv = lambda l: l.neg().exp()
+            grid_of = lambda n: sigmas
+        x = sigmas[0] * noise
+        if not self.multisteps:
+            orders, k = self.singlestep_orders()
+            grid = grid_of(k)
+            for i, o in enumerate(orders):
+                cur, nxt = grid[i], grid[i + 1]
+                h = lam(nxt) - lam(cur)
+                eps = call(x, sig(cur))
+                base = sig(nxt) / sig(cur) * x - torch.expm1(-h) * eps
+                if o == 1:
+                    x = base
+                elif o == 2:
+                    r1 = 1 / 2
+                    s1 = inv(cur + r1 * h)
+                    u1 = sig(s1) / sig(cur) * x - torch.expm1(-r1 * h) * eps
+                    x = base - 1 / (2 * r1) * torch.expm1(-h) * (call(u1, sig(s1)) - eps)
+                else:
+                    r1, r2 = 1 / 3, 2 / 3
+                    s1, s2 = inv(cur + r1 * h), inv(cur + r2 * h)
+                    u1 = sig(s1) / sig(cur) * x - (-r1 * h).expm1() * eps
+                    eps_r1 = call(u1, sig(s1))
+                    u2 = (sig(s2) / sig(cur) * x - (-r2 * h).expm1() * eps
+                          + (r2 / r1) * ((-r2 * h).expm1() / (r2 * h) + 1) * (eps_r1 - eps))
+                    x = base + 1 / r2 * (torch.expm1(-h) / h + 1) * (call(u2, sig(s2)) - eps)
+            return x.clamp(-1.0, 1.0)
         steps, order = self.num_steps, self.order
         assert steps >= order
-        lam = lambda s: -s.log()
-        call = lambda x, s: fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)
-        x = sigmas[0] * noise
-        s_hist, m_hist = [sigmas[0]], [call(x, sigmas[0])]
+        grid = grid_of(steps)
+        s_hist, m_hist = [grid[0]], [call(x, sig(grid[0]))]
         for step in range(1, steps + 1):
             o = step if step < order else min(order, steps + 1 - step)
-            s_cur, s0 = sigmas[step], s_hist[-1]
+            s_cur, s0 = grid[step], s_hist[-1]
             h = lam(s_cur) - lam(s0)
             phi1 = torch.expm1(-h)
-            new = s_cur / s0 * x - phi1 * m_hist[-1]
+            new = sig(s_cur) / sig(s0) * x - phi1 * m_hist[-1]
             if o == 2:
                 r0 = (lam(s0) - lam(s_hist[-2])) / h
                 new = new - 0.5 * phi1 * ((1.0 / r0) * (m_hist[-1] - m_hist[-2]))
@@ -205,7 +257,62 @@ class DPMSampler(nn.Module):
             x = new
             s_hist = (s_hist + [s_cur])[-order:]
             if step < steps:
-                m_hist = (m_hist + [call(x, s_cur)])[-order:]
+                m_hist = (m_hist + [call(x, sig(s_cur))])[-order:]
+        return x.clamp(-1.0, 1.0)
+
+
+class LMSSampler(nn.Module):
+    """'LMS Karras' linear multistep solver (sampler_edm.py:1134-1190): ``num_steps - 1`` evaluations, the last ``order``
+    derivatives combined with the integrals of their Lagrange basis polynomials over the step (the reference integrates
+    them with scipy ``quad`` on fp32 NumPy scalars, so its values carry ~1e-7 relative noise that depends on the NumPy
+    version's promotion rules; they are cubics at most, so 3-point Gauss-Legendre in double is exact)."""
+
+    def __init__(self, num_steps: int = 50, cond_scale: float = 1.0, order: int = 4, use_graph: bool = True):
+        super().__init__()
+        self.num_steps, self.cond_scale, self.order, self.use_graph = num_steps, cond_scale, order, use_graph
+
+    @staticmethod
+    def linear_multistep_coeff(order: int, t, i: int, j: int) -> float:
+        if order - 1 > i:
+            raise ValueError(f"Order {order} too high for step {i}")
+        a, b = float(t[i]), float(t[i + 1])
+        half, mid, acc = 0.5 * (b - a), 0.5 * (a + b), 0.0
+        for gx, gw in ((-0.7745966692414834, 5 / 9), (0.0, 8 / 9), (0.7745966692414834, 5 / 9)):
+            tau, prod = mid + half * gx, 1.0
+            for k in range(order):
+                if k != j:
+                    prod *= (tau - float(t[i - k])) / (float(t[i - j]) - float(t[i - k]))
+            acc += gw * prod
+        return acc * half
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_LMS, int(self.num_steps)
+        d.s_tmin = d.s_tmax = d.s_churn = 0.0
+        d.s_noise = 1.0
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, int(self.order), sigma_data, int(self.use_graph)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
+        if not 1 <= self.order <= 4:
+            raise ValueError("LMSSampler: order must be 1..4")
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
+        # ---- interface-compatibility branch --------------------------------------------------------
+        t = sigmas.detach().cpu().numpy()
+        x = sigmas[0] * noise
+        ds = []
+        for i in range(self.num_steps - 1):
+            d = (x - fn(x, net=net, sigma=sigmas[i], inference=True, cond_scale=self.cond_scale, **kwargs)) / sigmas[i]
+            ds = (ds + [d])[-self.order:]
+            cur = min(i + 1, self.order)
+            coeffs = [self.linear_multistep_coeff(cur, t, i, j) for j in range(cur)]
+            x = x + sum(c * dd for c, dd in zip(coeffs, reversed(ds)))
         return x.clamp(-1.0, 1.0)
 
 

@@ -58,6 +58,8 @@ typedef struct adf_net_config {
 #define ADF_SAMPLER_DPM_MULTISTEP 2 /* DPMSampler(multisteps=True, x0_pred=True, log_time_spacing=False) */
 #define ADF_SAMPLER_DPM2 3      /* DPM2Sampler ("DPM2 Karras", optional churn)   sampler_edm.py:401-493 */
 #define ADF_SAMPLER_ADPM2 4     /* ADPM2Sampler ("DPM2 a Karras", ancestral)     stochastic_sampler_edm.py:35-100 */
+#define ADF_SAMPLER_LMS 5       /* LMSSampler ("LMS Karras"), order 1..4         sampler_edm.py:1134-1190 */
+#define ADF_SAMPLER_DPM_SINGLESTEP 6 /* DPMSampler(multisteps=False, x0_pred=True) sampler_edm.py:568-622, :769-805 */
 
 typedef struct adf_sampler_desc {
     int32_t kind;
@@ -65,10 +67,11 @@ typedef struct adf_sampler_desc {
     float s_tmin, s_tmax, s_churn, s_noise;  /* EDM */
     int32_t use_heun;    /* EDM, EDM_ALPHA */
     float alpha;         /* EDM_ALPHA */
-    int32_t order;       /* DPM: 1..3 */
+    int32_t order;       /* DPM: 1..3; LMS: 1..4 */
     float sigma_data;    /* EluDiffusion.sigma_data */
     int32_t use_graph;   /* capture the whole step loop into one hipGraph and replay it */
     float rho, eta;      /* ADPM2 */
+    int32_t log_time_spacing;  /* DPM (both kinds): the reference's log_time_spacing flag (sampler_edm.py:518, :546-556) */
 } adf_sampler_desc;
 
 typedef struct adf_handle adf_handle;

@@ -44,11 +44,11 @@ def import_reference():
     from src.models.components.diffusion import EluDiffusion
     from src.models.components.sampler_edm import EDMSampler, EDMAlphaSampler, DPMSampler
     from src.models.components.scheduler import KarrasSchedule
-    from src.models.components.sampler_edm import DPM2Sampler
+    from src.models.components.sampler_edm import DPM2Sampler, LMSSampler
     from src.models.components.stochastic_sampler_edm import ADPM2Sampler
     return dict(UNet1dBase=UNet1dBase, EluDiffusion=EluDiffusion, EDMSampler=EDMSampler,
                 EDMAlphaSampler=EDMAlphaSampler, DPMSampler=DPMSampler, KarrasSchedule=KarrasSchedule,
-                DPM2Sampler=DPM2Sampler, ADPM2Sampler=ADPM2Sampler)
+                DPM2Sampler=DPM2Sampler, ADPM2Sampler=ADPM2Sampler, LMSSampler=LMSSampler)
 
 
 def build_ref_net(ref, cfg, weights):
@@ -367,6 +367,28 @@ def main():
         assert inj.shape[0] == 9
     assert max(more.values()) < 5e-4, more
     report["dpm2_samplers"] = more
+
+    # ---- 9. LMS, single-step DPM-Solver, log-spaced multistep DPM-Solver (the rest of SURVEY.md 8f rank 2) ----
+    more = {}
+    with torch.no_grad():
+        for order in (4, 2):
+            y = ref["LMSSampler"](num_steps=10, order=order)(noise, fn=diff.denoise_fn, net=net, sigmas=sg)
+            yo = S.lms_sampler(noise, fn_o, sg, 10, order=order)
+            more[f"lms_o{order}"] = rel_err(yo, y); out[f"smp_lms10_o{order}_final"] = y.numpy()
+        for order, logsp, n in ((3, True, 10), (3, True, 9), (2, True, 7), (1, True, 4), (3, False, 10), (2, False, 10)):
+            tag = f"o{order}_{'log' if logsp else 'lin'}_n{n}"
+            sgn = E.karras_sigmas(0.002, 80.0, 7.0, n)
+            y = ref["DPMSampler"](1.0, order=order, num_steps=n, multisteps=False, x0_pred=True,
+                                  log_time_spacing=logsp)(noise, fn=diff.denoise_fn, net=net, sigmas=sgn)
+            yo = S.dpm_singlestep_sampler(noise, fn_o, sgn, n, order=order, log_time_spacing=logsp)
+            more[f"dpm_single_{tag}"] = rel_err(yo, y); out[f"smp_dpm_single_{tag}_final"] = y.numpy()
+        for order in (3, 2):
+            y = ref["DPMSampler"](1.0, order=order, num_steps=10, multisteps=True, x0_pred=True,
+                                  log_time_spacing=True)(noise, fn=diff.denoise_fn, net=net, sigmas=sg)
+            yo = S.dpm_multistep_sampler(noise, fn_o, sg, 10, order=order, log_time_spacing=True)
+            more[f"dpm_multi_log_o{order}"] = rel_err(yo, y); out[f"smp_dpm_multi_log_o{order}_final"] = y.numpy()
+    assert max(more.values()) < 5e-4, more
+    report["lms_dpm_single_samplers"] = more
 
     print(json.dumps(report, indent=1))
     if args.check_only:

@@ -63,31 +63,44 @@ def edm_alpha_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, n
     return x
 
 
+def _dpm_grid(sigmas: torch.Tensor, n_intervals: int, log_time_spacing: bool):
+    """DPMSampler.get_lambda / lambd / sigma / inv_lambd (sampler_edm.py:528-556).  Returns (grid, lam, sig, inv):
+    log spacing: the grid holds lambda = -log sigma, linspace over n_intervals + 1 points between the first and the
+    last sigma, lam = inv = identity, sig(l) = exp(-l); otherwise the grid IS the sigma list, lam(s) = -log s,
+    sig = identity, inv(l) = exp(-l)."""
+    if log_time_spacing:
+        grid = torch.linspace(-sigmas[0].log(), -sigmas[-1].log(), n_intervals + 1)
+        ident = lambda v: v
+        return grid, ident, (lambda l: l.neg().exp()), ident
+    return sigmas, (lambda s_: -s_.log()), (lambda v: v), (lambda l: l.neg().exp())
+
+
 def dpm_multistep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int,
-                          order: int = 3, trace: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
-    """sampler_edm.py:710-768 + :624-690, the shipped setting
-    (configs/experiment/sc09_inference/diffunet_complex_sc09_eval_dpm.yaml:57-64):
-    multisteps=True, x0_pred=True, log_time_spacing=False.  Then the "lambda" list is the sigma
-    list itself (:556), lambd(s) = -log s (:532), the loop makes num_steps-1 updates (:526)
-    and ends at sigmas[num_steps-1]; final clamp (:805)."""
-    steps = num_steps - 1
+                          order: int = 3, trace: Optional[List[torch.Tensor]] = None,
+                          log_time_spacing: bool = False) -> torch.Tensor:
+    """sampler_edm.py:710-768 + :624-690 with multisteps=True, x0_pred=True.  The shipped setting
+    (configs/experiment/sc09_inference/diffunet_complex_sc09_eval_dpm.yaml:57-64) has log_time_spacing=False: the
+    "lambda" list is the sigma list itself (:556), lambd(s) = -log s (:532), the loop makes num_steps-1 updates (:526)
+    and ends at sigmas[num_steps-1].  log_time_spacing=True: num_steps updates on a lambda grid that is linear between
+    the first and the last sigma (:549-552).  Final clamp (:805)."""
+    steps = num_steps if log_time_spacing else num_steps - 1
     assert steps >= order
-    lam = lambda s: -s.log()
+    grid, lam, sig, _ = _dpm_grid(sigmas, steps, log_time_spacing)
     x = sigmas[0] * noise
-    s_hist = [sigmas[0]]
-    m_hist = [fn(x, sigma=sigmas[0])]
+    s_hist = [grid[0]]
+    m_hist = [fn(x, sigma=sig(grid[0]))]
 
     def update(x, s_cur, ord_):
         s0 = s_hist[-1]
         h = lam(s_cur) - lam(s0)
         phi1 = torch.expm1(-h)
         if ord_ == 1:
-            return s_cur / s0 * x - phi1 * m_hist[-1]
+            return sig(s_cur) / sig(s0) * x - phi1 * m_hist[-1]
         if ord_ == 2:
             h1 = lam(s0) - lam(s_hist[-2])
             r0 = h1 / h
             d1 = (1.0 / r0) * (m_hist[-1] - m_hist[-2])
-            return s_cur / s0 * x - phi1 * m_hist[-1] - 0.5 * phi1 * d1
+            return sig(s_cur) / sig(s0) * x - phi1 * m_hist[-1] - 0.5 * phi1 * d1
         h1 = lam(s_hist[-2]) - lam(s_hist[-3])
         h0 = lam(s0) - lam(s_hist[-2])
         r0, r1 = h0 / h, h1 / h
@@ -97,19 +110,102 @@ def dpm_multistep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tenso
         d2 = (1.0 / (r0 + r1)) * (d10 - d11)
         phi2 = phi1 / h + 1.0
         phi3 = phi2 / h - 0.5
-        return s_cur / s0 * x - phi1 * m_hist[-1] + phi2 * d1 - phi3 * d2
+        return sig(s_cur) / sig(s0) * x - phi1 * m_hist[-1] + phi2 * d1 - phi3 * d2
 
     for step in range(1, steps + 1):
         ord_ = step if step < order else min(order, steps + 1 - step)
-        s_cur = sigmas[step]
+        s_cur = grid[step]
         x = update(x, s_cur, ord_)
         s_hist.append(s_cur)
         s_hist[:] = s_hist[-order:]
         if step < steps:
-            m_hist.append(fn(x, sigma=s_cur))
+            m_hist.append(fn(x, sigma=sig(s_cur)))
             m_hist[:] = m_hist[-order:]
         if trace is not None:
             trace.append(x.clone())
+    return x.clamp(-1.0, 1.0)
+
+
+def dpm_singlestep_orders(num_steps_eff: int, order: int) -> List[int]:
+    """sampler_edm.py:770-789: the orders of the single-step solver ("DPM-Solver-fast")."""
+    n = num_steps_eff
+    if order == 3:
+        k = n // 3 + 1
+        return [3] * (k - 2) + [2, 1] if n % 3 == 0 else [3] * (k - 1) + [n % 3]
+    if order == 2:
+        return [2] * (n // 2) if n % 2 == 0 else [2] * (n // 2) + [1]
+    if order == 1:
+        return [1] * n
+    raise ValueError("'order' must be '1' or '2' or '3'.")
+
+
+def dpm_singlestep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int, order: int = 3,
+                           log_time_spacing: bool = True) -> torch.Tensor:
+    """sampler_edm.py:769-805 (the multisteps=False branch) + :568-622 (dpm_solver_{1,2,3}_step), x0_pred=True.
+    Kept as written: (a) with log_time_spacing=False the grid is the full sigma list but only len(orders) intervals are
+    walked, so the run stops early (:791-795); (b) in that mode the intermediate points add a lambda-space step to a
+    SIGMA (`s1 = lambd_cur + r1 * h`, :584/:604) before inv_lambd; (c) the first evaluation of every interval is made
+    once and cached (:796).  num_steps_eff = num_steps (log spacing) or num_steps - 1 (:526)."""
+    n_eff = num_steps if log_time_spacing else num_steps - 1
+    orders = dpm_singlestep_orders(n_eff, order)
+    k = {3: n_eff // 3 + 1, 2: (n_eff + 1) // 2, 1: n_eff}[order]
+    grid, lam, sig, inv = _dpm_grid(sigmas, k, log_time_spacing)
+    x = sigmas[0] * noise
+    for i, o in enumerate(orders):
+        cur, nxt = grid[i], grid[i + 1]
+        h = lam(nxt) - lam(cur)
+        eps = fn(x, sigma=sig(cur))
+        if o == 1:
+            x = sig(nxt) / sig(cur) * x - torch.expm1(-h) * eps
+        elif o == 2:
+            r1 = 1 / 2
+            s1 = inv(cur + r1 * h)
+            u1 = sig(s1) / sig(cur) * x - torch.expm1(-r1 * h) * eps
+            eps_r1 = fn(u1, sigma=sig(s1))
+            x = sig(nxt) / sig(cur) * x - torch.expm1(-h) * eps - 1 / (2 * r1) * torch.expm1(-h) * (eps_r1 - eps)
+        else:
+            r1, r2 = 1 / 3, 2 / 3
+            s1 = inv(cur + r1 * h)
+            s2 = inv(cur + r2 * h)
+            u1 = sig(s1) / sig(cur) * x - (-r1 * h).expm1() * eps
+            eps_r1 = fn(u1, sigma=sig(s1))
+            u2 = sig(s2) / sig(cur) * x - (-r2 * h).expm1() * eps + (r2 / r1) * ((-r2 * h).expm1() / (r2 * h) + 1) * (eps_r1 - eps)
+            eps_r2 = fn(u2, sigma=sig(s2))
+            x = sig(nxt) / sig(cur) * x - torch.expm1(-h) * eps + 1 / r2 * (torch.expm1(-h) / h + 1) * (eps_r2 - eps)
+    return x.clamp(-1.0, 1.0)
+
+
+def lms_coeff(order: int, t, i: int, j: int) -> float:
+    """LMSSampler.linear_multistep_coeff (sampler_edm.py:1149-1160): integral over [t_i, t_{i+1}] of the Lagrange basis
+    polynomial of node t_{i-j} among t_i .. t_{i-order+1} (scipy quad, epsrel 1e-4, as in the reference)."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def basis(tau):
+        prod = 1.0
+        for k in range(order):
+            if j == k:
+                continue
+            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(basis, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+def lms_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int, order: int = 4) -> torch.Tensor:
+    """LMSSampler.forward (sampler_edm.py:1162-1190, 'LMS Karras'): num_steps-1 evaluations, derivative history of up to
+    `order` entries, coefficients from the fp32 sigma list on the host, final clamp."""
+    t = sigmas.detach().cpu().numpy()
+    x = sigmas[0] * noise
+    ds: List[torch.Tensor] = []
+    for i in range(num_steps - 1):
+        d = (x - fn(x, sigma=sigmas[i])) / sigmas[i]
+        ds.append(d)
+        if len(ds) > order:
+            ds.pop(0)
+        cur = min(i + 1, order)
+        coeffs = [lms_coeff(cur, t, i, j) for j in range(cur)]
+        x = x + sum(c * dd for c, dd in zip(coeffs, reversed(ds)))
     return x.clamp(-1.0, 1.0)
 
 

@@ -318,6 +318,40 @@ def test_dpm2_family_vs_reference_golden(golden, graph):
     assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_lms_and_dpm_variants_vs_reference_golden(golden, graph):
+    """LMSSampler (orders 4 and 2), single-step DPM-Solver (both spacings, every order pattern, including the early stop of
+    the sigma-grid mode) and the log-spaced multistep solver, against the reference's own results."""
+    net, _ = make_net(A.config_tiny(), "fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    noise = generate_noise(70, 2, 256).cuda()
+    sched = lambda n: A.KarrasSchedule(0.002, 80.0, 7.0, n)()
+    cases = [(A.LMSSampler(num_steps=10, order=o, use_graph=graph), 10, f"smp_lms10_o{o}_final") for o in (4, 2)]
+    for order, logsp, n in ((3, True, 10), (3, True, 9), (2, True, 7), (1, True, 4), (3, False, 10), (2, False, 10)):
+        cases.append((A.DPMSampler(1.0, order=order, num_steps=n, multisteps=False, log_time_spacing=logsp, use_graph=graph), n,
+                      f"smp_dpm_single_o{order}_{'log' if logsp else 'lin'}_n{n}_final"))
+    for order in (3, 2):
+        cases.append((A.DPMSampler(1.0, order=order, num_steps=10, multisteps=True, log_time_spacing=True, use_graph=graph), 10,
+                      f"smp_dpm_multi_log_o{order}_final"))
+    for smp, n, key in cases:
+        for _ in range(2):
+            y = smp(noise, fn=d.denoise_fn, net=net, sigmas=sched(n))
+            assert rel_err(y.cpu(), T(golden[key])) < FP32_TOL, key
+
+
+def test_new_sampler_nfe_counts():
+    lib = A._lib.load_library()
+    import ctypes as C
+    def nfe(smp, n):
+        sig = A.KarrasSchedule(0.002, 80.0, 7.0, n)().numpy()
+        desc = smp._desc(0.2)
+        return lib.adf_sampler_nfe(C.byref(desc), sig.ctypes.data_as(C.POINTER(C.c_float)), len(sig))
+    assert nfe(A.LMSSampler(num_steps=10, order=4), 10) == 9
+    assert nfe(A.DPMSampler(1.0, order=3, num_steps=10, multisteps=False, log_time_spacing=True), 10) == 10
+    assert nfe(A.DPMSampler(1.0, order=3, num_steps=10, multisteps=False, log_time_spacing=False), 10) == 9
+    assert nfe(A.DPMSampler(1.0, order=3, num_steps=10, multisteps=True, log_time_spacing=True), 10) == 10
+
+
 # ---- shape sweep: odd batches / other lengths through whatever routes the launcher picks ---------------------------
 @pytest.mark.parametrize("B,L", [(1, 16384), (3, 4096), (5, 2048), (96, 1024), (33, 3072)])
 def test_config2_shape_sweep_vs_oracle(B, L):

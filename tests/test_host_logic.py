@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AdfNetConfig) == 4 * (9 + 13 + 12 * 3 + 4 + 2 + 1)
-    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 13
+    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 14
 
 
 def test_sampler_nfe_via_abi():
@@ -149,7 +149,49 @@ def test_samplers_compat_branch_mock(golden):
     y = A.DPMSampler(1.0, order=3, num_steps=50, multisteps=True, x0_pred=True, log_time_spacing=False)(noise, fn=mock, net=None, sigmas=s50)
     assert rel(y, T(golden["smp_dpm50_tiny_mock_final"])) < 1e-6
     with pytest.raises(NotImplementedError):
-        A.DPMSampler(1.0, order=3, num_steps=50, multisteps=False)(noise, fn=mock, net=None, sigmas=s50)
+        A.DPMSampler(1.0, order=3, num_steps=50, multisteps=False, x0_pred=False)(noise, fn=mock, net=None, sigmas=s50)
+
+
+def test_lms_and_dpm_variants_compat_branch(golden):
+    """The tensor-op branches of LMSSampler / DPMSampler (foreign denoiser callable) against the reference's results."""
+    from oracle import edm as E
+    cfg = A.config_tiny()
+    den = E.make_denoiser(generate_weights(cfg, seed=0), cfg, 0.2)
+    fn = lambda x, net=None, sigma=None, **kw: den(x, sigma=sigma)
+    noise = generate_noise(70, 2, 256)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 10)()
+    with torch.no_grad():
+        for order in (4, 2):
+            y = A.LMSSampler(num_steps=10, order=order)(noise, fn=fn, net=None, sigmas=sig)
+            assert rel(y, T(golden[f"smp_lms10_o{order}_final"])) < 5e-4
+        for order, logsp, n in ((3, True, 10), (3, True, 9), (2, True, 7), (1, True, 4), (3, False, 10), (2, False, 10)):
+            tag = f"o{order}_{'log' if logsp else 'lin'}_n{n}"
+            smp = A.DPMSampler(1.0, order=order, num_steps=n, multisteps=False, log_time_spacing=logsp)
+            y = smp(noise, fn=fn, net=None, sigmas=A.KarrasSchedule(0.002, 80.0, 7.0, n)())
+            assert rel(y, T(golden[f"smp_dpm_single_{tag}_final"])) < 5e-4, tag
+        for order in (3, 2):
+            y = A.DPMSampler(1.0, order=order, num_steps=10, multisteps=True, log_time_spacing=True)(noise, fn=fn, net=None, sigmas=sig)
+            assert rel(y, T(golden[f"smp_dpm_multi_log_o{order}_final"])) < 5e-4
+
+
+def test_lms_coefficients_match_scipy_quad():
+    """The exact Gauss-Legendre integrals against the reference's scipy quad call (sampler_edm.py:1149-1160), which runs
+    on fp32 NumPy scalars (under NumPy 2 promotion the whole basis polynomial is evaluated in fp32): agreement to fp32 noise."""
+    from oracle import samplers as S
+    t = A.KarrasSchedule(0.002, 80.0, 7.0, 12)().numpy()
+    for i in range(11):
+        cur = min(i + 1, 4)
+        for j in range(cur):
+            assert abs(A.LMSSampler.linear_multistep_coeff(cur, t, i, j) - S.lms_coeff(cur, t, i, j)) <= 5e-7 * max(1.0, abs(S.lms_coeff(cur, t, i, j)))
+    with pytest.raises(ValueError):
+        A.LMSSampler.linear_multistep_coeff(3, t, 1, 0)
+
+
+def test_dpm_nfe_counts():
+    assert A.DPMSampler(1.0, order=3, num_steps=50, multisteps=True, log_time_spacing=False).nfe() == 49
+    assert A.DPMSampler(1.0, order=3, num_steps=10, multisteps=False, log_time_spacing=True).nfe() == 10
+    assert A.DPMSampler(1.0, order=3, num_steps=10, multisteps=False, log_time_spacing=False).nfe() == 9
+    assert A.DPMSampler(1.0, order=2, num_steps=7, multisteps=False, log_time_spacing=True).nfe() == 7
 
 
 def test_sampler_kwargs_forwarded_to_fn():

@@ -214,3 +214,35 @@ def test_dpm2_family_with_tiny_net(golden):
         for rho, eta, tag in ((1.0, 1.0, "r1"), (7.0, 0.6, "r7")):
             y = S.adpm2_sampler(noise, fn, sig, 10, rho=rho, eta=eta, injected_noise=recorded_draws(9300, 9, noise.shape))
             assert rel(y, T(golden[f"smp_adpm2_{tag}_final"])) < 5e-4, tag
+
+
+LMS_DPM_CASES = [(3, True, 10), (3, True, 9), (2, True, 7), (1, True, 4), (3, False, 10), (2, False, 10)]
+
+
+def test_lms_and_dpm_variants_with_tiny_net(golden):
+    """LMSSampler, single-step DPM-Solver (both spacings, every order pattern) and the log-spaced multistep solver
+    against the reference's results (fixtures of oracle/gen_golden.py section 9)."""
+    cfg = config_tiny()
+    fn = E.make_denoiser(generate_weights(cfg, seed=0), cfg, 0.2)
+    noise = generate_noise(70, 2, 256)
+    sig = E.karras_sigmas(0.002, 80.0, 7.0, 10)
+    with torch.no_grad():
+        for order in (4, 2):
+            assert rel(S.lms_sampler(noise, fn, sig, 10, order=order), T(golden[f"smp_lms10_o{order}_final"])) < 5e-4
+        for order, logsp, n in LMS_DPM_CASES:
+            tag = f"o{order}_{'log' if logsp else 'lin'}_n{n}"
+            y = S.dpm_singlestep_sampler(noise, fn, E.karras_sigmas(0.002, 80.0, 7.0, n), n, order=order, log_time_spacing=logsp)
+            assert rel(y, T(golden[f"smp_dpm_single_{tag}_final"])) < 5e-4, tag
+        for order in (3, 2):
+            y = S.dpm_multistep_sampler(noise, fn, sig, 10, order=order, log_time_spacing=True)
+            assert rel(y, T(golden[f"smp_dpm_multi_log_o{order}_final"])) < 5e-4
+
+
+def test_singlestep_order_patterns():
+    """sampler_edm.py:770-789."""
+    assert S.dpm_singlestep_orders(10, 3) == [3, 3, 3, 1]
+    assert S.dpm_singlestep_orders(9, 3) == [3, 3, 2, 1]
+    assert S.dpm_singlestep_orders(7, 2) == [2, 2, 2, 1]
+    assert S.dpm_singlestep_orders(4, 1) == [1, 1, 1, 1]
+    with pytest.raises(ValueError):
+        S.dpm_singlestep_orders(4, 4)
