@@ -542,30 +542,53 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         if (++nbk == nb) { nbk = 0; ++nt; }
         return desc(nt < ntiles ? nt : ntiles - 1, nbk);     // past the end: a valid but unused descriptor
     };
-    PpBlk dc = desc(0, 0);
-    PpBlk d1 = next_desc();
-    PpBlk d2 = next_desc();
-    (void)issue_a(dc, 0, -1);
-    if (GB > 1) (void)issue_a(d1, 1, -1);
-    issue_w(dc.w, 0);
-    // ---- bias vector and the first tile's affine table -> LDS with ordinary loads, issued while the first DMAs fly
-    // (their latency and the DMA latency overlap; the compiler's waits for these loads also cover the older DMAs)
-    for (int n = tid; n < a.n_pad; n += 512) {
+#ifdef ADF_PP_STAMP
+    auto pstamp = [&](int id) __attribute__((always_inline)) {
+        if (bidx == 0 && a.nseg == 1 && a.n_pad <= 128) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) ((unsigned long long*)(smem + kPpOffBias + 512))[wave * 24 + id] = t;
+        }
+    };
+#else
+    auto pstamp = [&](int) __attribute__((always_inline)) {};
+#endif
+    pstamp(17);
+    // bias vector and the first tile's affine table: their global loads go out first (one HBM round trip, ~3 us on a cold
+    // line, that gates the block's first barrier), then the descriptors and the first DMAs, then the LDS stores
+    float bias_v[(kPpMaxN + 511) / 512];
+#pragma unroll
+    for (int q = 0; q < (kPpMaxN + 511) / 512; ++q) {
+        const int n = tid + q * 512;
         float bv = 0.f;
         if (n < a.n) {
             const int bi = n % a.bias_mod;
             if (a.bias0) bv += a.bias0[bi];
             if (a.bias1) bv += a.bias1[bi];
         }
-        ldsBias[n] = bv;
+        bias_v[q] = bv;
     }
-    if (use_tab) {
+    f32x4_t tab_v = {0.f, 0.f, 0.f, 0.f};
+    if (use_tab && tid * 2 < ctot0) {
         int b0, m0, n0;
         geom(0, b0, m0, n0);
-        if (tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b0 * ctot0 + tid * 2) * 2);
+        tab_v = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b0 * ctot0 + tid * 2) * 2);
     }
+    PpBlk dc = desc(0, 0);
+    (void)issue_a(dc, 0, -1);
+    issue_w(dc.w, 0);
+    PpBlk d1 = next_desc();
+    if (GB > 1) (void)issue_a(d1, 1, -1);
+    PpBlk d2 = next_desc();
+    pstamp(18);
+#pragma unroll
+    for (int q = 0; q < (kPpMaxN + 511) / 512; ++q)
+        if (tid + q * 512 < a.n_pad) ldsBias[tid + q * 512] = bias_v[q];
+    if (use_tab && tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = tab_v;
+    pstamp(19);
     wait_dma(0);
+    pstamp(20);
     __syncthreads();
+    pstamp(21);
     {
         int b0, m0, n0;
         geom(0, b0, m0, n0);
@@ -580,7 +603,9 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_r[j];
     }
     transform(dc, 0, part_all);
+    pstamp(22);
     lds_barrier();
+    pstamp(23);
 
     int stA = 0, stW = 0;
     // the two waves of a SIMD run their own copy of the loop (EARLY decides where the prologue elements sit among the

@@ -32,6 +32,12 @@ fn.restype = C.c_int
 print("copy rc", fn(buf))
 names = {0: "start", 1: "S0 early-tr", 2: "S0 mfma", 3: "S0 late-tr", 4: "S0 dma", 5: "S0 bar", 6: "S1 early-tr", 7: "S1 mfma",
          8: "S1 late-tr", 9: "S1 dma", 10: "S1 bar", 11: "S2 early-tr", 12: "S2 mfma", 13: "S2 late-tr", 14: "S2 dma", 15: "S2 bar", 16: "desc"}
+pro = {17: "entry", 18: "dma issued", 19: "bias/tab ld", 20: "dma landed", 21: "syncthreads", 22: "transform", 23: "barrier"}
+p0 = min(buf[w * 32 + 17] for w in range(8))
+print("kernel prologue (cycles from the first wave's entry)")
+for i in sorted(pro):
+    print("%-12s" % pro[i] + "".join("%8d" % (buf[w * 32 + i] - p0) for w in range(8)))
+print("K block nb+1 starts at", min(buf[w * 32] for w in range(8)) - p0)
 t0 = min(buf[w * 32] for w in range(8))
 print("%-12s" % "point" + "".join("%8s" % ("w%d" % w) for w in range(8)))
 for i in sorted(names):
