@@ -65,6 +65,69 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
     return q;
 }
 
+// GroupNorm(+FiLM) folded to a per-(sample, channel) affine y = A*x + Bc of the (possibly concatenated) input
+// [src0 ; scale1*src1]: statistics [B][G][2] (sum, sumsq in fp64) per source tensor, gamma / beta, optional FiLM
+// (scale + 1, shift) with an optional second addend.  Shared by gn_finalize_kernel, gn_norm_apply_kernel and the GEMM
+// kernels that derive their affine table themselves.
+struct GnFinalizeArgs {
+    const double* stats0; const double* stats1;  // [B][G][2] per source tensor
+    int c0, c1, L, G, B;
+    float scale1, eps;
+    const float* gamma; const float* beta;        // [c0+c1]
+    const float* film; int film_bstride;           // film[b*bstride + c] = scale, film[b*bstride + ctot + c] = shift
+    const float* film2; int film2_bstride;         // optional second addend (class-embedding part of the projection)
+    float* ab;                                     // [B][c0+c1][2] (gn_finalize only)
+};
+// FAST (bf16 throughput mode, inside a GEMM kernel's start-up path): no fp64 division / square root -- the variance is still
+// formed in fp64 (cancellation), the reciprocal square root in fp32 with one Newton step (~1e-7 relative).
+template <bool FAST = false>
+__device__ __forceinline__ void gn_affine(const GnFinalizeArgs& a, int b, int c, float& A, float& Bc) {
+    const int ctot = a.c0 + a.c1;
+    const int gs = ctot / a.G;
+    const int cstart = (c / gs) * gs;
+    const bool s1 = cstart >= a.c0;
+    const double* st = s1 ? a.stats1 : a.stats0;
+    const int csrc = s1 ? a.c1 : a.c0;
+    const int lc = s1 ? cstart - a.c0 : cstart;
+    const int fg = csrc / a.G;                // channels per stored (fine) group
+    const int g0 = lc / fg, g1 = (lc + gs + fg - 1) / fg;
+    double sum = 0.0, sq = 0.0;
+    for (int g = g0; g < g1; ++g) { sum += st[((size_t)b * a.G + g) * 2]; sq += st[((size_t)b * a.G + g) * 2 + 1]; }
+    const double sc = s1 ? (double)a.scale1 : 1.0;
+    sum *= sc; sq *= sc * sc;
+    float rstd, meanf;
+    if constexpr (FAST) {
+        const double inv_cnt = (double)(1.0f / ((float)a.L * (float)gs));     // L * gs is a small power-of-two multiple: exact in fp32 for the shapes served
+        const double mean = sum * inv_cnt;
+        double var = sq * inv_cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float vf = (float)var + a.eps;
+        float r = __builtin_amdgcn_rsqf(vf);
+        r = r * (1.5f - 0.5f * vf * r * r);
+        rstd = r; meanf = (float)mean;
+    } else {
+        const double cnt = (double)a.L * (double)gs;
+        const double mean = sum / cnt;
+        double var = sq / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        meanf = (float)mean;
+    }
+    A = rstd * a.gamma[c];
+    Bc = a.beta[c] - meanf * A;
+    if (a.film) {
+        float fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
+        float fh = a.film[(size_t)b * a.film_bstride + ctot + c];
+        if (a.film2) {      // class-embedding part of the FiLM projection (precomputed per sampler run)
+            fs += a.film2[(size_t)b * a.film2_bstride + c];
+            fh += a.film2[(size_t)b * a.film2_bstride + ctot + c];
+        }
+        A *= fs;
+        Bc = fmaf(Bc, fs, fh);
+    }
+    if (s1) A *= a.scale1;
+}
+
 // SiLU = v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): 5 VALU ops, 2 of them transcendental
 __device__ __forceinline__ float silu_f(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));

@@ -37,6 +37,8 @@ struct GemmSeg {
     const void* src1;   // optional second source, concatenated along channels
     int c0, c1;
     const float* ab;    // [B][c0+c1][2] fused affine, or nullptr = raw input
+    GnFinalizeArgs gn;  // gn.gamma != nullptr: `ab` (= gn.ab) has NOT been computed yet.  launch_conv_gemm either lets the
+                        // kernel derive the table from the statistics itself (DMA kernel) or launches gn_finalize first.
     float scale1;       // raw input: multiplier of source 1 (skip scale)
     int act;            // 1 = SiLU after the affine
     int taps, stride, off0, step;
@@ -48,6 +50,7 @@ struct GemmArgs {
     GemmSeg seg[2];
     int nseg;
     int B, lin, mrows, n, n_pad;
+    int gn_ready;        // replay of a recorded launch: the `ab` tables are already filled, do not launch gn_finalize again
     int flat;            // set by the launcher: tiles run over the flattened B*mrows rows
     int seg_rows;        // set by the launcher: rows of one sample inside a tile (flat mode)
     const float* bias0;

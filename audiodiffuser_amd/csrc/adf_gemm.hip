@@ -1,6 +1,7 @@
 // Tile-shape dispatch for the fused implicit-GEMM kernel (see adf_gemm.h).
 #include "adf_gemm.h"
 #include "adf_gemm_pp.h"
+#include "adf_kernels.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -188,6 +189,22 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
     if (a.n % epc || a.out_c % epc) return "conv_gemm: output channels must be a multiple of a 16-byte chunk";
     const long long esz = dtype_bf16 ? 2 : 4;
     if ((long long)a.B * a.out_rows * a.out_c * esz >= (1LL << 32)) return "conv_gemm: output tensor must be < 4 GiB";
+    // GroupNorm affine of segment 0 still to be derived from the statistics: the DMA kernel does it itself (one launch
+    // less per GroupNorm: 4.7 us each, 44 per network pass before), every other route gets gn_finalize launched here
+    const bool gn_pending = a.seg[0].gn.gamma != nullptr;
+    static int gn_in_kernel = -1;     // ADF_GEMM_GN=0: always launch gn_finalize (A/B)
+    if (gn_in_kernel < 0) { const char* e = getenv("ADF_GEMM_GN"); gn_in_kernel = e ? atoi(e) : 1; }
+    auto settle_gn = [&](bool in_kernel) -> const char* {
+        if (!gn_pending) return nullptr;
+        in_kernel = in_kernel && gn_in_kernel;
+        const char* err = nullptr;
+        if (!in_kernel) {
+            if (!a.gn_ready) err = launch_gn_finalize(a.seg[0].gn, stream);
+            a.seg[0].gn.gamma = nullptr;
+        }
+        return err;
+    };
+    if (a.nseg > 1) a.seg[1].gn.gamma = nullptr;
     bool raw = true;
     for (int s = 0; s < a.nseg; ++s) {
         const GemmSeg& g = a.seg[s];
@@ -277,6 +294,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                 a.stats = ok ? a_in.stats : nullptr;
                 if (stats_fused) *stats_fused = ok;
             }
+            if (const char* e = settle_gn(false)) return e;
             trace_route("ksplit", a, tile, tile);
             if (big) return dtype_bf16 ? launch_ksplit<bf16_t, 2, 2>(a, stream) : launch_ksplit<float, 2, 2>(a, stream);
             return dtype_bf16 ? launch_ksplit<bf16_t, 1, 1>(a, stream) : launch_ksplit<float, 1, 1>(a, stream);
@@ -318,6 +336,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                     a.nseg = 2;
                     a.res = nullptr;
                 }
+                if (const char* e = settle_gn(a.seg[0].taps == 3)) return e;
                 trace_route("pp", a, ptm, 128);
                 return ptm == 256 ? launch_pp<2>(a, stream) : launch_pp<1>(a, stream);
             }
@@ -345,6 +364,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                     a.stats = ok ? a_in.stats : nullptr;
                     if (stats_fused) *stats_fused = ok;
                 }
+                if (const char* e = settle_gn(false)) return e;
                 trace_route("ws", a, 128, wtn);
                 if (wtn == 128) return dtype_bf16 ? launch_ws_variant<bf16_t, 2, 2>(a, stream) : launch_ws_variant<float, 2, 2>(a, stream);
                 return dtype_bf16 ? launch_ws_variant<bf16_t, 1, 2>(a, stream) : launch_ws_variant<float, 1, 2>(a, stream);
@@ -353,6 +373,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             // the weights through an LDS-DMA ring beside the producer / consumer waves measured 1 % slower end to end
         }
     }
+    if (const char* e = settle_gn(false)) return e;
     trace_route("plain", a, tm, tn);
     return dtype_bf16 ? dispatch<bf16_t>(a, tm, tn, stream) : dispatch<float>(a, tm, tn, stream);
 }

@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const int nb1 = a.nseg > 1 ? (a.seg[1].c0 + a.seg[1].c1) >> 6 : 0;
     const int nb = nb0 + nb1;                                                // K blocks per tile
     const int GB = ntiles * nb;                                              // K blocks of this thread block
-    const bool use_tab = a.seg[0].ab != nullptr;
+    const bool gn_in = a.seg[0].gn.gamma != nullptr;                         // the affine table is derived here from the GroupNorm statistics
+    const bool use_tab = a.seg[0].ab != nullptr || gn_in;
     const unsigned slab = (unsigned)a.n_pad * (unsigned)kRowBytes;           // one tap of packed weights
 
     auto geom = [&](int tseq, int& b0, int& m0, int& n0) __attribute__((always_inline)) {
@@ -139,6 +140,17 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         n0 = (t & ((1 << tn_shift) - 1)) * kPpTN;
         b0 = tml >> tm_shift;
         m0 = (tml & ((1 << tm_shift) - 1)) * TM;
+    };
+    int b_first;
+    { int m0_, n0_; geom(0, b_first, m0_, n0_); }
+    // (a, b) of one sample's input channels -> table slot: two channels per thread, the arithmetic of gn_finalize_kernel
+    auto fill_table = [&](int b, int slot) __attribute__((always_inline)) {
+        if (tid * 2 < ctot0) {
+            float A0, B0, A1, B1;
+            gn_affine<true>(a.seg[0].gn, b, tid * 2, A0, B0);
+            gn_affine<true>(a.seg[0].gn, b, tid * 2 + 1, A1, B1);
+            *(f32x4_t*)(ldsTab + slot * kPpTab + tid * 16) = f32x4_t{A0, B0, A1, B1};
+        }
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) {
         if (dbg & 128) return;
@@ -169,7 +181,8 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         d.rowbase = (unsigned)(b0 * a.lin);
         d.p_lo = m0 + sg.off0;
         d.taps = sg.taps;
-        d.tabofs = (!s1 && use_tab) ? (tseq & 1) * kPpTab + cbase * 8 : -1;
+        // table slot: alternates per tile (DMA of a precomputed table) or per sample (derived in the kernel)
+        d.tabofs = (!s1 && use_tab) ? ((gn_in ? b0 - b_first : tseq) & 1) * kPpTab + cbase * 8 : -1;
         d.act = sg.act;
         d.scale = from1 ? sg.scale1 : 1.0f;
         d.tseq = tseq;
@@ -210,7 +223,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 if (lane < 16) pp_dma16(base + (unsigned)TM * d.rowbytes, vh, (unsigned)(st * kPpAStage) + (unsigned)HP * 1024u);
                 n += 1;
             }
-            if (use_tab && d.last && d.tseq + 1 < ntiles && (unsigned)wave * 1024u < (unsigned)ctot0 * 8u) {
+            if (use_tab && !gn_in && d.last && d.tseq + 1 < ntiles && (unsigned)wave * 1024u < (unsigned)ctot0 * 8u) {
                 int b0, m0, n0;
                 geom(d.tseq + 1, b0, m0, n0);
                 const unsigned boff = (unsigned)wave * 1024u + lane_lds;
@@ -568,11 +581,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         bias_v[q] = bv;
     }
     f32x4_t tab_v = {0.f, 0.f, 0.f, 0.f};
-    if (use_tab && tid * 2 < ctot0) {
-        int b0, m0, n0;
-        geom(0, b0, m0, n0);
-        tab_v = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b0 * ctot0 + tid * 2) * 2);
-    }
+    if (use_tab && !gn_in && tid * 2 < ctot0) tab_v = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b_first * ctot0 + tid * 2) * 2);
     PpBlk dc = desc(0, 0);
     (void)issue_a(dc, 0, -1);
     issue_w(dc.w, 0);
@@ -583,7 +592,8 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
     for (int q = 0; q < (kPpMaxN + 511) / 512; ++q)
         if (tid + q * 512 < a.n_pad) ldsBias[tid + q * 512] = bias_v[q];
-    if (use_tab && tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = tab_v;
+    if (gn_in) fill_table(b_first, 0);
+    else if (use_tab && tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = tab_v;
     pstamp(19);
     wait_dma(0);
     pstamp(20);
@@ -681,6 +691,12 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
             stamp(8);
             wait_dma(0);
             stamp(9);
+            if (gn_in && (g % nb) == 0 && dc.tseq + 1 < ntiles) {            // first block of a tile: the next tile's sample
+                int bc, bn, m0_, n0_;
+                geom(dc.tseq, bc, m0_, n0_);
+                geom(dc.tseq + 1, bn, m0_, n0_);
+                if (bn != bc) fill_table(bn, (bn - b_first) & 1);           // nothing else is in flight here (vmcnt drained)
+            }
             stW ^= 1;
             lds_barrier();
             stamp(10);

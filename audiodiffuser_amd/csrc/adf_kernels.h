@@ -11,15 +11,7 @@ const char* launch_gn_stats(const void* x, int bf16, int B, int L, int C, int G,
 
 // Fold GroupNorm (+ optional FiLM scale/shift) into a per-(sample, channel) affine y = a*x + b
 // for a (possibly concatenated) input [src0 (c0) ; scale1 * src1 (c1)].
-struct GnFinalizeArgs {
-    const double* stats0; const double* stats1;  // [B][G][2] per source tensor
-    int c0, c1, L, G, B;
-    float scale1, eps;
-    const float* gamma; const float* beta;        // [c0+c1]
-    const float* film; int film_bstride;           // film[b*bstride + c] = scale, film[b*bstride + ctot + c] = shift
-    const float* film2; int film2_bstride;         // optional second addend (class-embedding part of the projection)
-    float* ab;                                     // [B][c0+c1][2]
-};
+// GnFinalizeArgs: adf_common.h
 const char* launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
 
 // out[b][l][c0+c1] = act(a*x + b) of the concatenated input [src0 ; src1] (affine from launch_gn_finalize).

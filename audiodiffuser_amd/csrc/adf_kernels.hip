@@ -72,40 +72,9 @@ const char* launch_gn_stats(const void* x, int bf16, int B, int L, int C, int G,
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a) {
     const int b = blockIdx.x;
     const int ctot = a.c0 + a.c1;
-    const int gs = ctot / a.G;
     for (int c = threadIdx.x; c < ctot; c += 256) {
-        const int j = c / gs;
-        const int cstart = j * gs;
-        const bool s1 = cstart >= a.c0;
-        const double* st = s1 ? a.stats1 : a.stats0;
-        const int csrc = s1 ? a.c1 : a.c0;
-        const int lc = s1 ? cstart - a.c0 : cstart;
-        const int fg = csrc / a.G;                // channels per stored (fine) group
-        const int g0 = lc / fg, g1 = (lc + gs + fg - 1) / fg;
-        double sum = 0.0, sq = 0.0;
-        for (int g = g0; g < g1; ++g) { sum += st[((size_t)b * a.G + g) * 2]; sq += st[((size_t)b * a.G + g) * 2 + 1]; }
-        const double sc = s1 ? (double)a.scale1 : 1.0;
-        sum *= sc; sq *= sc * sc;
-        const double cnt = (double)a.L * (double)gs;
-        const double mean = sum / cnt;
-        double var = sq / cnt - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        const float meanf = (float)mean;
-        const float gam = a.gamma[c], bet = a.beta[c];
-        float A = rstd * gam;
-        float Bc = bet - meanf * A;
-        if (a.film) {
-            float fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
-            float fh = a.film[(size_t)b * a.film_bstride + ctot + c];
-            if (a.film2) {      // class-embedding part of the FiLM projection (precomputed per sampler run)
-                fs += a.film2[(size_t)b * a.film2_bstride + c];
-                fh += a.film2[(size_t)b * a.film2_bstride + ctot + c];
-            }
-            A *= fs;
-            Bc = fmaf(Bc, fs, fh);
-        }
-        if (s1) A *= a.scale1;
+        float A, Bc;
+        gn_affine(a, b, c, A, Bc);
         float* o = a.ab + ((size_t)b * ctot + c) * 2;
         o[0] = A; o[1] = Bc;
     }
