@@ -85,13 +85,12 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
     }
     constexpr int TM = 128 * MT;
     const int tiles_m = a.mrows / TM, tiles_n = a.n_pad / kPpTN;
-    int tm_shift = 0, tn_shift = 0;
+    int tm_shift = 0;
     while ((1 << tm_shift) < tiles_m) ++tm_shift;
-    while ((1 << tn_shift) < tiles_n) ++tn_shift;
     const long long tiles_total = (long long)a.B * tiles_m * tiles_n;
-    if (tiles_total <= 0 || tiles_total > 0x7fffffffLL) return "conv_gemm_pp: bad tile count";
+    if (tiles_total <= 0 || tiles_total > (1 << 22)) return "conv_gemm_pp: bad tile count";
     const long long grid = tiles_total < num_cu ? tiles_total : num_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kPpLds, stream, a, (int)tiles_total, tm_shift, tn_shift);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kPpLds, stream, a, (int)tiles_total, tm_shift, tiles_n);
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_pp: launch failed";
 }
 
@@ -99,9 +98,9 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
 // second segment
 bool pp_eligible(const GemmArgs& a, int tm) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (a.scatter_f || a.gelu || a.mrows % tm || a.lin != a.mrows || a.out_rows != a.mrows) return false;
+    if (a.scatter_f || a.mrows % tm || a.lin != a.mrows || a.out_rows != a.mrows) return false;
     if (a.n != a.n_pad || a.out_c != a.n || a.n_pad % kPpTN || a.n_pad > kPpMaxN) return false;
-    if (!pow2(a.mrows / tm) || !pow2(a.n_pad / kPpTN)) return false;
+    if (!pow2(a.mrows / tm)) return false;
     if (a.res && a.nseg > 1) return false;
     int nb = a.res ? a.n / 64 : 0;
     for (int s = 0; s < a.nseg; ++s) {
@@ -278,7 +277,9 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             if ((32 / ks_seg) * ((ks_seg - 1) + g.taps) > ks_a_rows(1)) ks_ok = false;
             nit_total += g.nchunk;
         }
-        if (ks_ok && nit_total >= 4) {
+        static int ks_minit = -1;           // ADF_GEMM_KSPLIT_MINIT: fewest 64-channel K chunks (all segments) for which K is split over the waves
+        if (ks_minit < 0) { const char* e = getenv("ADF_GEMM_KSPLIT_MINIT"); ks_minit = e ? atoi(e) : 4; }
+        if (ks_ok && nit_total >= ks_minit) {
             // 64 x 64 tiles when they still give >= 128 blocks: every tile row re-reads all weights and every tile column
             // all activations (from L2), so the bytes a CU pulls halve against 32 x 32 (ADF_GEMM_KSPLIT=32 forces the small tile)
             const bool big = use_ks != 32 && !ks_flat && a.mrows % 64 == 0 && a.n_pad % 64 == 0 &&
@@ -317,7 +318,13 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             else if (t128 >= need && use_pp != 3) ptm = 128;       // ADF_GEMM_PP=3: 256-row tiles only (A/B)
         }
         if (ptm) {
-            const bool take = use_pp == 2 || !a.res;
+            // identity-residual 3-tap layers stay with the weight-stationary kernel; the transformer's 1x1 projections
+            // can come here with ADF_GEMM_PP_LINEAR=1 (residual as an identity K segment, GELU in the epilogue): measured
+            // equal to the plain kernel end to end (388.6-393.9 vs 389.6-390.9 ms), so they stay there by default
+            static int pp_linear = -1;
+            if (pp_linear < 0) { const char* e = getenv("ADF_GEMM_PP_LINEAR"); pp_linear = e ? atoi(e) : 0; }
+            const bool linear = a.seg[0].taps == 1 && a.nseg == 1;
+            const bool take = linear ? pp_linear != 0 : (use_pp == 2 || !a.res);
             if (take) {
                 if (a_in.stats) {
                     const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
@@ -350,7 +357,9 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         for (int s = 0; s < a.nseg; ++s)
             if (a.seg[s].stride != 1 || 127 + a.seg[s].taps > kWsARows) ws_ok = false;
         const long long tiles_m_total = (long long)((a.mrows + 127) / 128) * a.B;
-        if (ws_ok && tiles_m_total >= 256) {
+        static long long ws_min_m = -1;     // ADF_GEMM_WS_MINM: fewest 128-row tiles for the weight-stationary kernel
+        if (ws_min_m < 0) { const char* e = getenv("ADF_GEMM_WS_MINM"); ws_min_m = e ? atoll(e) : 256; }
+        if (ws_ok && tiles_m_total >= ws_min_m) {
             // measured on MI355X: the weight-stationary kernel wins with 128-wide N tiles (Cin = Cout = 128 layers);
             // with 64-wide tiles (ADF_GEMM_WS=64 to force) the doubled activation staging loses to the plain kernel
             int wtn = 0;

@@ -28,7 +28,7 @@
 //     affine table is double-buffered per tile; the bias vector sits in LDS.
 // Shapes (checked by the launcher): stride 1, step +1, taps 3 (pad 1) or 1, channels multiple of 64 and sources
 // split at a multiple of 64, mrows = lin = out_rows a multiple of 256, n = n_pad = out_c a multiple of 128,
-// tile counts powers of two, at least 2 K blocks, no phase scatter / GELU.
+// M tile count a power of two, at least 2 K blocks, no phase scatter.
 #pragma once
 #include "adf_gemm.h"
 #include <type_traits>
@@ -69,7 +69,7 @@ __device__ __forceinline__ void pp_dma16(const char* base, unsigned voff, unsign
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 #else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(base), "v"(voff), "s"(lds_dst) : "memory");
+                 : "=&s"(keep) : "s"(base), "v"(voff), "s"(lds_dst) : "memory", "vcc");   // (vcc is not accepted as the address pair)
 #endif
 }
 
@@ -91,7 +91,7 @@ struct PpBlk {
 // would leave CUs idle (L = 256 at batch 64): half the MFMAs per sub-step, but still far less per-step latency than
 // the plain kernel.
 template <int MT>
-__global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int tiles_total, int tm_shift, int tn_shift) {
+__global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int tiles_total, int tm_shift, int tiles_n) {
     typedef bf16_t T;
     constexpr int TM = 128 * MT;                    // rows of the block tile
     constexpr int HP = TM / 8;                      // index of the halo piece (rows TM, TM + 1) inside an A stage
@@ -134,10 +134,13 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const bool use_tab = a.seg[0].ab != nullptr || gn_in;
     const unsigned slab = (unsigned)a.n_pad * (unsigned)kRowBytes;           // one tap of packed weights
 
+    const float inv_tiles_n = 1.0f / (float)tiles_n;
+    const int tn_shift = 31 - __builtin_clz((unsigned)tiles_n);
     auto geom = [&](int tseq, int& b0, int& m0, int& n0) __attribute__((always_inline)) {
         const int t = t_lo + tseq;
-        const int tml = t >> tn_shift;
-        n0 = (t & ((1 << tn_shift) - 1)) * kPpTN;
+        // N tile index fastest; the N tile count need not be a power of two (768-wide q|k|v projections): exact for t < 2^22
+        const int tml = __builtin_amdgcn_readfirstlane((tiles_n & (tiles_n - 1)) == 0 ? t >> tn_shift : (int)(((float)t + 0.5f) * inv_tiles_n));
+        n0 = (t - tml * tiles_n) * kPpTN;
         b0 = tml >> tm_shift;
         m0 = (tml & ((1 << tm_shift) - 1)) * TM;
     };
@@ -514,6 +517,10 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 {
                     const float4 q0 = *(const float4*)(scr), q1 = *(const float4*)(scr + 4);
                     v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                }
+                if (a.gelu) {                                            // uniform: FeedForward1d's GELU on the 1x1 "conv" output
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
                 }
                 if (!(dbg & 1)) *(u32x4_t*)(out + off) = pack16<T>(v);
 #pragma unroll
