@@ -10,6 +10,7 @@
 #include "../../include/audiodiffuser_amd.h"
 #include "adf_gemm.h"
 #include "adf_kernels.h"
+#include "adf_transformer.h"
 
 #include <algorithm>
 #include <cmath>
@@ -28,6 +29,7 @@ std::string g_create_error;
 
 struct ConvW {
     void* w = nullptr;
+    void* wfrag = nullptr;   // transformer 1x1 weights (bf16): second copy in MFMA-fragment order (adf_transformer.h)
     float* bias = nullptr;
     int cout = 0, cin = 0, K = 0, n = 0, n_pad = 0, nchunk = 0, taps = 0, f = 0;
 };
@@ -48,6 +50,7 @@ struct UpW { std::vector<ResW> blocks; bool attn = false; TrW tr; ConvW up; int 
 struct Slot {
     int kind = 0;  // 0 = fp32 copy, 1 = pack conv/linear, 2 = pack transposed conv
     void* dst = nullptr;
+    void* frag = nullptr;    // also repacked to ConvW::wfrag after packing
     int64_t numel = 0;
     bool loaded = false;
     int cout = 0, cin = 0, K = 0, f = 0, n_offset = 0, n_pad = 0, nchunk = 0;
@@ -199,6 +202,16 @@ struct Registrar {
         conv(pre + ".feed_forward.1", t.ff1, t.mid, c, 1, false);
         t.g3 = reg_f32(pre + ".feed_forward.3.g", t.mid);
         conv(pre + ".feed_forward.4", t.ff2, c, t.mid, 1, false);
+        if (h->bf16) {
+            for (ConvW* w : {&t.qkv, &t.proj, &t.ff1, &t.ff2}) {
+                w->wfrag = dalloc(h, (size_t)w->nchunk * w->n_pad * kRowBytes);
+                if (!w->wfrag) { ok = false; return; }
+            }
+            const std::pair<const char*, ConvW*> m[] = {{".attention.to_q.weight", &t.qkv}, {".attention.to_kv.weight", &t.qkv},
+                                                       {".attention.to_out.weight", &t.proj}, {".feed_forward.1.weight", &t.ff1},
+                                                       {".feed_forward.4.weight", &t.ff2}};
+            for (const auto& kv : m) h->slots[pre + kv.first].frag = kv.second->wfrag;
+        }
     }
     struct FilmName { std::string pre; int off, rows; };
     std::vector<FilmName> film_names;
@@ -420,6 +433,37 @@ struct Walker {
 
     Act transformer(const std::string& name, Act& x, const TrW& t) {
         const long long rows = (long long)p->B * x.L;
+        // short levels in bf16 mode: the whole block in one launch (adf_transformer.h); ADF_TR_FUSED=0 keeps the nine launches
+        static int tr_fused = -1;
+        if (tr_fused < 0) { const char* e = getenv("ADF_TR_FUSED"); tr_fused = e ? atoi(e) : 1; }
+        if (tr_fused && h->bf16 && t.c == 256 && t.mid == 512 && h->cfg.attention_heads == 8 && (x.L == 16 || x.L == 64) &&
+            x.C == 256 && t.qkv.nchunk == 4 && t.ff2.nchunk == 8 && t.qkv.wfrag) {
+            Act x2 = new_act(t.c, x.L);
+            TrFusedArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.x = (const bf16_t*)x.p; fa.out = (bf16_t*)x2.p;
+            fa.ln_w = t.lnw; fa.ln_b = t.lnb; fa.g0 = t.g0; fa.g3 = t.g3;
+            fa.wqkv = t.qkv.wfrag; fa.wproj = t.proj.wfrag; fa.wff1 = t.ff1.wfrag; fa.wff2 = t.ff2.wfrag;
+            fa.npad_qkv = t.qkv.n_pad; fa.npad_proj = t.proj.n_pad; fa.npad_ff1 = t.ff1.n_pad; fa.npad_ff2 = t.ff2.n_pad;
+            fa.eps = 1e-5f;
+            if (h->cfg.resnet_groups == 8 && !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) { x2.stats = alloc_stats(); fa.stats = x2.stats; }
+            static int tr_stamps = -1;    // ADF_TR_STAMPS=1 (eager runs only): print the stage times of workgroup 0 of every fused block
+            if (tr_stamps < 0) { const char* e = getenv("ADF_TR_STAMPS"); tr_stamps = e ? atoi(e) : 0; }
+            unsigned long long* dst = nullptr;
+            if (tr_stamps && live()) { if (hipMalloc((void**)&dst, 16 * 8) != hipSuccess) dst = nullptr; fa.stamps = dst; }
+            if (live()) check(launch_transformer_small(fa, p->B, x.L, s));
+            if (dst) {
+                unsigned long long hst[11];
+                if (hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+                    fprintf(stderr, "[adf transformer] %s L=%d cycles:", name.c_str(), x.L);
+                    for (int i = 1; i < 11; ++i) fprintf(stderr, " s%d=%llu", i, hst[i] - hst[i - 1]);
+                    fprintf(stderr, " total=%llu\n", hst[10] - hst[0]);
+                }
+                (void)hipFree(dst);
+            }
+            tap(name, x2);
+            return x2;
+        }
         Act xn = new_act(t.c, x.L);
         if (live()) check(launch_ln_rows(x.p, xn.p, h->bf16, rows, t.c, t.lnw, t.lnb, 1e-5f, s));
         Act qkv = linear(xn, t.qkv, nullptr, 0, false);
@@ -1046,6 +1090,10 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
         const char* e = launch_pack_weight(dev, sl.dst, h->bf16, sl.kind == 2 ? 1 : (sl.kind == 3 ? 2 : 0), sl.cout, sl.cin, sl.K, sl.f, sl.n_offset,
                                            sl.n_pad, sl.nchunk, s);
         if (e) return fail(h, e);
+        if (sl.frag) {
+            e = launch_repack_frag(sl.dst, sl.frag, sl.n_offset, sl.cout, sl.n_pad, sl.nchunk, s);
+            if (e) return fail(h, e);
+        }
     }
     sl.loaded = true;
     return 0;

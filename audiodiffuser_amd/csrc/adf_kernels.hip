@@ -1069,4 +1069,24 @@ const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, 
     return ADF_LAUNCH_CHECK("pack_weight");
 }
 
+// Second copy of a packed bf16 1x1 weight in MFMA-fragment order for adf_transformer.h: dst[K step][half][n][8 channels],
+// i.e. the 16-byte B fragments of one K step (16 channels) are contiguous over the output columns.
+__global__ void __launch_bounds__(256) repack_frag_kernel(const char* __restrict__ src, char* __restrict__ dst, int n_offset, int n_rows,
+                                                          int n_pad, int nchunk) {
+    const long long total = (long long)nchunk * n_rows * 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int u = (int)(i & 7);                      // 16-byte unit of the 128-byte row: K step u >> 1 of the chunk, half u & 1
+        const int n = n_offset + (int)((i >> 3) % n_rows);
+        const int chunk = (int)((i >> 3) / n_rows);
+        const u32x4_t v = *(const u32x4_t*)(src + ((size_t)chunk * n_pad + n) * 128 + u * 16);
+        *(u32x4_t*)(dst + (((size_t)(chunk * 4 + (u >> 1)) * 2 + (u & 1)) * n_pad + n) * 16) = v;
+    }
+}
+const char* launch_repack_frag(const void* src, void* dst, int n_offset, int n_rows, int n_pad, int nchunk, hipStream_t s) {
+    const long long total = (long long)nchunk * n_rows * 8;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(repack_frag_kernel, dim3(grid), dim3(256), 0, s, (const char*)src, (char*)dst, n_offset, n_rows, n_pad, nchunk);
+    return ADF_LAUNCH_CHECK("repack_frag");
+}
+
 }  // namespace adf

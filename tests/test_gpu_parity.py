@@ -237,6 +237,29 @@ def test_pipelined_dma_gemm_route_matches_plain_routes(tmp_path, batch, pp):
     assert rel("out") < 3e-2, rel("out")
 
 
+def test_fused_transformer_block_matches_the_unfused_launches(tmp_path):
+    """adf_transformer.h (one launch per TransformerBlock1d at the 64- and 16-token levels, bf16 mode) against the nine
+    launches it replaces (ADF_TR_FUSED=0): both round to bf16 at the same points, so the first fused block agrees to
+    accumulation-order noise and the end of the net to compounded bf16 rounding.  (Switch read once per process.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"tr{mode}.pt")
+        env = dict(os.environ, ADF_TR_FUSED=mode, B="5")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(path)
+    a, b = outs["1"], outs["0"]
+    assert all(bool(torch.isfinite(v).all()) for v in a.values())
+    rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
+    assert rel("down3.attn") == 0.0                      # 256 tokens: not fused, identical launches
+    assert rel("down4.attn") < 2e-3, rel("down4.attn")   # first fused block (64 tokens)
+    assert rel("down5.attn") < 1e-2, rel("down5.attn")   # 16 tokens
+    assert rel("out") < 3e-2, rel("out")
+
+
 # ---- class conditioning + classifier-free guidance (SURVEY.md 8f rank 1) ------------------------------------
 def _cc_net(dtype="fp32"):
     cfg = A.config_tiny_cc()
