@@ -237,6 +237,29 @@ def test_pipelined_dma_gemm_route_matches_plain_routes(tmp_path, batch, pp):
     assert rel("out") < 3e-2, rel("out")
 
 
+def test_fused_short_level_resblock_matches_the_unfused_launches(tmp_path):
+    """adf_resblock_small.h (one launch per ResnetBlock1d at the 64- and 16-position levels, bf16 mode; identity and 1x1-conv
+    residual, skip concat, FiLM) against the launches it replaces (ADF_RB_FUSED=0)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"rb{mode}.pt")
+        env = dict(os.environ, ADF_RB_FUSED=mode, ADF_TR_FUSED="0", B="5")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(path)
+    a, b = outs["1"], outs["0"]
+    assert all(bool(torch.isfinite(v).all()) for v in a.values())
+    rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
+    assert rel("down4.conv") == 0.0                      # everything before the first fused block is the same launches
+    assert rel("down4.block0") < 1e-3, rel("down4.block0")   # identity residual, 64 positions
+    assert rel("down5.block1") < 1e-2, rel("down5.block1")   # 16 positions
+    assert rel("up0.block0") < 2e-2, rel("up0.block0")       # skip concat + 1x1 residual conv
+    assert rel("out") < 3e-2, rel("out")
+
+
 def test_fused_transformer_block_matches_the_unfused_launches(tmp_path):
     """adf_transformer.h (one launch per TransformerBlock1d at the 64- and 16-token levels, bf16 mode) against the nine
     launches it replaces (ADF_TR_FUSED=0): both round to bf16 at the same points, so the first fused block agrees to
@@ -246,7 +269,7 @@ def test_fused_transformer_block_matches_the_unfused_launches(tmp_path):
     outs = {}
     for mode in ("0", "1"):
         path = str(tmp_path / f"tr{mode}.pt")
-        env = dict(os.environ, ADF_TR_FUSED=mode, B="5")
+        env = dict(os.environ, ADF_TR_FUSED=mode, ADF_RB_FUSED="0", B="5")
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
