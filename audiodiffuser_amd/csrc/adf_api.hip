@@ -470,7 +470,7 @@ struct Walker {
         const long long rows = (long long)p->B * x.L;
         // short levels in bf16 mode: the whole block in one launch (adf_transformer.h); ADF_TR_FUSED=0 keeps the nine launches
         static int tr_fused = -1;
-        if (tr_fused < 0) { const char* e = getenv("ADF_TR_FUSED"); tr_fused = e ? atoi(e) : 1; }
+        if (tr_fused < 0) { const char* e = getenv("ADF_TR_FUSED"); tr_fused = e ? atoi(e) : 2; }
         if (tr_fused && h->bf16 && t.c == 256 && t.mid == 512 && h->cfg.attention_heads == 8 && (x.L == 16 || x.L == 64) &&
             x.C == 256 && t.qkv.nchunk == 4 && t.ff2.nchunk == 8 && t.qkv.wfrag) {
             Act x2 = new_act(t.c, x.L);
@@ -495,6 +495,27 @@ struct Walker {
                     fprintf(stderr, " total=%llu\n", hst[10] - hst[0]);
                 }
                 (void)hipFree(dst);
+            }
+            tap(name, x2);
+            return x2;
+        }
+        // longer samples (256 tokens): two fused launches around the attention kernel (ADF_TR_FUSED=1 keeps these unfused)
+        if (tr_fused >= 2 && h->bf16 && t.c == 256 && t.mid == 512 && h->cfg.attention_heads == 8 && x.L % 64 == 0 && x.L > 64 &&
+            x.C == 256 && t.qkv.nchunk == 4 && t.ff2.nchunk == 8 && t.qkv.wfrag && h->cfg.resnet_groups == 8 &&
+            !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) {
+            Act qkv = new_act(3 * t.c, x.L), att = new_act(t.c, x.L), x2 = new_act(t.c, x.L);
+            TrFusedArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.x = (const bf16_t*)x.p; fa.out = (bf16_t*)x2.p; fa.qkv_out = (bf16_t*)qkv.p; fa.att = (const bf16_t*)att.p;
+            fa.ln_w = t.lnw; fa.ln_b = t.lnb; fa.g0 = t.g0; fa.g3 = t.g3;
+            fa.wqkv = t.qkv.wfrag; fa.wproj = t.proj.wfrag; fa.wff1 = t.ff1.wfrag; fa.wff2 = t.ff2.wfrag;
+            fa.npad_qkv = t.qkv.n_pad; fa.npad_proj = t.proj.n_pad; fa.npad_ff1 = t.ff1.n_pad; fa.npad_ff2 = t.ff2.n_pad;
+            fa.eps = 1e-5f;
+            x2.stats = alloc_stats(); fa.stats = x2.stats;
+            if (live()) {
+                check(launch_transformer_tiles(fa, (int)rows, x.L, 1, s));
+                check(launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
+                check(launch_transformer_tiles(fa, (int)rows, x.L, 2, s));
             }
             tap(name, x2);
             return x2;

@@ -32,14 +32,21 @@ struct TrFusedArgs {
     int npad_qkv, npad_proj, npad_ff1, npad_ff2;
     double* stats;        // [B][8][2] sum / sumsq of the output per group of 32 channels, or nullptr
     float eps;
-    int B;                // samples = worker workgroups; the grid may carry helper workgroups beyond (see the kernel)
+    const bf16_t* att;    // MODE 2: attention output [rows][256]
+    bf16_t* qkv_out;      // MODE 1: q|k|v [rows][768]
+    int tiles_per_sample; // MODE 1 / 2: workgroups (64-row tiles) per sample
+    int B;                // samples (MODE 0) or row tiles = worker workgroups; the grid may carry helper workgroups beyond (see the kernel)
     unsigned long long* stamps;   // diagnostics (ADF_TR_STAMPS=1): s_memtime of workgroup 0 after every stage, or nullptr
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 tr_bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float tr_f32x16_t;
 
-template <int NTOK>
+// MODE 0: the whole block, one workgroup per sample (16 or 64 tokens).  Longer samples (256 tokens) run as two launches around
+// the stand-alone attention kernel, a workgroup per 64-row tile (everything but the attention is row-local):
+// MODE 1: LayerNorm -> q|k|v projection -> a.qkv_out;  MODE 2: attention output a.att -> projection + residual -> ... -> out,
+// statistics by fp64 atomics (tiles_per_sample workgroups share a sample).
+template <int NTOK, int MODE = 0>
 __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArgs a) {
     constexpr int C = 256, MID = 512, D = 32;
     constexpr int MR = NTOK < 32 ? 32 : NTOK;           // rows of the MFMA tiles (rows >= NTOK are padding)
@@ -82,10 +89,12 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
                              : "=&s"(keep) : "v"(g), "s"(scratch) : "memory");
             }
         };
-        warm(a.wqkv, a.npad_qkv, 4);
-        warm(a.wproj, a.npad_proj, 4);
-        warm(a.wff1, a.npad_ff1, 4);
-        warm(a.wff2, a.npad_ff2, 8);
+        if (MODE != 2) warm(a.wqkv, a.npad_qkv, 4);
+        if (MODE != 1) {
+            warm(a.wproj, a.npad_proj, 4);
+            warm(a.wff1, a.npad_ff1, 4);
+            warm(a.wff2, a.npad_ff2, 8);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
@@ -195,6 +204,7 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     // LayerNorm parameters -> LDS, their loads in flight together with the input rows' (one round trip instead of three)
     for (int i = tid; i < 1280; i += 512)
         prm[i] = i < 256 ? a.ln_w[i] : (i < 512 ? a.ln_b[i - 256] : (i < 768 ? a.g0[i - 512] : a.g3[i - 768]));
+    if constexpr (MODE != 2) {
     // ---- S0: LayerNorm of the input rows -> bufA ------------------------------------------------------------------
     layer_norm(std::integral_constant<int, C>{}, (const char*)xb, C * 2, true, bufA, PA, prm, prm + 256, true);
     __syncthreads();
@@ -214,8 +224,26 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
                     *(unsigned short*)(bufQ + row_of(i, e) * PQ + (wave * 96 + j * 32 + r) * 2) = f32_to_bf16(acc[i][j][e]);
     }
     __syncthreads();
+    }
+    if constexpr (MODE == 1) {                          // q|k|v rows -> global, done
+        bf16_t* const qo = a.qkv_out + (size_t)b * NTOK * 3 * C;
+        for (int idx = tid; idx < NTOK * (3 * C / 8); idx += 512) {
+            const int row = idx / (3 * C / 8), cc = idx % (3 * C / 8);
+            *(u32x4_t*)(qo + (size_t)row * 3 * C + cc * 8) = *(const u32x4_t*)(bufQ + row * PQ + cc * 16);
+        }
+        return;
+    }
+    if constexpr (MODE == 2) {                          // attention output rows -> bufA
+        const bf16_t* const ab = a.att + (size_t)b * NTOK * C;
+        for (int idx = tid; idx < NTOK * (C / 8); idx += 512) {
+            const int row = idx / (C / 8), cc = idx % (C / 8);
+            *(u32x4_t*)(bufA + row * PA + cc * 16) = *(const u32x4_t*)(ab + (size_t)row * C + cc * 8);
+        }
+        __syncthreads();
+    }
 
     stamp(2);
+    if constexpr (MODE == 0) {
     // ---- S2: attention, wave = head; output rows -> bufA ---------------------------------------------------------
     {
         const char* const qb = bufQ + wave * D * 2;
@@ -295,6 +323,7 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
         }
     }
     __syncthreads();
+    }
 
     stamp(3);
     // ---- S3: x1 = att Wp^T + x (32 columns per wave); kept (rounded to bf16, as the unfused path stores it) for S7 -----
@@ -366,8 +395,14 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
             if (lane == 0) {
-                double* sp = a.stats + ((size_t)b * 8 + wave) * 2;
-                sp[0] = (double)s1; sp[1] = (double)s2;
+                if constexpr (MODE == 0) {
+                    double* sp = a.stats + ((size_t)b * 8 + wave) * 2;
+                    sp[0] = (double)s1; sp[1] = (double)s2;
+                } else {
+                    double* sp = a.stats + ((size_t)(b / a.tiles_per_sample) * 8 + wave) * 2;
+                    atomicAdd(sp, (double)s1);
+                    atomicAdd(sp + 1, (double)s2);
+                }
             }
         }
     }
@@ -401,6 +436,27 @@ inline const char* launch_transformer_small(const TrFusedArgs& a, int B, int nto
     if (ntok == 64) hipLaunchKernelGGL(transformer_small_kernel<64>, dim3(B + helpers), dim3(512), lds, s, aa);
     else hipLaunchKernelGGL(transformer_small_kernel<16>, dim3(B + helpers), dim3(512), lds, s, aa);
     return hipGetLastError() == hipSuccess ? nullptr : "transformer_small: launch failed";
+}
+
+// 256-token (or longer) samples: MODE 1 / MODE 2 over 64-row tiles (rows = B * tokens, a multiple of 64)
+inline const char* launch_transformer_tiles(const TrFusedArgs& a, int rows, int tokens, int mode, hipStream_t s) {
+    if (rows % 64 || tokens % 64 || (mode != 1 && mode != 2)) return "transformer_tiles: unsupported shape";
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)transformer_small_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)transformer_small_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return "transformer_tiles: hipFuncSetAttribute failed";
+        attr = true;
+    }
+    const size_t lds = (size_t)64 * (256 * 2 + 16) + (size_t)64 * (768 * 2 + 16) + 8 * 1024 + 1280 * 4;
+    const int tiles = rows / 64;
+    const int helpers = tiles < 256 ? ((256 - tiles) / 8 > 3 * tiles / 8 ? 3 * tiles / 8 : (256 - tiles) / 8) * 8 : 0;
+    TrFusedArgs aa = a;
+    aa.B = tiles;
+    aa.tiles_per_sample = tokens / 64;
+    if (mode == 1) hipLaunchKernelGGL((transformer_small_kernel<64, 1>), dim3(tiles + helpers), dim3(512), lds, s, aa);
+    else hipLaunchKernelGGL((transformer_small_kernel<64, 2>), dim3(tiles + helpers), dim3(512), lds, s, aa);
+    return hipGetLastError() == hipSuccess ? nullptr : "transformer_tiles: launch failed";
 }
 
 }  // namespace adf

@@ -261,26 +261,33 @@ def test_fused_short_level_resblock_matches_the_unfused_launches(tmp_path):
 
 
 def test_fused_transformer_block_matches_the_unfused_launches(tmp_path):
-    """adf_transformer.h (one launch per TransformerBlock1d at the 64- and 16-token levels, bf16 mode) against the nine
-    launches it replaces (ADF_TR_FUSED=0): both round to bf16 at the same points, so the first fused block agrees to
-    accumulation-order noise and the end of the net to compounded bf16 rounding.  (Switch read once per process.)"""
+    """adf_transformer.h (bf16 mode) against the nine launches per TransformerBlock1d it replaces (ADF_TR_FUSED=0): mode 1 = one
+    launch per block at the 64- and 16-token levels, mode 2 (default) = also the 256-token level as two fused launches around
+    the attention kernel.  Both paths round to bf16 at the same points, so the first fused block agrees to accumulation-order
+    noise and the end of the net to compounded bf16 rounding.  (The switch is read once per process.)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         path = str(tmp_path / f"tr{mode}.pt")
         env = dict(os.environ, ADF_TR_FUSED=mode, ADF_RB_FUSED="0", B="5")
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[mode] = torch.load(path)
-    a, b = outs["1"], outs["0"]
-    assert all(bool(torch.isfinite(v).all()) for v in a.values())
-    rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
-    assert rel("down3.attn") == 0.0                      # 256 tokens: not fused, identical launches
-    assert rel("down4.attn") < 2e-3, rel("down4.attn")   # first fused block (64 tokens)
-    assert rel("down5.attn") < 1e-2, rel("down5.attn")   # 16 tokens
-    assert rel("out") < 3e-2, rel("out")
+    b = outs["0"]
+    for mode in ("1", "2"):
+        a = outs[mode]
+        assert all(bool(torch.isfinite(v).all()) for v in a.values())
+        rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
+        if mode == "1":
+            assert rel("down3.attn") == 0.0                  # 256 tokens: not fused in mode 1, identical launches
+            assert rel("down4.attn") < 2e-3, rel("down4.attn")   # first fused block (64 tokens)
+        else:
+            assert rel("down3.block1") == 0.0
+            assert rel("down3.attn") < 2e-3, rel("down3.attn")   # 256 tokens: LayerNorm + q|k|v, attention, the rest in one launch
+        assert rel("down5.attn") < 1e-2, rel("down5.attn")   # 16 tokens
+        assert rel("out") < 3e-2, rel("out")
 
 
 # ---- class conditioning + classifier-free guidance (SURVEY.md 8f rank 1) ------------------------------------
