@@ -189,7 +189,7 @@ struct Registrar {
         conv(pre + ".block2.project", r.c2, cout, cout, 3, true);
         r.has_res = cin != cout;
         if (r.has_res) conv(pre + ".to_out", r.cr, cout, cin, 1, true);
-        if (h->bf16 && cout == 256 && (cin == 256 || cin == 512)) {   // candidates of the fused short-level kernel (adf_resblock_small.h)
+        if (h->bf16 && (cout == 256 || cout == 128) && (cin == cout || cin == 2 * cout)) {   // fragment-major copies: adf_resblock_small.h, adf_gemm_tile.h
             const std::pair<const char*, ConvW*> m[] = {{".block1.project.weight", &r.c1}, {".block2.project.weight", &r.c2}, {".to_out.weight", &r.cr}};
             for (const auto& kv : m) {
                 ConvW* w = kv.second;
@@ -353,7 +353,7 @@ struct Walker {
         sg.src1 = skip ? skip->p : nullptr; sg.c1 = skip ? skip->C : 0;
         sg.ab = ab; sg.scale1 = scale1; sg.act = act;
         sg.taps = taps; sg.stride = stride; sg.off0 = off0; sg.step = step;
-        sg.w = w.w; sg.nchunk = w.nchunk;
+        sg.w = w.w; sg.wfrag = w.wfrag; sg.nchunk = w.nchunk;
         return sg;
     }
     void run_gemm(GemmArgs& g, Act& out, bool want_stats) {

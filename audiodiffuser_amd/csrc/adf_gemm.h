@@ -43,6 +43,7 @@ struct GemmSeg {
     int act;            // 1 = SiLU after the affine
     int taps, stride, off0, step;
     const void* w;      // packed [nchunk][taps][n_pad][row of 128 B]
+    const void* wfrag;  // optional second copy in MFMA-fragment order [K step][2][n_pad][8] (bf16; adf_gemm_tile.h)
     int nchunk;
 };
 

@@ -1,6 +1,7 @@
 // Tile-shape dispatch for the fused implicit-GEMM kernel (see adf_gemm.h).
 #include "adf_gemm.h"
 #include "adf_gemm_pp.h"
+#include "adf_gemm_tile.h"
 #include "adf_kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +68,26 @@ const char* launch_ws_variant(const GemmArgs& a, hipStream_t stream) {
     if (bpn > tiles_m_total) bpn = tiles_m_total;
     hipLaunchKernelGGL(kern, dim3((unsigned)(bpn * tiles_n)), dim3(512), (size_t)ws_lds_bytes(a, TN), stream, a, (int)tiles_m_total, (int)bpn);
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_ws: launch failed";
+}
+
+// Tile kernel (adf_gemm_tile.h): persistent 512-thread workgroups over tiles of 128 (N = 256) or 256 (N = 128) positions
+template <int N, int CIN, int CRES>
+const char* launch_tile(const GemmArgs& a, hipStream_t stream) {
+    typedef TileCfg<N, CIN, CRES> Cfg;
+    static bool attr_set = false;
+    auto kern = conv_gemm_tile_kernel<N, CIN, CRES>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, tile) failed";
+        attr_set = true;
+    }
+    static_assert(Cfg::kLds <= 160 * 1024, "tile kernel LDS budget");
+    const int tps = a.mrows / Cfg::TM;
+    const long long tiles = (long long)a.B * tps;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return "conv_gemm_tile: bad tile count";
+    const long long grid = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), Cfg::kLds, stream, a, (int)tiles, tps);
+    return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_tile: launch failed";
 }
 
 // Persistent LDS-DMA kernel (adf_gemm_pp.h): one 512-thread block per CU, block tile (128 MT) x 128.
@@ -299,6 +320,39 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             trace_route("ksplit", a, tile, tile);
             if (big) return dtype_bf16 ? launch_ksplit<bf16_t, 2, 2>(a, stream) : launch_ksplit<float, 2, 2>(a, stream);
             return dtype_bf16 ? launch_ksplit<bf16_t, 1, 1>(a, stream) : launch_ksplit<float, 1, 1>(a, stream);
+        }
+    }
+    {
+        // resblock convs (3 taps, 128 or 256 output channels, GroupNorm prologue from the statistics, optional 1x1 residual
+        // segment / identity residual) in bf16 on the tile kernel (adf_gemm_tile.h): ADF_GEMM_TILE=1.  OFF by default -- measured
+        // (tools/layer_table.py, us per launch, tile vs the routes below): L = 4096 K = 384 / 768: 76-88 / 126 vs 50-60 / 97;
+        // L = 1024 (256 channels) K = 768 / 1536: 53-60 / 91 vs 45-56 / 93; L = 256: 26-48 vs 24-40; 334 vs 319 ms per step.
+        static int use_tile = -1;
+        if (use_tile < 0) { const char* e = getenv("ADF_GEMM_TILE"); use_tile = e ? atoi(e) : 0; }
+        const GemmSeg& g = a.seg[0];
+        const int N = a.n, cin = g.c0 + g.c1;
+        bool ok = use_tile && dtype_bf16 && !flat && !a.scatter_f && !a.gelu && g.taps == 3 && g.stride == 1 && g.off0 == -1 && g.step == 1 &&
+                  g.wfrag && a.n == a.n_pad && a.out_c == a.n && (N == 128 || N == 256) && a.lin == a.mrows && a.out_rows == a.mrows &&
+                  a.mrows % (N == 256 ? 128 : 256) == 0 && (cin == N || cin == 2 * N) && (gn_pending || !g.ab) && a.bias_mod == a.n &&
+                  (!a_in.stats || a.stats_groups == 8) && (long long)a.B * (a.mrows / (N == 256 ? 128 : 256)) >= 64;
+        int cres = 0;
+        if (ok && a.nseg == 2) {
+            const GemmSeg& s1 = a.seg[1];
+            ok = s1.taps == 1 && s1.stride == 1 && s1.off0 == 0 && s1.step == 1 && !s1.ab && !s1.act && s1.wfrag && s1.c0 + s1.c1 == 2 * N &&
+                 cin == N && !a.res;
+            cres = 2 * N;
+        }
+        if (ok) {
+            if (const char* e = settle_gn(true)) return e;
+            a.stats = a_in.stats;
+            if (stats_fused && a_in.stats) *stats_fused = true;
+            trace_route("tile", a, N == 256 ? 128 : 256, N);
+            if (N == 128 && cin == 128 && !cres) return launch_tile<128, 128, 0>(a, stream);
+            if (N == 128 && cin == 256) return launch_tile<128, 256, 0>(a, stream);
+            if (N == 128) return launch_tile<128, 128, 256>(a, stream);
+            if (cin == 256 && !cres) return launch_tile<256, 256, 0>(a, stream);
+            if (cin == 512) return launch_tile<256, 512, 0>(a, stream);
+            return launch_tile<256, 256, 512>(a, stream);
         }
     }
     {
