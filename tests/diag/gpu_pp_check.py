@@ -15,8 +15,12 @@ def save(path):
     B = int(os.environ.get("B", "8"))
     x = generate_noise(0, B, 16384) * 0.7
     t = torch.linspace(-1.0, 0.5, B)
+    kw = {}
+    if os.environ.get("CLASSES"):        # class-conditional variant of the net: labels per sample (FiLM gets the class addend)
+        cfg.class_cond, cfg.num_classes = True, 10
+        kw = {"classes": (torch.arange(B) % 10).cuda(), "cond_drop_prob": 0.0}
     net, w = make_net(cfg, "bf16", int(os.environ.get("FLAGS", "0")))
-    y = net(x.cuda(), t.cuda())
+    y = net(x.cuda(), t.cuda(), **kw)
     torch.cuda.synchronize()
     hd = net.native(torch.device("cuda", 0))
     out = {"out": y.float().cpu()}

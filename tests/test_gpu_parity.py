@@ -237,15 +237,17 @@ def test_pipelined_dma_gemm_route_matches_plain_routes(tmp_path, batch, pp):
     assert rel("out") < 3e-2, rel("out")
 
 
-def test_fused_short_level_resblock_matches_the_unfused_launches(tmp_path):
+@pytest.mark.parametrize("classes", ["", "1"])
+def test_fused_short_level_resblock_matches_the_unfused_launches(tmp_path, classes):
     """adf_resblock_small.h (one launch per ResnetBlock1d at the 64- and 16-position levels, bf16 mode; identity and 1x1-conv
-    residual, skip concat, FiLM) against the launches it replaces (ADF_RB_FUSED=0)."""
+    residual, skip concat, FiLM -- with and without the per-sample class addend of a class-conditional net) against the
+    launches it replaces (ADF_RB_FUSED=0)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for mode in ("0", "1"):
         path = str(tmp_path / f"rb{mode}.pt")
-        env = dict(os.environ, ADF_RB_FUSED=mode, ADF_TR_FUSED="0", B="5")
+        env = dict(os.environ, ADF_RB_FUSED=mode, ADF_TR_FUSED="0", B="5", CLASSES=classes)
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
