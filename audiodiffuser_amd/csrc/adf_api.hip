@@ -415,7 +415,20 @@ struct Walker {
             fa.b1 = r.c1.bias; fa.b2 = r.c2.bias; fa.br = r.has_res ? r.cr.bias : nullptr;
             fa.skip_scale = sscale; fa.eps = 1e-5f;
             y.stats = alloc_stats(); fa.stats = y.stats;
+            static int rb_stamps = -1;    // ADF_TR_STAMPS=1 (eager runs only): stage times of workgroup 0
+            if (rb_stamps < 0) { const char* e = getenv("ADF_TR_STAMPS"); rb_stamps = e ? atoi(e) : 0; }
+            unsigned long long* dst = nullptr;
+            if (rb_stamps && live()) { if (hipMalloc((void**)&dst, 16 * 8) != hipSuccess) dst = nullptr; fa.stamps = dst; }
             if (live()) check(launch_resblock_small(fa, B, x.L, ctot, s));
+            if (dst) {
+                unsigned long long hst[8];
+                if (hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+                    fprintf(stderr, "[adf resblock] %s L=%d cin=%d cycles: params+raw=%llu res=%llu act=%llu conv1=%llu gn2=%llu conv2=%llu out=%llu total=%llu\n",
+                            name.c_str(), x.L, ctot, hst[1] - hst[0], hst[2] - hst[1], hst[3] - hst[2], hst[4] - hst[3], hst[5] - hst[4],
+                            hst[6] - hst[5], hst[7] - hst[6], hst[7] - hst[0]);
+                }
+                (void)hipFree(dst);
+            }
             RbRec rec{name, GemmArgs{}, GemmArgs{}, r.cin, r.cout, x.L};
             rec.g1.nseg = 0;                               // marks a fused block for adf_bench_resblock (keeps the block numbering)
             p->rbs.push_back(rec);

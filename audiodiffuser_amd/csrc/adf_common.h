@@ -56,6 +56,8 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     f32x2_hw_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
+// one fp32 -> bf16 with the hardware converter (the software f32_to_bf16 above is ~8 vector instructions)
+__device__ __forceinline__ unsigned short f32_to_bf16_hw(float f) { return (unsigned short)(pack_bf16x2(f, f) & 0xffffu); }
 template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
     u32x4_t q;
     q.x = pack_bf16x2(f[0], f[1]);

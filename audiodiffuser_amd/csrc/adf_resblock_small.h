@@ -27,6 +27,7 @@ struct RbFusedArgs {
     float skip_scale, eps;
     double* stats;                             // [B][8][2] statistics of the output, or nullptr
     int B;
+    unsigned long long* stamps;                // diagnostics (ADF_TR_STAMPS=1): s_memtime of workgroup 0 after every stage, or nullptr
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 rb_bf16x8_t;
@@ -74,21 +75,33 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         return;
     }
 
+    auto stamp = [&](int id) __attribute__((always_inline)) {
+        if (a.stamps && b == 0 && tid == 0) a.stamps[id] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     // ---- GEMM stage: acc[i] += sum over taps t and K steps: A[row i*32 + r + t + row0][channels] * W[tap t][columns n0 + r]^T.
     // A from LDS (pitch, halo-shifted rows), W fragments from the fragment-major global copy in packed K order [chunk][tap] --------
+    // The ring of weight fragments lives across the stages: `prefetch(W)` issues the first 16 K steps of a GEMM (16 KB per wave)
+    // and is called BEFORE the phase that precedes that GEMM (parameter loads, prologue, the previous GEMM's epilogue), so
+    // the weight stream -- the floor of this kernel -- keeps running through the vector-only phases.
+    constexpr int DEPTH = 16, RING = DEPTH + 1;
+    rb_bf16x8_t wf[RING];
+    auto wptr = [&](const void* W, int n0) __attribute__((always_inline)) -> const char* { return (const char*)W + ((size_t)hh * CO + n0 + r) * 16; };
+    auto prefetch = [&](const void* W, int n0) __attribute__((always_inline)) {
+        const char* const wl = wptr(W, n0);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) wf[d] = __builtin_bit_cast(rb_bf16x8_t, *(const u32x4_t*)(wl + (size_t)d * 2 * CO * 16));
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto gemm = [&](auto tapsc, auto chunksc, const char* A, int pitch, int row0, const void* W, int n0, rb_f32x16_t (&acc)[MT])
                     __attribute__((always_inline)) {
         constexpr int TAPS = decltype(tapsc)::value, CH = decltype(chunksc)::value;     // CH = 64-channel chunks of the input
         constexpr int KS = CH * TAPS * 4;
-        const char* const wl = (const char*)W + ((size_t)hh * CO + n0 + r) * 16;
+        static_assert(KS >= DEPTH, "ring depth");
+        const char* const wl = wptr(W, n0);
         auto wfrag = [&](int ks) __attribute__((always_inline)) -> rb_bf16x8_t {
             return __builtin_bit_cast(rb_bf16x8_t, *(const u32x4_t*)(wl + (size_t)ks * 2 * CO * 16));
         };
-        constexpr int DEPTH = 16 < KS ? 16 : KS;         // 16 KB of weight loads in flight per wave
-        constexpr int RING = DEPTH + 1;
-        rb_bf16x8_t wf[RING];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) wf[d] = wfrag(d);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int kb = 0; kb < KS; kb += RING) {           // RING K steps per trip, so that ring slots are compile-time registers
@@ -119,6 +132,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
     const bf16_t* const xb = a.x + (size_t)b * NTOK * 256;
     const bf16_t* const sb = a.skip ? a.skip + (size_t)b * NTOK * 256 : nullptr;
 
+    prefetch(a.wr ? a.wr : a.w1, wave * 32);
     // ---- R0: parameters and the GroupNorm-1 table -> LDS; raw input rows -> bufX (for the 1x1 residual conv) ---------------
     for (int i = tid; i < 6 * 256; i += 512) {
         const int k = i >> 8, c = i & 255;
@@ -158,6 +172,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         }
     }
     __syncthreads();
+    stamp(1);
 
     // ---- R1: the residual into the output accumulators: 1x1 conv of the raw concat, or the input itself -------------------
     rb_f32x16_t accy[MT];
@@ -167,6 +182,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         for (int e = 0; e < 16; ++e) accy[i][e] = 0.f;
     if (a.wr) {
         gemm(one, chin, bufX, PX, 1, a.wr, wave * 32, accy);
+        prefetch(a.w1, wave * 32);
         __syncthreads();                                  // bufX is rewritten next
     } else {
 #pragma unroll
@@ -178,6 +194,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
             }
     }
 
+    stamp(2);
     // ---- R2: silu(GroupNorm1(input)) -> bufX rows 1 .. NTOK, zero halo rows ---------------------------------------------
     for (int idx = tid; idx < NTOK * CPR; idx += 512) {
         const int row = idx / CPR, cc = idx % CPR;
@@ -196,6 +213,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         *(u32x4_t*)(bufH + row * PH + cc * 16) = u32x4_t{0u, 0u, 0u, 0u};
     }
     __syncthreads();
+    stamp(3);
 
     // ---- R3: h1 = conv1 + bias; GroupNorm 2 over the sample (this wave's 32 columns are one group); silu(FiLM(GN2(h1))) -> bufH
     {
@@ -205,6 +223,8 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
 #pragma unroll
             for (int e = 0; e < 16; ++e) acch[i][e] = 0.f;
         gemm(three, chin, bufX, PX, 0, a.w1, wave * 32, acch);
+        prefetch(a.w2, wave * 32);
+        stamp(4);
         const float bias = prm[col];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -233,15 +253,17 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row_of(i, e);
-                const float h1 = bf16_to_f32(f32_to_bf16(acch[i][e]));          // as the unfused path stores it
-                const unsigned short q = row < NTOK ? f32_to_bf16(silu_f(fmaf(h1, A, Bc))) : (unsigned short)0;
+                const float h1 = bf16_to_f32(f32_to_bf16_hw(acch[i][e]));          // as the unfused path stores it
+                const unsigned short q = row < NTOK ? f32_to_bf16_hw(silu_f(fmaf(h1, A, Bc))) : (unsigned short)0;
                 *(unsigned short*)(bufH + (row + 1) * PH + col * 2) = q;        // rows >= NTOK: zeros (row NTOK is the upper halo row)
             }
     }
     __syncthreads();
+    stamp(5);
 
     // ---- R4: y = conv2 + residual + biases -> statistics, bf16 rows -> bufX -> global ------------------------------------
     gemm(three, chco, bufH, PH, 0, a.w2, wave * 32, accy);
+    stamp(6);
     {
         const float bias = prm[256 + col];
         float s1 = 0.f, s2 = 0.f;
@@ -252,7 +274,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
                 const int row = row_of(i, e);
                 const float v = accy[i][e] + bias;
                 if (row < NTOK) { s1 += v; s2 = fmaf(v, v, s2); }
-                *(unsigned short*)(bufX + (row + 1) * PX + col * 2) = f32_to_bf16(v);
+                *(unsigned short*)(bufX + (row + 1) * PX + col * 2) = f32_to_bf16_hw(v);
             }
         if (a.stats) {
             double d1 = (double)s1, d2 = (double)s2;
@@ -272,6 +294,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
             *(u32x4_t*)(ob + (size_t)row * CO + cc * 8) = *(const u32x4_t*)(bufX + (row + 1) * PX + cc * 16);
         }
     }
+    stamp(7);
 }
 
 inline size_t resblock_small_lds(int ntok, int cin) {

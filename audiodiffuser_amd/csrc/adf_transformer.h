@@ -141,32 +141,38 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     };
 
     // ---- one GEMM stage: acc[i][j] += A[rows of M tile i][K] * W[columns n0 + 32 j ..][K]^T, A from LDS, W fragments from
-    // the packed global weights, loaded DEPTH K steps (of 16 channels) ahead -----------------------------------------
+    // the fragment-major global weights.  The ring of fragments lives across the stages: `prefetch` issues the first DEPTH K
+    // steps (16 KB per wave) BEFORE the phase that precedes the GEMM (LayerNorm, attention, the previous epilogue), so the
+    // weight stream -- the floor of this kernel -- keeps running through the vector-only phases.
+    // fragment-major weights (repack_frag_kernel): the 16-byte fragments of K step ks, half hh, for all columns are
+    // contiguous, so a wave's load is two 512-byte runs.  (Read from the conv layout -- 128-byte rows -- every lane is
+    // its own 64-byte request: 64 requests per KB held all four GEMMs at 9-14 B/clk/CU whatever was in flight.)
+    tr_bf16x8_t wf[21];                                  // max over NT of (DEPTH + 1) * NT: 17, 18, 21
+    auto depth_of = [](int nt) constexpr -> int { return nt == 1 ? 16 : (nt == 2 ? 8 : 6); };
+    auto prefetch = [&](auto ntc, const void* W, int n_pad, int n0) __attribute__((always_inline)) {
+        constexpr int NT = decltype(ntc)::value, DEPTH = depth_of(NT);
+        const char* const wl = (const char*)W + ((size_t)hh * n_pad + n0 + r) * 16;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[d * NT + j] = __builtin_bit_cast(tr_bf16x8_t, *(const u32x4_t*)(wl + ((size_t)d * 2 * n_pad + j * 32) * 16));
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto gemm = [&](auto ntc, auto ksc, const char* A, int pitch, const void* W, int n_pad, int n0, tr_f32x16_t (&acc)[MT][decltype(ntc)::value])
                     __attribute__((always_inline)) {
         constexpr int NT = decltype(ntc)::value, KS = decltype(ksc)::value;
-        // fragment-major weights (repack_frag_kernel): the 16-byte fragments of K step ks, half hh, for all columns are
-        // contiguous, so a wave's load is two 512-byte runs.  (Read from the conv layout -- 128-byte rows -- every lane is
-        // its own 64-byte request: 64 requests per KB held all four GEMMs at 9-14 B/clk/CU whatever was in flight.)
+        constexpr int DEPTH = depth_of(NT), RING = DEPTH + 1;
+        static_assert(KS >= DEPTH, "ring depth");
         const char* const wl = (const char*)W + ((size_t)hh * n_pad + n0 + r) * 16;
         auto wfrag = [&](int ks, int j) __attribute__((always_inline)) -> tr_bf16x8_t {
             return __builtin_bit_cast(tr_bf16x8_t, *(const u32x4_t*)(wl + ((size_t)ks * 2 * n_pad + j * 32) * 16));
         };
-        // 16 KB of loads in flight per wave: 16 / 8 / 6 K steps ahead for 1 / 2 / 3 column tiles
-        constexpr int DEPTH0 = NT == 1 ? 16 : (NT == 2 ? 8 : 6);
-        constexpr int DEPTH = DEPTH0 < KS ? DEPTH0 : KS;
-        constexpr int RING = DEPTH + 1;
-        tr_bf16x8_t wf[RING][NT];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wf[d][j] = wfrag(d, j);
-        __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks the loads next to their uses: 3-4 in flight)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + DEPTH < KS) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) wf[(ks + DEPTH) % RING][j] = wfrag(ks + DEPTH, j);
+                for (int j = 0; j < NT; ++j) wf[((ks + DEPTH) % RING) * NT + j] = wfrag(ks + DEPTH, j);
             }
             __builtin_amdgcn_sched_barrier(0);
             tr_bf16x8_t af[MT];
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[ks % RING][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[(ks % RING) * NT + j], acc[i][j], 0, 0, 0);
         }
     };
     // GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result): a fifth of
@@ -201,6 +207,8 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     const std::integral_constant<int, 16> ks16{};
     const std::integral_constant<int, 32> ks32{};
 
+    if constexpr (MODE != 2) prefetch(nt3, a.wqkv, a.npad_qkv, wave * 96);
+    else prefetch(nt1, a.wproj, a.npad_proj, wave * 32);
     // LayerNorm parameters -> LDS, their loads in flight together with the input rows' (one round trip instead of three)
     for (int i = tid; i < 1280; i += 512)
         prm[i] = i < 256 ? a.ln_w[i] : (i < 512 ? a.ln_b[i - 256] : (i < 768 ? a.g0[i - 512] : a.g3[i - 768]));
@@ -215,13 +223,14 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
         tr_f32x16_t acc[MT][3];
         zero(acc);
         gemm(nt3, ks16, bufA, PA, a.wqkv, a.npad_qkv, wave * 96, acc);
+        if constexpr (MODE == 0) prefetch(nt1, a.wproj, a.npad_proj, wave * 32);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    *(unsigned short*)(bufQ + row_of(i, e) * PQ + (wave * 96 + j * 32 + r) * 2) = f32_to_bf16(acc[i][j][e]);
+                    *(unsigned short*)(bufQ + row_of(i, e) * PQ + (wave * 96 + j * 32 + r) * 2) = f32_to_bf16_hw(acc[i][j][e]);
     }
     __syncthreads();
     }
@@ -332,13 +341,14 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
         tr_f32x16_t acc[MT][1];
         zero(acc);
         gemm(nt1, ks16, bufA, PA, a.wproj, a.npad_proj, wave * 32, acc);
+        prefetch(nt2, a.wff1, a.npad_ff1, wave * 64);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row_of(i, e);
                 const float res = row < NTOK ? bf16_to_f32(xb[(size_t)row * C + wave * 32 + r].v) : 0.f;
-                x1r[i][e] = bf16_to_f32(f32_to_bf16(acc[i][0][e] + res));
+                x1r[i][e] = bf16_to_f32(f32_to_bf16_hw(acc[i][0][e] + res));
             }
     }
     __syncthreads();                                    // every wave is done reading att
@@ -346,7 +356,7 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) *(unsigned short*)(bufA + row_of(i, e) * PA + (wave * 32 + r) * 2) = f32_to_bf16(x1r[i][e]);
+        for (int e = 0; e < 16; ++e) *(unsigned short*)(bufA + row_of(i, e) * PA + (wave * 32 + r) * 2) = f32_to_bf16_hw(x1r[i][e]);
     __syncthreads();
 
     stamp(5);
@@ -360,13 +370,14 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
         tr_f32x16_t acc[MT][2];
         zero(acc);
         gemm(nt2, ks16, bufA, PA, a.wff1, a.npad_ff1, wave * 64, acc);
+        prefetch(nt1, a.wff2, a.npad_ff2, wave * 32);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    *(unsigned short*)(bufQ + row_of(i, e) * PF + (wave * 64 + j * 32 + r) * 2) = f32_to_bf16(gelu_fast(acc[i][j][e]));
+                    *(unsigned short*)(bufQ + row_of(i, e) * PF + (wave * 64 + j * 32 + r) * 2) = f32_to_bf16_hw(gelu_fast(acc[i][j][e]));
     }
     __syncthreads();
 
@@ -387,7 +398,7 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row_of(i, e);
-                const unsigned short q = f32_to_bf16(acc[i][0][e] + x1r[i][e]);
+                const unsigned short q = f32_to_bf16_hw(acc[i][0][e] + x1r[i][e]);
                 *(unsigned short*)(bufA + row * PA + (wave * 32 + r) * 2) = q;
                 if (row < NTOK) { const float v = bf16_to_f32(q); s1 += v; s2 = fmaf(v, v, s2); }
             }
