@@ -62,12 +62,23 @@ __global__ void __launch_bounds__(512) conv_gemm_tile_kernel(const GemmArgs a, i
         auto wfrag = [&](int ks) __attribute__((always_inline)) -> bf16x8_t {
             return __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(wl + (size_t)ks * 2 * N * 16));
         };
-        constexpr int DEPTH = 16 < KS ? 16 : KS;
+        constexpr int DEPTH = 15 < KS ? 15 : KS;         // 15 KB of weight loads in flight per wave; RING even: A-fragment parity is static
         constexpr int RING = DEPTH + 1;
+        static_assert(RING % 2 == 0, "ring");
         bf16x8_t wf[RING];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) wf[d] = wfrag(d);
         __builtin_amdgcn_sched_barrier(0);
+        // A fragments one K step ahead (their LDS latency would otherwise sit between every load and its four MFMAs)
+        auto afrag = [&](int ks, bf16x8_t (&af)[MT]) __attribute__((always_inline)) {
+            const int ct = ks >> 2, q = ks & 3;
+            const int chunk = ct / TAPS, tap = ct - chunk * TAPS;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *(const bf16x8_t*)(bufX + (rowbase + i * 32 + r + tap + row0) * PX + chunk * 128 + q * 32 + hh * 16);
+        };
+        bf16x8_t af[2][MT];
+        afrag(0, af[0]);
 #pragma unroll 1
         for (int kb = 0; kb < KS; kb += RING) {
 #pragma unroll
@@ -75,15 +86,10 @@ __global__ void __launch_bounds__(512) conv_gemm_tile_kernel(const GemmArgs a, i
                 const int ks = kb + u;
                 if (ks < KS) {
                     if (ks + DEPTH < KS) wf[(u + DEPTH) % RING] = wfrag(ks + DEPTH);
+                    if (ks + 1 < KS) afrag(ks + 1, af[(u + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int ct = ks >> 2, q = ks & 3;
-                    const int chunk = ct / TAPS, tap = ct - chunk * TAPS;
-                    bf16x8_t af[MT];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        af[i] = *(const bf16x8_t*)(bufX + (rowbase + i * 32 + r + tap + row0) * PX + chunk * 128 + q * 32 + hh * 16);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[u], acc[i], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][i], wf[u], acc[i], 0, 0, 0);
                 }
             }
         }

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
     // The ring of weight fragments lives across the stages: `prefetch(W)` issues the first 16 K steps of a GEMM (16 KB per wave)
     // and is called BEFORE the phase that precedes that GEMM (parameter loads, prologue, the previous GEMM's epilogue), so
     // the weight stream -- the floor of this kernel -- keeps running through the vector-only phases.
-    constexpr int DEPTH = 16, RING = DEPTH + 1;
+    constexpr int DEPTH = 15, RING = DEPTH + 1;          // RING even: the parity of the A-fragment double buffer is static
     rb_bf16x8_t wf[RING];
     auto wptr = [&](const void* W, int n0) __attribute__((always_inline)) -> const char* { return (const char*)W + ((size_t)hh * CO + n0 + r) * 16; };
     auto prefetch = [&](const void* W, int n0) __attribute__((always_inline)) {
@@ -103,6 +103,15 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
             return __builtin_bit_cast(rb_bf16x8_t, *(const u32x4_t*)(wl + (size_t)ks * 2 * CO * 16));
         };
         __builtin_amdgcn_sched_barrier(0);
+        // A fragments one K step ahead (their LDS latency would otherwise sit between every load and its MFMAs)
+        auto afrag = [&](int ks, rb_bf16x8_t (&af)[MT]) __attribute__((always_inline)) {
+            const int ct = ks >> 2, q = ks & 3;           // (chunk, tap) pair in packed order, K step inside the chunk
+            const int chunk = ct / TAPS, tap = ct - chunk * TAPS;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *(const rb_bf16x8_t*)(A + (i * 32 + r + tap + row0) * pitch + chunk * 128 + q * 32 + hh * 16);
+        };
+        rb_bf16x8_t af[2][MT];
+        afrag(0, af[0]);
 #pragma unroll 1
         for (int kb = 0; kb < KS; kb += RING) {           // RING K steps per trip, so that ring slots are compile-time registers
 #pragma unroll
@@ -110,15 +119,10 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
                 const int ks = kb + u;
                 if (ks < KS) {
                     if (ks + DEPTH < KS) wf[(u + DEPTH) % RING] = wfrag(ks + DEPTH);
+                    if (ks + 1 < KS) afrag(ks + 1, af[(u + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int ct = ks >> 2, q = ks & 3;   // (chunk, tap) pair in packed order, K step inside the chunk
-                    const int chunk = ct / TAPS, tap = ct - chunk * TAPS;
-                    rb_bf16x8_t af[MT];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        af[i] = *(const rb_bf16x8_t*)(A + (i * 32 + r + tap + row0) * pitch + chunk * 128 + q * 32 + hh * 16);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[u], acc[i], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][i], wf[u], acc[i], 0, 0, 0);
                 }
             }
         }

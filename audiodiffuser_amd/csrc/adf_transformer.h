@@ -168,20 +168,24 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
             return __builtin_bit_cast(tr_bf16x8_t, *(const u32x4_t*)(wl + ((size_t)ks * 2 * n_pad + j * 32) * 16));
         };
         __builtin_amdgcn_sched_barrier(0);
+        tr_bf16x8_t af[2][MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[0][i] = *(const tr_bf16x8_t*)(A + (i * 32 + r) * pitch + hh * 16);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + DEPTH < KS) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) wf[((ks + DEPTH) % RING) * NT + j] = wfrag(ks + DEPTH, j);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            tr_bf16x8_t af[MT];
+            if (ks + 1 < KS) {                           // A fragments one K step ahead
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *(const tr_bf16x8_t*)(A + (i * 32 + r) * pitch + ks * 32 + hh * 16);
+                for (int i = 0; i < MT; ++i) af[(ks + 1) & 1][i] = *(const tr_bf16x8_t*)(A + (i * 32 + r) * pitch + (ks + 1) * 32 + hh * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[(ks % RING) * NT + j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], wf[(ks % RING) * NT + j], acc[i][j], 0, 0, 0);
         }
     };
     // GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result): a fifth of
