@@ -54,7 +54,7 @@ struct Slot {
     void* frag = nullptr;    // also repacked to ConvW::wfrag after packing
     int64_t numel = 0;
     bool loaded = false;
-    int cout = 0, cin = 0, K = 0, f = 0, n_offset = 0, n_pad = 0, nchunk = 0;
+    int cout = 0, cin = 0, K = 0, f = 0, n_offset = 0, n_pad = 0, nchunk = 0, taps = 0;
 };
 
 struct Act { void* p = nullptr; int C = 0, L = 0; double* stats = nullptr; };
@@ -152,7 +152,7 @@ struct Registrar {
         }
         w.cout = cout;
         Slot s; s.kind = transposed ? 2 : 1; s.dst = w.w; s.numel = (int64_t)cout * cin * K;
-        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = n_offset; s.n_pad = w.n_pad; s.nchunk = w.nchunk;
+        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = n_offset; s.n_pad = w.n_pad; s.nchunk = w.nchunk; s.taps = w.taps;
         h->names.push_back(name); h->slots[name] = s;
     }
     void conv(const std::string& pre, ConvW& w, int cout, int cin, int K, bool bias) {
@@ -171,7 +171,7 @@ struct Registrar {
         if (!w.w) { ok = false; return; }
         w.cout = cout;
         Slot s; s.kind = 3; s.dst = w.w; s.numel = (int64_t)cout * cin * K;
-        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = 0; s.n_pad = w.n_pad; s.nchunk = w.nchunk;
+        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = 0; s.n_pad = w.n_pad; s.nchunk = w.nchunk; s.taps = w.taps;
         h->names.push_back(pre + ".weight"); h->slots[pre + ".weight"] = s;
         w.bias = reg_f32(pre + ".bias", cout);
     }
@@ -279,6 +279,11 @@ int build_weights(adf_handle* h) {
         if (up.attn) R.transformer(pre + ".transformer", up.tr, up.cin, c.attention_multiplier);
         const int f = up.factor;
         R.reg_pack(pre + ".upsample.weight", up.up, up.cout, up.cin, 2 * f, 0, f * up.cout, true, f);
+        if (h->bf16 && up.up.w && (up.cin == 128 || up.cin == 256) && (up.cout == 64 || up.cout == 128 || up.cout == 256) && (f == 2 || f == 4)) {
+            up.up.wfrag = dalloc(h, (size_t)up.up.nchunk * up.up.taps * up.up.n_pad * kRowBytes);   // fragment-major copy: adf_gemm_up.h
+            if (!up.up.wfrag) R.ok = false;
+            else h->slots[pre + ".upsample.weight"].frag = up.up.wfrag;
+        }
         up.up.bias = R.reg_f32(pre + ".upsample.bias", up.cout);
     }
     // one concatenated FiLM projection for all resblocks
@@ -1160,7 +1165,8 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
                                            sl.n_pad, sl.nchunk, s);
         if (e) return fail(h, e);
         if (sl.frag) {
-            e = launch_repack_frag(sl.dst, sl.frag, sl.n_offset, sl.cout, sl.n_pad, sl.nchunk * sl.K, s);   // K taps of a plain conv / linear
+            // rows of this tensor: cout (conv / linear) or f * cout phase-major rows (transposed conv)
+            e = launch_repack_frag(sl.dst, sl.frag, sl.n_offset, sl.kind == 2 ? sl.f * sl.cout : sl.cout, sl.n_pad, sl.nchunk * sl.taps, s);
             if (e) return fail(h, e);
         }
     }

@@ -2,6 +2,7 @@
 #include "adf_gemm.h"
 #include "adf_gemm_pp.h"
 #include "adf_gemm_tile.h"
+#include "adf_gemm_up.h"
 #include "adf_kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +89,35 @@ const char* launch_tile(const GemmArgs& a, hipStream_t stream) {
     const long long grid = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), Cfg::kLds, stream, a, (int)tiles, tps);
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_tile: launch failed";
+}
+
+// Transposed-conv kernel (adf_gemm_up.h): persistent 512-thread workgroups over tiles of m = 0 .. L
+template <int CIN, int COUT, int F, int MTP>
+const char* launch_up_mt(const GemmArgs& a, hipStream_t stream) {
+    typedef UpCfg<CIN, COUT, F, MTP> Cfg;
+    static bool attr_set = false;
+    auto kern = conv_gemm_up_kernel<CIN, COUT, F, MTP>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, up) failed";
+        attr_set = true;
+    }
+    static_assert(Cfg::kLds <= 160 * 1024, "up kernel LDS budget");
+    const int tps = (a.mrows + Cfg::TM - 1) / Cfg::TM;
+    const long long items = (long long)a.B * tps * Cfg::NPASS;
+    if (items <= 0 || items > 0x7fffffffLL) return "conv_gemm_up: bad tile count";
+    const long long grid = items < 256 ? items : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), Cfg::kLds, stream, a, (int)items, tps);
+    return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_up: launch failed";
+}
+// tile height: the one that needs fewer rounds of 256 workgroups; ties go to the taller tile (weights are re-read per tile)
+template <int CIN, int COUT, int F>
+const char* launch_up(const GemmArgs& a, hipStream_t stream) {
+    auto rounds = [&](int tm, int npass) { return ((long long)a.B * ((a.mrows + tm - 1) / tm) * npass + 255) / 256; };
+    typedef UpCfg<CIN, COUT, F, 2> C2;
+    typedef UpCfg<CIN, COUT, F, 4> C4;
+    if (rounds(C4::TM, C4::NPASS) <= rounds(C2::TM, C2::NPASS)) return launch_up_mt<CIN, COUT, F, 4>(a, stream);
+    return launch_up_mt<CIN, COUT, F, 2>(a, stream);
 }
 
 // Persistent LDS-DMA kernel (adf_gemm_pp.h): one 512-thread block per CU, block tile (128 MT) x 128.
@@ -280,6 +310,36 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
                         (!flat || a.mrows % rpk == 0);
         if (!ok) a.stats = nullptr;
         else if (stats_fused) *stats_fused = true;
+    }
+    {
+        // transposed convs of the up path in bf16 (adf_gemm_up.h); ADF_GEMM_UP=0 leaves them to the plain / weight-stationary kernels
+        static int use_up = -1;
+        if (use_up < 0) { const char* e = getenv("ADF_GEMM_UP"); use_up = e ? atoi(e) : 1; }
+        const GemmSeg& g = a.seg[0];
+        const int f = a.scatter_f, cout = a.out_c, cin = g.c0;
+        if (use_up && dtype_bf16 && (f == 2 || f == 4) && a.nseg == 1 && g.taps == 2 && g.stride == 1 && g.off0 == 0 && g.step == -1 && !g.ab &&
+            !gn_pending && !g.act && g.scale1 == 1.0f && g.wfrag && g.c1 == 0 && a.n == f * cout && a.n == a.n_pad && a.mrows == a.lin + 1 &&
+            a.out_rows == a.lin * f && a.scatter_pad == f / 2 && a.bias_mod == cout && !a.res && !a.gelu && !a.bias1 &&
+            (!a_in.stats || a.stats_groups == 8)) {
+            int cfg = 0;
+            // measured (us per launch, this kernel vs the plain / weight-stationary route): 256 -> 256 x4 at L = 16 / 64 / 256: 28 each vs
+            // 17 / 27 / 65; 256 -> 128 x2 at L = 1024: 47 vs 66; 128 -> 128 x2 at L = 2048 and 128 -> 64 x2 at L = 4096: 57 / 53 vs 57 / 53
+            // (their tiles are bound by the per-CU HBM fetch rate, which this kernel does not overlap with the MFMAs): those two
+            // stay on the old routes unless ADF_GEMM_UP=2
+            if (cin == 256 && cout == 256 && f == 4) cfg = 1;
+            else if (cin == 256 && cout == 128 && f == 2) cfg = 2;
+            else if (use_up >= 2 && cin == 128 && cout == 128 && f == 2) cfg = 3;
+            else if (use_up >= 2 && cin == 128 && cout == 64 && f == 2) cfg = 4;
+            if (cfg) {
+                a.stats = a_in.stats;
+                if (stats_fused && a_in.stats) *stats_fused = true;
+                trace_route("up", a, 64, 256);
+                if (cfg == 1) return launch_up<256, 256, 4>(a, stream);
+                if (cfg == 2) return launch_up<256, 128, 2>(a, stream);
+                if (cfg == 3) return launch_up<128, 128, 2>(a, stream);
+                return launch_up<128, 64, 2>(a, stream);
+            }
+        }
     }
     {
         // short levels (few rows, long K): intra-block split-K, 32 x 32 tiles, 4 waves x K/4 each

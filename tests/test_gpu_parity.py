@@ -237,6 +237,27 @@ def test_pipelined_dma_gemm_route_matches_plain_routes(tmp_path, batch, pp):
     assert rel("out") < 3e-2, rel("out")
 
 
+def test_transposed_conv_kernel_matches_the_generic_routes(tmp_path):
+    """adf_gemm_up.h (bf16 up-path transposed convs, all four shapes with ADF_GEMM_UP=2) against the plain / weight-stationary
+    routes (ADF_GEMM_UP=0): same K order, so single-tile levels agree bit for bit and the others to accumulation noise."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "2"):
+        path = str(tmp_path / f"up{mode}.pt")
+        env = dict(os.environ, ADF_GEMM_UP=mode, B="5")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(path)
+    a, b = outs["2"], outs["0"]
+    assert all(bool(torch.isfinite(v).all()) for v in a.values())
+    rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
+    for k in ("up0.conv", "up1.conv", "up2.conv", "up3.conv", "up4.conv", "up5.conv"):
+        assert rel(k) < 6e-3, (k, rel(k))
+    assert rel("out") < 2e-2, rel("out")
+
+
 @pytest.mark.parametrize("classes", ["", "1"])
 def test_fused_short_level_resblock_matches_the_unfused_launches(tmp_path, classes):
     """adf_resblock_small.h (one launch per ResnetBlock1d at the 64- and 16-position levels, bf16 mode; identity and 1x1-conv
