@@ -80,10 +80,13 @@ struct GnFinalizeArgs {
     const float* film2; int film2_bstride;         // optional second addend (class-embedding part of the projection)
     float* ab;                                     // [B][c0+c1][2] (gn_finalize only)
 };
-// FAST (bf16 throughput mode, inside a GEMM kernel's start-up path): no fp64 division / square root -- the variance is still
-// formed in fp64 (cancellation), the reciprocal square root in fp32 with one Newton step (~1e-7 relative).
-template <bool FAST = false>
-__device__ __forceinline__ void gn_affine(const GnFinalizeArgs& a, int b, int c, float& A, float& Bc) {
+// The computation is split in two so that a kernel can issue the loads, do other work (its first DMAs), and finish later:
+// gn_affine_load only loads, gn_affine_finish only computes.
+struct GnRaw {
+    double sum, sq;          // statistics of the (coarse) group, summed over its stored fine groups
+    float gamma, beta, fs, fh;
+};
+__device__ __forceinline__ GnRaw gn_affine_load(const GnFinalizeArgs& a, int b, int c) {
     const int ctot = a.c0 + a.c1;
     const int gs = ctot / a.G;
     const int cstart = (c / gs) * gs;
@@ -93,10 +96,31 @@ __device__ __forceinline__ void gn_affine(const GnFinalizeArgs& a, int b, int c,
     const int lc = s1 ? cstart - a.c0 : cstart;
     const int fg = csrc / a.G;                // channels per stored (fine) group
     const int g0 = lc / fg, g1 = (lc + gs + fg - 1) / fg;
-    double sum = 0.0, sq = 0.0;
-    for (int g = g0; g < g1; ++g) { sum += st[((size_t)b * a.G + g) * 2]; sq += st[((size_t)b * a.G + g) * 2 + 1]; }
+    GnRaw r;
+    r.sum = 0.0; r.sq = 0.0;
+    for (int g = g0; g < g1; ++g) { r.sum += st[((size_t)b * a.G + g) * 2]; r.sq += st[((size_t)b * a.G + g) * 2 + 1]; }
+    r.gamma = a.gamma[c];
+    r.beta = a.beta[c];
+    r.fs = 1.0f; r.fh = 0.0f;
+    if (a.film) {
+        r.fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
+        r.fh = a.film[(size_t)b * a.film_bstride + ctot + c];
+        if (a.film2) {      // class-embedding part of the FiLM projection (precomputed per sampler run)
+            r.fs += a.film2[(size_t)b * a.film2_bstride + c];
+            r.fh += a.film2[(size_t)b * a.film2_bstride + ctot + c];
+        }
+    }
+    return r;
+}
+// FAST (bf16 throughput mode, inside a GEMM kernel's start-up path): no fp64 division / square root -- the variance is still
+// formed in fp64 (cancellation), the reciprocal square root in fp32 with one Newton step (~1e-7 relative).
+template <bool FAST = false>
+__device__ __forceinline__ void gn_affine_finish(const GnFinalizeArgs& a, int c, const GnRaw& r, float& A, float& Bc) {
+    const int ctot = a.c0 + a.c1;
+    const int gs = ctot / a.G;
+    const bool s1 = (c / gs) * gs >= a.c0;
     const double sc = s1 ? (double)a.scale1 : 1.0;
-    sum *= sc; sq *= sc * sc;
+    const double sum = r.sum * sc, sq = r.sq * sc * sc;
     float rstd, meanf;
     if constexpr (FAST) {
         const double inv_cnt = (double)(1.0f / ((float)a.L * (float)gs));     // L * gs is a small power-of-two multiple: exact in fp32 for the shapes served
@@ -104,9 +128,9 @@ __device__ __forceinline__ void gn_affine(const GnFinalizeArgs& a, int b, int c,
         double var = sq * inv_cnt - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const float vf = (float)var + a.eps;
-        float r = __builtin_amdgcn_rsqf(vf);
-        r = r * (1.5f - 0.5f * vf * r * r);
-        rstd = r; meanf = (float)mean;
+        float q = __builtin_amdgcn_rsqf(vf);
+        q = q * (1.5f - 0.5f * vf * q * q);
+        rstd = q; meanf = (float)mean;
     } else {
         const double cnt = (double)a.L * (double)gs;
         const double mean = sum / cnt;
@@ -115,19 +139,17 @@ __device__ __forceinline__ void gn_affine(const GnFinalizeArgs& a, int b, int c,
         rstd = (float)(1.0 / sqrt(var + (double)a.eps));
         meanf = (float)mean;
     }
-    A = rstd * a.gamma[c];
-    Bc = a.beta[c] - meanf * A;
+    A = rstd * r.gamma;
+    Bc = r.beta - meanf * A;
     if (a.film) {
-        float fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
-        float fh = a.film[(size_t)b * a.film_bstride + ctot + c];
-        if (a.film2) {      // class-embedding part of the FiLM projection (precomputed per sampler run)
-            fs += a.film2[(size_t)b * a.film2_bstride + c];
-            fh += a.film2[(size_t)b * a.film2_bstride + ctot + c];
-        }
-        A *= fs;
-        Bc = fmaf(Bc, fs, fh);
+        A *= r.fs;
+        Bc = fmaf(Bc, r.fs, r.fh);
     }
     if (s1) A *= a.scale1;
+}
+template <bool FAST = false>
+__device__ __forceinline__ void gn_affine(const GnFinalizeArgs& a, int b, int c, float& A, float& Bc) {
+    gn_affine_finish<FAST>(a, c, gn_affine_load(a, b, c), A, Bc);
 }
 
 // SiLU = v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): 5 VALU ops, 2 of them transcendental

@@ -589,6 +589,8 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     }
     f32x4_t tab_v = {0.f, 0.f, 0.f, 0.f};
     if (use_tab && !gn_in && tid * 2 < ctot0) tab_v = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b_first * ctot0 + tid * 2) * 2);
+    GnRaw gr0 = {}, gr1 = {};                                                // statistics / gamma / beta / FiLM of this thread's two channels
+    if (gn_in && tid * 2 < ctot0) { gr0 = gn_affine_load(a.seg[0].gn, b_first, tid * 2); gr1 = gn_affine_load(a.seg[0].gn, b_first, tid * 2 + 1); }
     PpBlk dc = desc(0, 0);
     (void)issue_a(dc, 0, -1);
     issue_w(dc.w, 0);
@@ -599,8 +601,14 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
     for (int q = 0; q < (kPpMaxN + 511) / 512; ++q)
         if (tid + q * 512 < a.n_pad) ldsBias[tid + q * 512] = bias_v[q];
-    if (gn_in) fill_table(b_first, 0);
-    else if (use_tab && tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = tab_v;
+    if (gn_in) {
+        if (tid * 2 < ctot0) {
+            float A0, B0, A1, B1;
+            gn_affine_finish<true>(a.seg[0].gn, tid * 2, gr0, A0, B0);
+            gn_affine_finish<true>(a.seg[0].gn, tid * 2 + 1, gr1, A1, B1);
+            *(f32x4_t*)(ldsTab + tid * 16) = f32x4_t{A0, B0, A1, B1};
+        }
+    } else if (use_tab && tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = tab_v;
     pstamp(19);
     wait_dma(0);
     pstamp(20);
