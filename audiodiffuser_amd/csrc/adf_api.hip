@@ -965,6 +965,42 @@ int run_dpm_single(SamplerCtx& c, float** result) {
     return 0;
 }
 
+// DPM2MSampler: sampler_edm.py:1111-1131 (num_steps updates over sigmas[i], sigmas[i + 1]; the schedule must hold num_steps + 1
+// entries -- with fewer the reference raises IndexError), :1072-1109 (step), fp32 scalars on the host
+int run_dpm2m(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int N = d.num_steps;
+    if (N < 1 || c.nsig < N + 1) return c.count_only ? 1 : fail(c.h, "DPM2MSampler: the schedule must hold num_steps + 1 sigmas (the reference indexes sigmas[i + 1])");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* D[2] = {c.count_only ? nullptr : p->sb[5], c.count_only ? nullptr : p->sb[6]};
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    for (int i = 0; i < N; ++i) {
+        const float sg = c.sig[i], sn = c.sig[i + 1];
+        float* den = D[i & 1];
+        const float* old = i > 0 ? D[(i + 1) & 1] : nullptr;
+        if (c.den(X, sg, den)) return 1;
+        const float t = -logf(sg), tn = -logf(sn);
+        const float h = tn - t;
+        const float ratio = fminf(expf(-tn), expf(-t)) / fmaxf(expf(-tn), expf(-t));
+        if (!old || sn == 0.0f) {
+            if (!c.count_only && c.ck(launch_dpm2m(XN, X, den, nullptr, ratio, expm1f(-h), 1.f, 0.f, c.n, c.s))) return 1;
+        } else {
+            const float h_last = t - (-logf(c.sig[i - 1]));
+            const float h_min = fminf(h_last, h), h_max = fmaxf(h_last, h);
+            const float r = h_max / h_min;
+            const float h_d = (h_max + h_min) / 2.0f;
+            const float c2 = 1.0f / (2.0f * r);
+            if (!c.count_only && c.ck(launch_dpm2m(XN, X, den, old, ratio, expm1f(-h_d), 1.0f + c2, c2, c.n, c.s))) return 1;
+        }
+        std::swap(X, XN);
+    }
+    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
+    *result = X;
+    return 0;
+}
+
 // LMSSampler.linear_multistep_coeff (sampler_edm.py:1149-1160): the integral over [t_i, t_{i+1}] of the Lagrange basis
 // polynomial of node t_{i-j} among t_i .. t_{i-order+1}.  Degree <= 3, so 3-point Gauss-Legendre in double is exact (the
 // reference integrates numerically with scipy quad to 1e-4 relative).
@@ -1099,6 +1135,7 @@ int run_sampler(SamplerCtx& c, float** result) {
         case ADF_SAMPLER_DPM_MULTISTEP: return run_dpm(c, result);
         case ADF_SAMPLER_DPM_SINGLESTEP: return run_dpm_single(c, result);
         case ADF_SAMPLER_LMS: return run_lms(c, result);
+        case ADF_SAMPLER_DPM2M: return run_dpm2m(c, result);
         default: return c.count_only ? 1 : fail(c.h, "unknown sampler kind");
     }
 }

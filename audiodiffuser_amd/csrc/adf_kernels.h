@@ -78,6 +78,9 @@ struct DpmArgs {
 };
 const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st);
 // x_next = x_base + ((x_eval - den) / sigma) * dt  (DPM2 / ancestral DPM2 steps)
+// DPM2MSampler update: out = ratio*x - coef*(c1*d - c2*d_old) (d_old may be null: out = ratio*x - coef*d)
+const char* launch_dpm2m(float* out, const float* x, const float* d, const float* d_old, float ratio, float coef, float c1, float c2, long long n,
+                         hipStream_t s);
 // LMSSampler: newest derivative d = (x - den) / sigma -> dcur; x += c[0]*d + c[1]*d1 + c[2]*d2 + c[3]*d3 (first `order` terms)
 struct LmsArgs { float* dcur; const float* d1; const float* d2; const float* d3; float c[4]; int order; };
 const char* launch_lms(float* x, const float* den, float sigma, const LmsArgs& a, long long n, hipStream_t s);

@@ -933,6 +933,15 @@ __global__ void __launch_bounds__(256) lincomb_kernel(float* out, const float* x
         out[i] = v;
     }
 }
+// DPM-Solver++(2M) update (sampler_edm.py:1096-1107): out = ratio*x - coef*(c1*d - c2*d_old); first step / final sigma 0: d_old null
+__global__ void __launch_bounds__(256) dpm2m_kernel(float* out, const float* x, const float* d, const float* d_old, float ratio, float coef,
+                                                    float c1, float c2, long long n) {
+    ADF_EW_LOOP {
+        float v = d[i];
+        if (d_old) v = c1 * v - c2 * d_old[i];
+        out[i] = ratio * x[i] - coef * v;
+    }
+}
 __global__ void __launch_bounds__(256) rk2_kernel(float* xn, const float* x, const float* d, const float* xe, const float* den2,
                                                   float sigma2, float h, float w1, float w2, long long n) {
     ADF_EW_LOOP { const float d2 = (xe[i] - den2[i]) / sigma2; xn[i] = x[i] + h * (w1 * d[i] + w2 * d2); }
@@ -978,6 +987,11 @@ const char* launch_rk2(float* x_next, const float* x, const float* d, const floa
 const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st) {
     hipLaunchKernelGGL(dpm_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x_out, x, a, clamp, n);
     return ADF_LAUNCH_CHECK("dpm_update");
+}
+const char* launch_dpm2m(float* out, const float* x, const float* d, const float* d_old, float ratio, float coef, float c1, float c2, long long n,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(dpm2m_kernel, dim3(ew_grid(n)), dim3(256), 0, st, out, x, d, d_old, ratio, coef, c1, c2, n);
+    return ADF_LAUNCH_CHECK("dpm2m");
 }
 const char* launch_lms(float* x, const float* den, float sigma, const LmsArgs& a, long long n, hipStream_t st) {
     hipLaunchKernelGGL(lms_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, den, sigma, a, n);

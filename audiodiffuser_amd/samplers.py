@@ -261,6 +261,54 @@ class DPMSampler(nn.Module):
         return x.clamp(-1.0, 1.0)
 
 
+class DPM2MSampler(nn.Module):
+    """'DPM-Solver++(2M) Karras' (sampler_edm.py:1056-1131).  The loop reads ``sigmas[i + 1]`` for ``i < num_steps``: the schedule
+    must hold ``num_steps + 1`` entries (a final 0 returns the last denoised estimate); with the module's own N-entry schedule the
+    reference raises IndexError on its last step, and so does this class."""
+
+    def __init__(self, num_steps: int = 50, cond_scale: float = 1.0, use_graph: bool = True):
+        super().__init__()
+        self.num_steps, self.cond_scale, self.use_graph = num_steps, cond_scale, use_graph
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_DPM2M, int(self.num_steps)
+        d.s_tmin = d.s_tmax = d.s_churn = 0.0
+        d.s_noise = 1.0
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, 2, sigma_data, int(self.use_graph)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
+        if len(sigmas) < self.num_steps + 1:
+            raise IndexError(f"index {self.num_steps} is out of bounds for dimension 0 with size {len(sigmas)}")
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
+        # ---- interface-compatibility branch --------------------------------------------------------
+        x = sigmas[0] * noise
+        old = None
+        for i in range(self.num_steps):
+            s_last, s, s_next = sigmas[i - 1], sigmas[i], sigmas[i + 1]
+            den = fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)
+            t, t_next = s.log().neg(), s_next.log().neg()
+            h = t_next - t
+            t_min, t_max = min(t_next.neg().exp(), t.neg().exp()), max(t_next.neg().exp(), t.neg().exp())
+            if old is None or s_next == 0:
+                x = (t_min / t_max) * x - (-h).expm1() * den
+            else:
+                h_last = t - s_last.log().neg()
+                h_min, h_max = min(h_last, h), max(h_last, h)
+                r = h_max / h_min
+                h_d = (h_max + h_min) / 2
+                x = (t_min / t_max) * x - (-h_d).expm1() * ((1 + 1 / (2 * r)) * den - (1 / (2 * r)) * old)
+            old = den
+        return x.clamp(-1.0, 1.0)
+
+
 class LMSSampler(nn.Module):
     """'LMS Karras' linear multistep solver (sampler_edm.py:1134-1190): ``num_steps - 1`` evaluations, the last ``order``
     derivatives combined with the integrals of their Lagrange basis polynomials over the step (the reference integrates

@@ -59,6 +59,7 @@ typedef struct adf_net_config {
 #define ADF_SAMPLER_DPM2 3      /* DPM2Sampler ("DPM2 Karras", optional churn)   sampler_edm.py:401-493 */
 #define ADF_SAMPLER_ADPM2 4     /* ADPM2Sampler ("DPM2 a Karras", ancestral)     stochastic_sampler_edm.py:35-100 */
 #define ADF_SAMPLER_LMS 5       /* LMSSampler ("LMS Karras"), order 1..4         sampler_edm.py:1134-1190 */
+#define ADF_SAMPLER_DPM2M 7     /* DPM2MSampler ("DPM-Solver++(2M) Karras"); needs num_steps + 1 sigmas   sampler_edm.py:1056-1131 */
 #define ADF_SAMPLER_DPM_SINGLESTEP 6 /* DPMSampler(multisteps=False, x0_pred=True) sampler_edm.py:568-622, :769-805 */
 
 typedef struct adf_sampler_desc {

@@ -44,11 +44,11 @@ def import_reference():
     from src.models.components.diffusion import EluDiffusion
     from src.models.components.sampler_edm import EDMSampler, EDMAlphaSampler, DPMSampler
     from src.models.components.scheduler import KarrasSchedule
-    from src.models.components.sampler_edm import DPM2Sampler, LMSSampler
+    from src.models.components.sampler_edm import DPM2Sampler, LMSSampler, DPM2MSampler
     from src.models.components.stochastic_sampler_edm import ADPM2Sampler
     return dict(UNet1dBase=UNet1dBase, EluDiffusion=EluDiffusion, EDMSampler=EDMSampler,
                 EDMAlphaSampler=EDMAlphaSampler, DPMSampler=DPMSampler, KarrasSchedule=KarrasSchedule,
-                DPM2Sampler=DPM2Sampler, ADPM2Sampler=ADPM2Sampler, LMSSampler=LMSSampler)
+                DPM2Sampler=DPM2Sampler, ADPM2Sampler=ADPM2Sampler, LMSSampler=LMSSampler, DPM2MSampler=DPM2MSampler)
 
 
 def build_ref_net(ref, cfg, weights):
@@ -387,6 +387,16 @@ def main():
                                   log_time_spacing=True)(noise, fn=diff.denoise_fn, net=net, sigmas=sg)
             yo = S.dpm_multistep_sampler(noise, fn_o, sg, 10, order=order, log_time_spacing=True)
             more[f"dpm_multi_log_o{order}"] = rel_err(yo, y); out[f"smp_dpm_multi_log_o{order}_final"] = y.numpy()
+        # DPM-Solver++(2M): needs num_steps + 1 sigmas -- an 11-entry Karras schedule, and a 10-entry one with a final 0
+        for tag, sg2m in (("k11", E.karras_sigmas(0.002, 80.0, 7.0, 11)), ("k10_zero", torch.cat([sg, torch.zeros(1)]))):
+            y = ref["DPM2MSampler"](num_steps=10)(noise, fn=diff.denoise_fn, net=net, sigmas=sg2m)
+            yo = S.dpm2m_sampler(noise, fn_o, sg2m, 10)
+            more[f"dpm2m_{tag}"] = rel_err(yo, y); out[f"smp_dpm2m_{tag}_final"] = y.numpy()
+        try:
+            ref["DPM2MSampler"](num_steps=10)(noise, fn=diff.denoise_fn, net=net, sigmas=sg)
+            raise AssertionError("the reference was expected to index past a 10-entry schedule")
+        except IndexError:
+            pass
     assert max(more.values()) < 5e-4, more
     report["lms_dpm_single_samplers"] = more
 

@@ -175,6 +175,31 @@ def dpm_singlestep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tens
     return x.clamp(-1.0, 1.0)
 
 
+def dpm2m_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int) -> torch.Tensor:
+    """DPM2MSampler ('DPM-Solver++(2M) Karras', sampler_edm.py:1056-1131): num_steps updates, each reading sigmas[i + 1] -- the
+    schedule must hold num_steps + 1 entries (with the module's own N-entry schedule the reference raises IndexError on its last
+    step; kept).  A final sigma of 0 returns the last denoised estimate (:1098); final clamp."""
+    x = sigmas[0] * noise
+    old = None
+    for i in range(num_steps):
+        s_last, s, s_next = sigmas[i - 1], sigmas[i], sigmas[i + 1]
+        den = fn(x, sigma=s)
+        t, t_next = s.log().neg(), s_next.log().neg()
+        h = t_next - t
+        t_min, t_max = min(t_next.neg().exp(), t.neg().exp()), max(t_next.neg().exp(), t.neg().exp())
+        if old is None or s_next == 0:
+            x = (t_min / t_max) * x - (-h).expm1() * den
+        else:
+            h_last = t - s_last.log().neg()
+            h_min, h_max = min(h_last, h), max(h_last, h)
+            r = h_max / h_min
+            h_d = (h_max + h_min) / 2
+            den_d = (1 + 1 / (2 * r)) * den - (1 / (2 * r)) * old
+            x = (t_min / t_max) * x - (-h_d).expm1() * den_d
+        old = den
+    return x.clamp(-1.0, 1.0)
+
+
 def lms_coeff(order: int, t, i: int, j: int) -> float:
     """LMSSampler.linear_multistep_coeff (sampler_edm.py:1149-1160): integral over [t_i, t_{i+1}] of the Lagrange basis
     polynomial of node t_{i-j} among t_i .. t_{i-order+1} (scipy quad, epsrel 1e-4, as in the reference)."""

@@ -413,6 +413,13 @@ def test_lms_and_dpm_variants_vs_reference_golden(golden, graph):
         for _ in range(2):
             y = smp(noise, fn=d.denoise_fn, net=net, sigmas=sched(n))
             assert rel_err(y.cpu(), T(golden[key])) < FP32_TOL, key
+    # DPM-Solver++(2M): num_steps + 1 sigmas (an 11-entry schedule; a 10-entry one with a final 0); IndexError as in the reference otherwise
+    for tag, sg2m in (("k11", sched(11)), ("k10_zero", torch.cat([sched(10), torch.zeros(1)]))):
+        for _ in range(2):
+            y = A.DPM2MSampler(num_steps=10, use_graph=graph)(noise, fn=d.denoise_fn, net=net, sigmas=sg2m)
+            assert rel_err(y.cpu(), T(golden[f"smp_dpm2m_{tag}_final"])) < FP32_TOL, tag
+    with pytest.raises(IndexError):
+        A.DPM2MSampler(num_steps=10)(noise, fn=d.denoise_fn, net=net, sigmas=sched(10))
 
 
 def test_new_sampler_nfe_counts():

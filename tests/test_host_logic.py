@@ -172,6 +172,11 @@ def test_lms_and_dpm_variants_compat_branch(golden):
         for order in (3, 2):
             y = A.DPMSampler(1.0, order=order, num_steps=10, multisteps=True, log_time_spacing=True)(noise, fn=fn, net=None, sigmas=sig)
             assert rel(y, T(golden[f"smp_dpm_multi_log_o{order}_final"])) < 5e-4
+        for tag, sg2m in (("k11", A.KarrasSchedule(0.002, 80.0, 7.0, 11)()), ("k10_zero", torch.cat([sig, torch.zeros(1)]))):
+            y = A.DPM2MSampler(num_steps=10)(noise, fn=fn, net=None, sigmas=sg2m)
+            assert rel(y, T(golden[f"smp_dpm2m_{tag}_final"])) < 5e-4, tag
+        with pytest.raises(IndexError):
+            A.DPM2MSampler(num_steps=10)(noise, fn=fn, net=None, sigmas=sig)
 
 
 def test_lms_coefficients_match_scipy_quad():
