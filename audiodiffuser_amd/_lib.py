@@ -43,7 +43,7 @@ class AdfSamplerDesc(C.Structure):
         ("kind", C.c_int32), ("num_steps", C.c_int32),
         ("s_tmin", C.c_float), ("s_tmax", C.c_float), ("s_churn", C.c_float), ("s_noise", C.c_float),
         ("use_heun", C.c_int32), ("alpha", C.c_float), ("order", C.c_int32), ("sigma_data", C.c_float),
-        ("use_graph", C.c_int32), ("rho", C.c_float), ("eta", C.c_float), ("log_time_spacing", C.c_int32),
+        ("use_graph", C.c_int32), ("rho", C.c_float), ("eta", C.c_float), ("log_time_spacing", C.c_int32), ("eps_pred", C.c_int32),
     ]
 
 

@@ -741,6 +741,12 @@ struct SamplerCtx {
         return denoise_scalar(h, p, x, sigma, d->sigma_data, out, s);
     }
     int ck(const char* e) { if (e) { h->err = e; return 1; } return 0; }
+    // DPMSampler.model_fn (sampler_edm.py:692-708): the denoised estimate, or with eps_pred the noise prediction (x - D) / sigma
+    int model(const float* x, float sigma, float* out) {
+        if (den(x, sigma, out)) return 1;
+        if (d->eps_pred && !count_only) return ck(launch_eps(out, x, sigma, n, s));
+        return 0;
+    }
 };
 
 // returns the buffer holding the final sample through *result
@@ -857,7 +863,8 @@ int run_dpm(SamplerCtx& c, float** result) {
     if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
     // history of grid values: index 0 = most recent
     float sh[3] = {G.g[0], 0.f, 0.f};
-    if (c.den(X, G.sig(G.g[0]), M[0])) return 1;
+    const bool eps = d.eps_pred != 0;
+    if (c.model(X, G.sig(G.g[0]), M[0])) return 1;
     for (int step = 1; step <= steps; ++step) {
         const int ord = step < order ? step : std::min(order, steps + 1 - step);
         const float sc = G.g[step];
@@ -865,8 +872,11 @@ int run_dpm(SamplerCtx& c, float** result) {
         DpmArgs a;
         memset(&a, 0, sizeof(a));
         a.order = ord;
-        a.ratio = G.sig(sc) / G.sig(sh[0]);
-        a.phi1 = expm1f(-hcur);
+        a.ratio = eps ? 1.0f : G.sig(sc) / G.sig(sh[0]);
+        const float scur = G.sig(sc);
+        // noise-prediction forms (:640-645, :660-662, :685-689): x - (s phi1) m0 - 0.5 (s phi1) D1_0, resp. - (s phi2) D1 - (s phi3) D2
+        const float e1 = expm1f(hcur);
+        a.phi1 = eps ? scur * e1 : expm1f(-hcur);
         a.m0 = M[0]; a.m1 = M[1]; a.m2 = M[2];
         if (ord == 2) {
             const float h1 = G.lam(sh[0]) - G.lam(sh[1]);
@@ -879,8 +889,14 @@ int run_dpm(SamplerCtx& c, float** result) {
             a.inv_r0 = 1.0f / r0; a.inv_r1 = 1.0f / r1;
             a.r0_frac = r0 / (r0 + r1);
             a.inv_r01 = 1.0f / (r0 + r1);
-            a.phi2 = a.phi1 / hcur + 1.0f;
-            a.phi3 = a.phi2 / hcur - 0.5f;
+            if (eps) {
+                const float p2 = e1 / hcur - 1.0f, p3 = p2 / hcur - 0.5f;
+                a.phi2 = -(scur * p2);                      // the kernel forms v + phi2 D1 - phi3 D2
+                a.phi3 = scur * p3;
+            } else {
+                a.phi2 = a.phi1 / hcur + 1.0f;
+                a.phi3 = a.phi2 / hcur - 0.5f;
+            }
         }
         const int last = step == steps;
         if (!c.count_only && c.ck(launch_dpm_update(XN, X, a, last, c.n, c.s))) return 1;
@@ -889,7 +905,7 @@ int run_dpm(SamplerCtx& c, float** result) {
         if (!last) {
             float* oldest = M[2];
             M[2] = M[1]; M[1] = M[0]; M[0] = oldest;
-            if (c.den(X, G.sig(sc), M[0])) return 1;
+            if (c.model(X, G.sig(sc), M[0])) return 1;
         }
     }
     *result = X;
@@ -938,24 +954,47 @@ int run_dpm_single(SamplerCtx& c, float** result) {
         const float h = G.lam(nxt) - G.lam(cur);
         const float ratio = G.sig(nxt) / G.sig(cur);
         const int last = i + 1 == orders.size();
-        if (c.den(X, G.sig(cur), E0)) return 1;
-        if (orders[i] == 1) {
+        if (c.model(X, G.sig(cur), E0)) return 1;
+        if (d.eps_pred) {
+            // noise-prediction forms (:578-579, :594-597, :617-621): every update is x - b eps + c (eps' - eps)
+            const float sn = G.sig(nxt), eh = expm1f(h);
+            if (orders[i] == 1) {
+                if (comb(XN, nullptr, 1.0f, sn * eh, 0.f, last)) return 1;
+            } else if (orders[i] == 2) {
+                const float r1 = 0.5f;
+                const float s1 = G.inv(cur + r1 * h);
+                if (comb(U, nullptr, 1.0f, G.sig(s1) * expm1f(r1 * h), 0.f, 0)) return 1;
+                if (c.model(U, G.sig(s1), E1)) return 1;
+                if (comb(XN, E1, 1.0f, sn * eh, -(sn / (float)(2.0 * 0.5) * eh), last)) return 1;
+            } else {
+                const double r1d = 1.0 / 3.0, r2d = 2.0 / 3.0;
+                const float r1 = (float)r1d, r2 = (float)r2d;
+                const float s1 = G.inv(cur + r1 * h), s2 = G.inv(cur + r2 * h);
+                if (comb(U, nullptr, 1.0f, G.sig(s1) * expm1f(r1 * h), 0.f, 0)) return 1;
+                if (c.model(U, G.sig(s1), E1)) return 1;
+                const float cu2 = -(G.sig(s2) * (float)(r2d / r1d) * (expm1f(r2 * h) / (r2 * h) - 1.0f));
+                if (comb(U, E1, 1.0f, G.sig(s2) * expm1f(r2 * h), cu2, 0)) return 1;
+                if (c.model(U, G.sig(s2), E2)) return 1;
+                const float cx3 = -(sn / (float)r2d * (eh / h - 1.0f));
+                if (comb(XN, E2, 1.0f, sn * eh, cx3, last)) return 1;
+            }
+        } else if (orders[i] == 1) {
             if (comb(XN, nullptr, ratio, expm1f(-h), 0.f, last)) return 1;
         } else if (orders[i] == 2) {
             const float r1 = 0.5f;
             const float s1 = G.inv(cur + r1 * h);
             if (comb(U, nullptr, G.sig(s1) / G.sig(cur), expm1f(-r1 * h), 0.f, 0)) return 1;
-            if (c.den(U, G.sig(s1), E1)) return 1;
+            if (c.model(U, G.sig(s1), E1)) return 1;
             if (comb(XN, E1, ratio, expm1f(-h), -((float)(1.0 / (2.0 * 0.5)) * expm1f(-h)), last)) return 1;
         } else {
             const double r1d = 1.0 / 3.0, r2d = 2.0 / 3.0;
             const float r1 = (float)r1d, r2 = (float)r2d;
             const float s1 = G.inv(cur + r1 * h), s2 = G.inv(cur + r2 * h);
             if (comb(U, nullptr, G.sig(s1) / G.sig(cur), expm1f(-r1 * h), 0.f, 0)) return 1;
-            if (c.den(U, G.sig(s1), E1)) return 1;
+            if (c.model(U, G.sig(s1), E1)) return 1;
             const float cu2 = (float)(r2d / r1d) * (expm1f(-r2 * h) / (r2 * h) + 1.0f);
             if (comb(U, E1, G.sig(s2) / G.sig(cur), expm1f(-r2 * h), cu2, 0)) return 1;
-            if (c.den(U, G.sig(s2), E2)) return 1;
+            if (c.model(U, G.sig(s2), E2)) return 1;
             const float cx3 = (float)(1.0 / r2d) * (expm1f(-h) / h + 1.0f);
             if (comb(XN, E2, ratio, expm1f(-h), cx3, last)) return 1;
         }

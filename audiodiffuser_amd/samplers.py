@@ -147,7 +147,8 @@ class DPMSampler(nn.Module):
     ``log_time_spacing=False``) and the single-step "DPM-Solver-fast" (``multisteps=False``), each on the sigma grid
     itself or on a grid linear in log sigma.  The reference's quirks are kept: without log spacing the single-step run
     walks only ``len(orders)`` intervals of the sigma list (stops early) and its intermediate points add a
-    lambda-space step to a sigma (:584, :604).  ``x0_pred=False`` raises."""
+    lambda-space step to a sigma (:584, :604).  ``x0_pred=False`` is the noise-prediction form of every update (:700-706); combined with the single-step
+    solver on the sigma grid the reference itself returns NaN, and so does this class."""
 
     def __init__(self, cond_scale, order=1, num_steps=10, multisteps=False, x0_pred: bool = True,
                  log_time_spacing: bool = True, use_graph: bool = True):
@@ -158,8 +159,6 @@ class DPMSampler(nn.Module):
         self.num_steps = num_steps if log_time_spacing else num_steps - 1      # sampler_edm.py:526
 
     def _check_supported(self) -> None:
-        if not self.x0_pred:
-            raise NotImplementedError("DPMSampler(x0_pred=False) (noise prediction) is not on the hot path (SURVEY.md 8f)")
         if self.order not in (1, 2, 3):
             raise ValueError("'order' must be '1' or '2' or '3'.")
 
@@ -184,6 +183,7 @@ class DPMSampler(nn.Module):
         d.s_noise = 1.0
         d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, int(self.order), sigma_data, int(self.use_graph)
         d.log_time_spacing = int(bool(self.log_time_spacing))
+        d.eps_pred = int(not self.x0_pred)
         return d
 
     @torch.no_grad()
@@ -196,6 +196,8 @@ class DPMSampler(nn.Module):
             _condition(net, hd, x.device, self.cond_scale, kwargs)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         # ---- interface-compatibility branch (sampler_edm.py:710-805, :568-690) --------------------
+        if not self.x0_pred:
+            raise NotImplementedError("DPMSampler(x0_pred=False) with a foreign net / fn: noise prediction runs on the native path only")
         call = lambda x, s: fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)
         if self.log_time_spacing:           # grid of lambda = -log sigma (:546-552); lambd = inv_lambd = identity
             lam = inv = lambda v: v

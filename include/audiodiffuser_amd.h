@@ -73,6 +73,7 @@ typedef struct adf_sampler_desc {
     int32_t use_graph;   /* capture the whole step loop into one hipGraph and replay it */
     float rho, eta;      /* ADPM2 */
     int32_t log_time_spacing;  /* DPM (both kinds): the reference's log_time_spacing flag (sampler_edm.py:518, :546-556) */
+    int32_t eps_pred;          /* DPM (both kinds): 1 = the reference's x0_pred=False (noise prediction, :700-706) */
 } adf_sampler_desc;
 
 typedef struct adf_handle adf_handle;

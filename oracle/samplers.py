@@ -77,7 +77,7 @@ def _dpm_grid(sigmas: torch.Tensor, n_intervals: int, log_time_spacing: bool):
 
 def dpm_multistep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int,
                           order: int = 3, trace: Optional[List[torch.Tensor]] = None,
-                          log_time_spacing: bool = False) -> torch.Tensor:
+                          log_time_spacing: bool = False, x0_pred: bool = True) -> torch.Tensor:
     """sampler_edm.py:710-768 + :624-690 with multisteps=True, x0_pred=True.  The shipped setting
     (configs/experiment/sc09_inference/diffunet_complex_sc09_eval_dpm.yaml:57-64) has log_time_spacing=False: the
     "lambda" list is the sigma list itself (:556), lambd(s) = -log s (:532), the loop makes num_steps-1 updates (:526)
@@ -87,12 +87,33 @@ def dpm_multistep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tenso
     assert steps >= order
     grid, lam, sig, _ = _dpm_grid(sigmas, steps, log_time_spacing)
     x = sigmas[0] * noise
+    # x0_pred=False: the model value is the noise prediction (x - D(x)) / sigma (:700-706) and the updates take their
+    # noise-prediction form (:640-645, :660-662, :685-689)
+    model = (lambda x_, g: fn(x_, sigma=sig(g))) if x0_pred else (lambda x_, g: (x_ - fn(x_, sigma=sig(g))) / sig(g))
     s_hist = [grid[0]]
-    m_hist = [fn(x, sigma=sig(grid[0]))]
+    m_hist = [model(x, grid[0])]
 
     def update(x, s_cur, ord_):
         s0 = s_hist[-1]
         h = lam(s_cur) - lam(s0)
+        if not x0_pred:
+            phi1 = torch.expm1(h)
+            if ord_ == 1:
+                return x - sig(s_cur) * phi1 * m_hist[-1]
+            if ord_ == 2:
+                r0 = (lam(s0) - lam(s_hist[-2])) / h
+                d1 = (1.0 / r0) * (m_hist[-1] - m_hist[-2])
+                return x - (sig(s_cur) * phi1) * m_hist[-1] - 0.5 * (sig(s_cur) * phi1) * d1
+            h1 = lam(s_hist[-2]) - lam(s_hist[-3])
+            h0 = lam(s0) - lam(s_hist[-2])
+            r0, r1 = h0 / h, h1 / h
+            d10 = (1.0 / r0) * (m_hist[-1] - m_hist[-2])
+            d11 = (1.0 / r1) * (m_hist[-2] - m_hist[-3])
+            d1 = d10 + (r0 / (r0 + r1)) * (d10 - d11)
+            d2 = (1.0 / (r0 + r1)) * (d10 - d11)
+            phi2 = phi1 / h - 1.0
+            phi3 = phi2 / h - 0.5
+            return x - (sig(s_cur) * phi1) * m_hist[-1] - (sig(s_cur) * phi2) * d1 - (sig(s_cur) * phi3) * d2
         phi1 = torch.expm1(-h)
         if ord_ == 1:
             return sig(s_cur) / sig(s0) * x - phi1 * m_hist[-1]
@@ -119,7 +140,7 @@ def dpm_multistep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tenso
         s_hist.append(s_cur)
         s_hist[:] = s_hist[-order:]
         if step < steps:
-            m_hist.append(fn(x, sigma=sig(s_cur)))
+            m_hist.append(model(x, s_cur))
             m_hist[:] = m_hist[-order:]
         if trace is not None:
             trace.append(x.clone())
@@ -140,7 +161,7 @@ def dpm_singlestep_orders(num_steps_eff: int, order: int) -> List[int]:
 
 
 def dpm_singlestep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int, order: int = 3,
-                           log_time_spacing: bool = True) -> torch.Tensor:
+                           log_time_spacing: bool = True, x0_pred: bool = True) -> torch.Tensor:
     """sampler_edm.py:769-805 (the multisteps=False branch) + :568-622 (dpm_solver_{1,2,3}_step), x0_pred=True.
     Kept as written: (a) with log_time_spacing=False the grid is the full sigma list but only len(orders) intervals are
     walked, so the run stops early (:791-795); (b) in that mode the intermediate points add a lambda-space step to a
@@ -151,10 +172,29 @@ def dpm_singlestep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tens
     k = {3: n_eff // 3 + 1, 2: (n_eff + 1) // 2, 1: n_eff}[order]
     grid, lam, sig, inv = _dpm_grid(sigmas, k, log_time_spacing)
     x = sigmas[0] * noise
+    model = (lambda x_, g: fn(x_, sigma=sig(g))) if x0_pred else (lambda x_, g: (x_ - fn(x_, sigma=sig(g))) / sig(g))
     for i, o in enumerate(orders):
         cur, nxt = grid[i], grid[i + 1]
         h = lam(nxt) - lam(cur)
-        eps = fn(x, sigma=sig(cur))
+        eps = model(x, cur)
+        if not x0_pred:                  # noise-prediction forms (:578-579, :594-597, :617-621)
+            if o == 1:
+                x = x - sig(nxt) * h.expm1() * eps
+            elif o == 2:
+                r1 = 1 / 2
+                s1 = inv(cur + r1 * h)
+                u1 = x - sig(s1) * (r1 * h).expm1() * eps
+                eps_r1 = model(u1, s1)
+                x = x - sig(nxt) * h.expm1() * eps - sig(nxt) / (2 * r1) * h.expm1() * (eps_r1 - eps)
+            else:
+                r1, r2 = 1 / 3, 2 / 3
+                s1, s2 = inv(cur + r1 * h), inv(cur + r2 * h)
+                u1 = x - sig(s1) * (r1 * h).expm1() * eps
+                eps_r1 = model(u1, s1)
+                u2 = x - sig(s2) * (r2 * h).expm1() * eps - sig(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1) * (eps_r1 - eps)
+                eps_r2 = model(u2, s2)
+                x = x - sig(nxt) * h.expm1() * eps - sig(nxt) / r2 * (h.expm1() / h - 1) * (eps_r2 - eps)
+            continue
         if o == 1:
             x = sig(nxt) / sig(cur) * x - torch.expm1(-h) * eps
         elif o == 2:

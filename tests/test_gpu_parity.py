@@ -409,6 +409,12 @@ def test_lms_and_dpm_variants_vs_reference_golden(golden, graph):
     for order in (3, 2):
         cases.append((A.DPMSampler(1.0, order=order, num_steps=10, multisteps=True, log_time_spacing=True, use_graph=graph), 10,
                       f"smp_dpm_multi_log_o{order}_final"))
+    for order in (3, 2):              # noise prediction (x0_pred=False): multistep on the sigma grid, single-step on the log grid
+        cases.append((A.DPMSampler(1.0, order=order, num_steps=10, multisteps=True, x0_pred=False, log_time_spacing=False, use_graph=graph), 10,
+                      f"smp_dpm_multi_eps_o{order}_final"))
+    for order, n in ((3, 10), (2, 7)):
+        cases.append((A.DPMSampler(1.0, order=order, num_steps=n, multisteps=False, x0_pred=False, log_time_spacing=True, use_graph=graph), n,
+                      f"smp_dpm_single_eps_o{order}_log_n{n}_final"))
     for smp, n, key in cases:
         for _ in range(2):
             y = smp(noise, fn=d.denoise_fn, net=net, sigmas=sched(n))

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AdfNetConfig) == 4 * (9 + 13 + 12 * 3 + 4 + 2 + 1)
-    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 14
+    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 15
 
 
 def test_sampler_nfe_via_abi():
@@ -149,7 +149,7 @@ def test_samplers_compat_branch_mock(golden):
     y = A.DPMSampler(1.0, order=3, num_steps=50, multisteps=True, x0_pred=True, log_time_spacing=False)(noise, fn=mock, net=None, sigmas=s50)
     assert rel(y, T(golden["smp_dpm50_tiny_mock_final"])) < 1e-6
     with pytest.raises(NotImplementedError):
-        A.DPMSampler(1.0, order=3, num_steps=50, multisteps=False, x0_pred=False)(noise, fn=mock, net=None, sigmas=s50)
+        A.DPMSampler(1.0, order=3, num_steps=50, multisteps=False, x0_pred=False)(noise, fn=mock, net=None, sigmas=s50)   # foreign fn: native path only
 
 
 def test_lms_and_dpm_variants_compat_branch(golden):

@@ -236,6 +236,12 @@ def test_lms_and_dpm_variants_with_tiny_net(golden):
         for order in (3, 2):
             y = S.dpm_multistep_sampler(noise, fn, sig, 10, order=order, log_time_spacing=True)
             assert rel(y, T(golden[f"smp_dpm_multi_log_o{order}_final"])) < 5e-4
+        for order in (3, 2):          # noise prediction (x0_pred=False)
+            y = S.dpm_multistep_sampler(noise, fn, sig, 10, order=order, log_time_spacing=False, x0_pred=False)
+            assert rel(y, T(golden[f"smp_dpm_multi_eps_o{order}_final"])) < 5e-4
+        for order, n in ((3, 10), (2, 7)):
+            y = S.dpm_singlestep_sampler(noise, fn, E.karras_sigmas(0.002, 80.0, 7.0, n), n, order=order, log_time_spacing=True, x0_pred=False)
+            assert rel(y, T(golden[f"smp_dpm_single_eps_o{order}_log_n{n}_final"])) < 5e-4
         for tag, sg2m in (("k11", E.karras_sigmas(0.002, 80.0, 7.0, 11)), ("k10_zero", torch.cat([sig, torch.zeros(1)]))):
             assert rel(S.dpm2m_sampler(noise, fn, sg2m, 10), T(golden[f"smp_dpm2m_{tag}_final"])) < 5e-4, tag
         with pytest.raises(IndexError):
