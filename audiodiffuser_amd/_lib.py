@@ -61,7 +61,7 @@ EXPORTS = {
     "adf_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adf_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adf_sampler_run": (C.c_int, [C.c_void_p, C.POINTER(AdfSamplerDesc), C.POINTER(C.c_float), C.c_int, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adf_sampler_nfe": (C.c_int, [C.POINTER(AdfSamplerDesc), C.POINTER(C.c_float), C.c_int]),
     "adf_debug_tap_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adf_debug_tap_copy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
@@ -71,6 +71,8 @@ EXPORTS = {
     "adf_bench_resblock": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.c_void_p]),
+    "adf_bench_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

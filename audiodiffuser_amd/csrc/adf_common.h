@@ -172,6 +172,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 constexpr int kRowBytes = 128;      // bytes of K per LDS row / per packed weight row
 constexpr int kRowBytesPack = kRowBytes;
 
+// Launch-side state that HIP keeps per device (kernel attributes, CU count, cached device buffers) is indexed by the
+// CURRENT device: the C entry points make the handle's device current before anything is launched (adf_api.hip DeviceScope).
+constexpr int kMaxDevices = 64;
+static inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

@@ -1,7 +1,6 @@
 // Tile-shape dispatch for the fused implicit-GEMM kernel (see adf_gemm.h).
 #include "adf_gemm.h"
 #include "adf_gemm_pp.h"
-#include "adf_gemm_tile.h"
 #include "adf_gemm_up.h"
 #include "adf_kernels.h"
 #include <cstdio>
@@ -24,7 +23,8 @@ template <typename T, int MT, int NT, int WM, int WN>
 const char* launch_variant(const GemmArgs& a, hipStream_t stream) {
     constexpr int TM = 32 * MT * WM, TN = 32 * NT * WN, NTHR = 64 * WM * WN;
     constexpr int lds = gemm_lds_bytes<TM, TN>();
-    static bool attr_set = false;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr_set = attr_done[current_device()];
     auto kern = conv_gemm_kernel<T, MT, NT, WM, WN>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -50,8 +50,10 @@ int ws_lds_bytes(const GemmArgs& a, int tn) {
 template <typename T, int NT, int WN>
 const char* launch_ws_variant(const GemmArgs& a, hipStream_t stream) {
     constexpr int TN = NT * WN * 32;
-    static bool attr_set = false;
-    static int num_cu = 0;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr_set = attr_done[current_device()];
+    static int num_cu_dev[kMaxDevices] = {};
+    int& num_cu = num_cu_dev[current_device()];
     auto kern = conv_gemm_ws_kernel<T, NT, WN>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -71,31 +73,12 @@ const char* launch_ws_variant(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_ws: launch failed";
 }
 
-// Tile kernel (adf_gemm_tile.h): persistent 512-thread workgroups over tiles of 128 (N = 256) or 256 (N = 128) positions
-template <int N, int CIN, int CRES>
-const char* launch_tile(const GemmArgs& a, hipStream_t stream) {
-    typedef TileCfg<N, CIN, CRES> Cfg;
-    static bool attr_set = false;
-    auto kern = conv_gemm_tile_kernel<N, CIN, CRES>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return "hipFuncSetAttribute(MaxDynamicSharedMemorySize, tile) failed";
-        attr_set = true;
-    }
-    static_assert(Cfg::kLds <= 160 * 1024, "tile kernel LDS budget");
-    const int tps = a.mrows / Cfg::TM;
-    const long long tiles = (long long)a.B * tps;
-    if (tiles <= 0 || tiles > 0x7fffffffLL) return "conv_gemm_tile: bad tile count";
-    const long long grid = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), Cfg::kLds, stream, a, (int)tiles, tps);
-    return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_tile: launch failed";
-}
-
 // Transposed-conv kernel (adf_gemm_up.h): persistent 512-thread workgroups over tiles of m = 0 .. L
 template <int CIN, int COUT, int F, int MTP>
 const char* launch_up_mt(const GemmArgs& a, hipStream_t stream) {
     typedef UpCfg<CIN, COUT, F, MTP> Cfg;
-    static bool attr_set = false;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr_set = attr_done[current_device()];
     auto kern = conv_gemm_up_kernel<CIN, COUT, F, MTP>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -123,8 +106,10 @@ const char* launch_up(const GemmArgs& a, hipStream_t stream) {
 // Persistent LDS-DMA kernel (adf_gemm_pp.h): one 512-thread block per CU, block tile (128 MT) x 128.
 template <int MT>
 const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
-    static int num_cu = 0;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr_set = attr_done[current_device()];
+    static int num_cu_dev[kMaxDevices] = {};
+    int& num_cu = num_cu_dev[current_device()];
     auto kern = conv_gemm_pp_kernel<MT>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess)
@@ -167,7 +152,8 @@ bool pp_eligible(const GemmArgs& a, int tm) {
 
 // packed bf16 identity [n/64 chunks][1 tap][n rows][64 channels]: row r of chunk c holds 1.0 at channel r - 64 c
 const void* pp_identity(int n, hipStream_t stream, const char** err) {
-    static void* cache[kPpMaxN / 64 + 1] = {};
+    static void* cache_dev[kMaxDevices][kPpMaxN / 64 + 1] = {};     // one copy per device (freed at process exit)
+    void** cache = cache_dev[current_device()];
     const int idx = n / 64;
     if (cache[idx]) return cache[idx];
     const size_t elems = (size_t)(n / 64 + kTapGroup) * n * 64;     // over-allocated like every packed weight
@@ -187,7 +173,8 @@ template <typename T, int MT, int NT>
 const char* launch_ksplit(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 4 * ks_wave_lds(MT, NT);
     constexpr int TM = 32 * MT, TN = 32 * NT;
-    static bool attr_set = false;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr_set = attr_done[current_device()];
     auto kern = conv_gemm_ksplit_kernel<T, MT, NT>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -380,39 +367,6 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             trace_route("ksplit", a, tile, tile);
             if (big) return dtype_bf16 ? launch_ksplit<bf16_t, 2, 2>(a, stream) : launch_ksplit<float, 2, 2>(a, stream);
             return dtype_bf16 ? launch_ksplit<bf16_t, 1, 1>(a, stream) : launch_ksplit<float, 1, 1>(a, stream);
-        }
-    }
-    {
-        // resblock convs (3 taps, 128 or 256 output channels, GroupNorm prologue from the statistics, optional 1x1 residual
-        // segment / identity residual) in bf16 on the tile kernel (adf_gemm_tile.h): ADF_GEMM_TILE=1.  OFF by default -- measured
-        // (tools/layer_table.py, us per launch, tile vs the routes below): L = 4096 K = 384 / 768: 76-88 / 126 vs 50-60 / 97;
-        // L = 1024 (256 channels) K = 768 / 1536: 53-60 / 91 vs 45-56 / 93; L = 256: 26-48 vs 24-40; 334 vs 319 ms per step.
-        static int use_tile = -1;
-        if (use_tile < 0) { const char* e = getenv("ADF_GEMM_TILE"); use_tile = e ? atoi(e) : 0; }
-        const GemmSeg& g = a.seg[0];
-        const int N = a.n, cin = g.c0 + g.c1;
-        bool ok = use_tile && dtype_bf16 && !flat && !a.scatter_f && !a.gelu && g.taps == 3 && g.stride == 1 && g.off0 == -1 && g.step == 1 &&
-                  g.wfrag && a.n == a.n_pad && a.out_c == a.n && (N == 128 || N == 256) && a.lin == a.mrows && a.out_rows == a.mrows &&
-                  a.mrows % (N == 256 ? 128 : 256) == 0 && (cin == N || cin == 2 * N) && (gn_pending || !g.ab) && a.bias_mod == a.n &&
-                  (!a_in.stats || a.stats_groups == 8) && (long long)a.B * (a.mrows / (N == 256 ? 128 : 256)) >= 64;
-        int cres = 0;
-        if (ok && a.nseg == 2) {
-            const GemmSeg& s1 = a.seg[1];
-            ok = s1.taps == 1 && s1.stride == 1 && s1.off0 == 0 && s1.step == 1 && !s1.ab && !s1.act && s1.wfrag && s1.c0 + s1.c1 == 2 * N &&
-                 cin == N && !a.res;
-            cres = 2 * N;
-        }
-        if (ok) {
-            if (const char* e = settle_gn(true)) return e;
-            a.stats = a_in.stats;
-            if (stats_fused && a_in.stats) *stats_fused = true;
-            trace_route("tile", a, N == 256 ? 128 : 256, N);
-            if (N == 128 && cin == 128 && !cres) return launch_tile<128, 128, 0>(a, stream);
-            if (N == 128 && cin == 256) return launch_tile<128, 256, 0>(a, stream);
-            if (N == 128) return launch_tile<128, 128, 256>(a, stream);
-            if (cin == 256 && !cres) return launch_tile<256, 256, 0>(a, stream);
-            if (cin == 512) return launch_tile<256, 512, 0>(a, stream);
-            return launch_tile<256, 256, 512>(a, stream);
         }
     }
     {

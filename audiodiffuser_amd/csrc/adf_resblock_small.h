@@ -308,7 +308,8 @@ inline size_t resblock_small_lds(int ntok, int cin) {
 
 inline const char* launch_resblock_small(const RbFusedArgs& a, int B, int ntok, int cin, hipStream_t s) {
     if ((ntok != 64 && ntok != 16) || (cin != 256 && cin != 512)) return "resblock_small: unsupported shape";
-    static bool attr = false;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr = attr_done[current_device()];
     if (!attr) {
         if (hipFuncSetAttribute((const void*)resblock_small_kernel<64, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)resblock_small_kernel<64, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

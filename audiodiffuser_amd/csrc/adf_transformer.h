@@ -437,7 +437,8 @@ inline const char* launch_transformer_small(const TrFusedArgs& a, int B, int nto
     const int mr = ntok < 32 ? 32 : ntok;
     const size_t lds = (size_t)mr * (256 * 2 + 16) + (size_t)mr * (768 * 2 + 16) + 8 * 1024 + 1280 * 4;   // + the warm-up scratch + LayerNorm parameters
     if (ntok != 64 && ntok != 16) return "transformer_small: 16 or 64 tokens per sample";
-    static bool attr = false;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr = attr_done[current_device()];
     if (!attr) {                                         // both instances need more than the default 64 KB of dynamic LDS
         if (hipFuncSetAttribute((const void*)transformer_small_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)transformer_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -456,7 +457,8 @@ inline const char* launch_transformer_small(const TrFusedArgs& a, int B, int nto
 // 256-token (or longer) samples: MODE 1 / MODE 2 over 64-row tiles (rows = B * tokens, a multiple of 64)
 inline const char* launch_transformer_tiles(const TrFusedArgs& a, int rows, int tokens, int mode, hipStream_t s) {
     if (rows % 64 || tokens % 64 || (mode != 1 && mode != 2)) return "transformer_tiles: unsupported shape";
-    static bool attr = false;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr = attr_done[current_device()];
     if (!attr) {
         if (hipFuncSetAttribute((const void*)transformer_small_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)transformer_small_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -65,10 +65,11 @@ class EluDiffusion(nn.Module):
             x = x_noisy.detach().to(torch.float32).contiguous()
             if net.cfg.class_cond:      # labels + guidance scale for this call (diffusion.py:49-54)
                 hd.set_condition(kwargs["classes"], x.device, null_labels=False, cond_scale=float(cond_scale))
-            if sigmas is not None:
-                sv = sigmas.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
-                return hd.denoise(x, self.sigma_data, sigmas=sv).to(x_noisy.dtype)
-            return hd.denoise(x, self.sigma_data, sigma=float(sigma)).to(x_noisy.dtype)
+            with torch.cuda.device(x.device):
+                if sigmas is not None:
+                    sv = sigmas.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+                    return hd.denoise(x, self.sigma_data, sigmas=sv).to(x_noisy.dtype)
+                return hd.denoise(x, self.sigma_data, sigma=float(sigma)).to(x_noisy.dtype)
         # ---- interface-compatibility branch: arbitrary `net` callable -------------------------
         b, device = x_noisy.shape[0], x_noisy.device
         if sigmas is None:
@@ -92,6 +93,9 @@ class EluDiffusion(nn.Module):
     # diffusion.py:65-98 (training loss; stock tensor ops, outside the accelerated path)
     def forward(self, x: Tensor, net: nn.Module, sigmas: Tensor, inference: bool = False, cond_scale: float = 1.0,
                 **kwargs) -> Tensor:
+        if isinstance(net, UNet1dBase) and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+            raise NotImplementedError("EluDiffusion.forward is the training loss; the HIP UNet1dBase is an inference path without "
+                                      "backward -- train the reference module and load its state_dict here, or call under torch.no_grad()")
         noise = torch.randn_like(x)
         x_noisy = x + _extend(sigmas, x.ndim) * noise
         mask = torch.ones_like(x)

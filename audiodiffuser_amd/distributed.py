@@ -8,7 +8,11 @@ its inference is unsharded (src/models/diffunet_complex_module.py:235-266).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -55,3 +59,20 @@ def sample_sharded(run_local: Callable[[torch.Tensor], torch.Tensor], global_bat
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     noise = rank_noise(global_batch, length, rank, world, channels, base_seed).to(device)
     return gather_samples(run_local(noise), global_batch, group)
+
+
+def launch_ranks(script: str, n: int, argv: Sequence[str], stdout=None, timeout: Optional[float] = None) -> int:
+    """Start ``n`` ranks of ``script`` on this node -- one process per GPU -- with ``torch.distributed.run`` and return its
+    exit code.  The caller must not have touched a GPU yet (a process that has initialised HIP must not be replaced, and
+    the children open the devices themselves); rendezvous is on 127.0.0.1 (the container hostname may not resolve).
+    ``bench.py --gpus N`` uses this when it is not already running under a launcher."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: needed by RCCL on this driver
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    return subprocess.run(cmd, env=env, stdout=stdout, timeout=timeout).returncode

@@ -60,8 +60,13 @@ class NativeHandle:
     def check(self, rc: int, what: str) -> None:
         _lib.check(self.lib, self.h, rc, what)
 
+    def invalidate(self) -> None:
+        """Forget what was uploaded: the next call re-packs every tensor."""
+        self._loaded.clear()
+
     def sync_weights(self, named: Dict[str, torch.Tensor], device: torch.device) -> None:
-        """Upload every tensor whose storage/version changed since the last call."""
+        """Upload every tensor whose storage/version changed since the last call.  (A write through ``p.data`` or a raw
+        pointer does not bump ``_version``: call ``UNet1dBase.invalidate_native()`` after such an update.)"""
         stream = _stream_ptr(device)
         for name, t in named.items():
             sig = (t.data_ptr(), t._version, t.device)
@@ -114,10 +119,17 @@ class NativeHandle:
         out = torch.empty_like(noise)
         sg = sigmas_host.detach().to("cpu", torch.float32).contiguous()
         arr = (C.c_float * sg.numel())(*sg.tolist())
+        n_inj = 0
+        if injected is not None:
+            if (injected.ndim != noise.ndim + 1 or tuple(injected.shape[1:]) != tuple(noise.shape) or injected.dtype != torch.float32
+                    or injected.device != noise.device or not injected.is_contiguous()):
+                raise ValueError("injected noise must be a contiguous fp32 [n, B, C, L] tensor on the device of `noise`")
+            n_inj = int(injected.shape[0])
         ip = C.c_void_p(injected.data_ptr()) if injected is not None else C.c_void_p(0)
-        self.check(self.lib.adf_sampler_run(self.h, C.byref(desc), arr, sg.numel(), C.c_void_p(noise.data_ptr()), ip,
-                                            C.c_void_p(out.data_ptr()), noise.shape[0], noise.shape[-1],
-                                            C.c_void_p(_stream_ptr(noise.device))), "adf_sampler_run")
+        with torch.cuda.device(noise.device):
+            self.check(self.lib.adf_sampler_run(self.h, C.byref(desc), arr, sg.numel(), C.c_void_p(noise.data_ptr()), ip, n_inj,
+                                                C.c_void_p(out.data_ptr()), noise.shape[0], noise.shape[-1],
+                                                C.c_void_p(_stream_ptr(noise.device))), "adf_sampler_run")
         return out
 
     def tap_names(self):
@@ -209,10 +221,31 @@ class UNet1dBase(nn.Module):
         hd.sync_weights(dict(self.named_parameters()), device)
         return hd
 
+    def invalidate_native(self) -> None:
+        """Force a re-upload of all weights on the next call.  The staleness check keys on ``(data_ptr, _version, device)``;
+        ``load_state_dict`` and in-place tensor ops bump ``_version``, but writes through ``p.data`` (some EMA / weight-swap
+        code) or raw pointers do not -- call this after them."""
+        for hd in self._handles.values():
+            hd.invalidate()
+
+    def _load_from_state_dict(self, *args, **kwargs):       # (only parameters registered on this module itself, if any)
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_native()
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_native()
+        return out
+
     def forward(self, x: torch.Tensor, t: torch.Tensor, classes=None, text_embeds=None, text_mask=None,
                 inj_embeddings=None, inj_channels=None, cond_drop_prob=None, **kwargs) -> torch.Tensor:
         if text_embeds is not None or inj_embeddings is not None or inj_channels is not None:
             raise NotImplementedError("text / injected conditioning inputs are outside the hot path (SURVEY.md 8f)")
+        if torch.is_grad_enabled() and x.requires_grad:
+            # the HIP path is inference only: its output carries no autograd history, so a loss built on it would fail at
+            # backward() with an unrelated-looking error -- say so here instead
+            raise NotImplementedError("the HIP UNet1dBase is an inference path (no backward); call it under torch.no_grad() "
+                                      "or with inputs that do not require grad")
         hd = self.native(x.device)
         if self.cfg.class_cond:
             # unet1d.py:874-877: labels -> LabelEmbedder(classes, cond_drop_prob); the label mask is deterministic only
@@ -229,4 +262,5 @@ class UNet1dBase(nn.Module):
         tin = t.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         if tin.numel() != xin.shape[0]:
             raise ValueError("t must have one entry per batch element")
-        return hd.net_forward(xin, tin).to(x.dtype)
+        with torch.cuda.device(x.device):
+            return hd.net_forward(xin, tin).to(x.dtype)

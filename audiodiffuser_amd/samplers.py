@@ -44,6 +44,21 @@ def _condition(net: UNet1dBase, hd, device, cond_scale: float, kwargs: dict) -> 
         hd.set_condition(kwargs["classes"], device, null_labels=False, cond_scale=float(cond_scale))
 
 
+def _draws(x: Tensor, n: int, injected: Optional[Tensor], needed: bool) -> Optional[Tensor]:
+    """The per-step ``randn_like`` draws of a reference loop ([n, B, C, L]).  ``injected`` replaces them after a shape
+    check (the C side copies n * B * C * L floats from the pointer).  Without it the draws are made here, one
+    ``randn_like`` per step in the reference's order -- ALSO when the schedule never uses them (``needed`` False, e.g.
+    s_churn = 0): the reference steps draw unconditionally (sampler_edm.py:346, :439), so the global generator is left
+    in the state the reference leaves it in and the next batch's initial noise matches seed for seed."""
+    if injected is not None:
+        if injected.ndim != x.ndim + 1 or tuple(injected.shape[1:]) != tuple(x.shape) or injected.shape[0] < n:
+            raise ValueError(f"injected_noise must be shaped [>= {n}, {', '.join(str(d) for d in x.shape)}] (one draw per step), "
+                             f"got {tuple(injected.shape)}")
+        return injected[:n].detach().to(device=x.device, dtype=torch.float32).contiguous()
+    draws = [torch.randn_like(x) for _ in range(n)]
+    return torch.stack(draws) if needed and n > 0 else None
+
+
 def _prep(noise: Tensor) -> Tensor:
     if noise.ndim != 3:
         raise ValueError("the HIP sampler expects waveforms shaped [B, C, L]")
@@ -74,12 +89,7 @@ class EDMSampler(nn.Module):
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs)
-            inj = injected_noise
-            if inj is None and self.s_churn > 0:
-                # same draw order as the reference's per-step randn_like (sampler_edm.py:346)
-                inj = torch.stack([torch.randn_like(x) for _ in range(self.num_steps)])
-            if inj is not None:
-                inj = inj.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            inj = _draws(x, self.num_steps, injected_noise, self.s_churn > 0)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
         # ---- interface-compatibility branch (sampler_edm.py:333-397) -----------------------------
         sig = torch.cat([sigmas, torch.zeros_like(sigmas[:1])])
@@ -392,11 +402,7 @@ class DPM2Sampler(nn.Module):
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs)
-            inj = injected_noise
-            if inj is None and self.s_churn > 0:
-                inj = torch.stack([torch.randn_like(x) for _ in range(self.num_steps - 1)])   # reference draw order (:439)
-            if inj is not None:
-                inj = inj.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            inj = _draws(x, self.num_steps - 1, injected_noise, self.s_churn > 0)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
         # ---- interface-compatibility branch (sampler_edm.py:428-493) ----------------------------------
         x = sigmas[0] * noise
@@ -442,10 +448,7 @@ class ADPM2Sampler(nn.Module):
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs)
-            inj = injected_noise
-            if inj is None:
-                inj = torch.stack([torch.randn_like(x) for _ in range(self.num_steps - 1)])   # reference draw order (:82)
-            inj = inj.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            inj = _draws(x, self.num_steps - 1, injected_noise, True)                          # reference draw order (:82)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
         # ---- interface-compatibility branch (stochastic_sampler_edm.py:29-32, :53-100) -----------------
         x = sigmas[0] * noise

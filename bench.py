@@ -1,38 +1,51 @@
 #!/usr/bin/env python
 """Headline benchmark: audio samples / second for full EDM sampler runs on MI355X.
 
-A "step" is ONE complete sampler run (KarrasSchedule N=50, Heun, 99 denoiser evaluations) over one
-batch of synthetic noise that is already resident in HBM: BASELINE.json configs[1]
-(UNet1d 64 ch, 16384-sample waveforms, batch 64 per GPU, bf16 storage / fp32 accumulate).
-With N > 1 GPUs the batch is sharded (64 waveforms per rank, weak scaling) and the only exchange
-is one all-gather of the finished waveforms (audiodiffuser_amd/distributed.py).
+A "step" is ONE complete sampler run over one batch of synthetic noise that is already resident in HBM.  Default
+workload = BASELINE.json configs[1]: UNet1d 64 ch, 16384-sample waveforms, KarrasSchedule N=50 Heun (99 denoiser
+evaluations), batch 64 per GPU, bf16 storage / fp32 accumulate.  `--config c3 --sampler dpm` is configs[2]
+(attention from the 16x level, DPM-Solver++ multistep order 3, 50 sigmas = 49 evaluations, 64 waveforms per GPU).
+With N > 1 GPUs the batch is sharded (weak scaling: --batch waveforms per rank) and the only exchange is one
+all-gather of the finished waveforms (audiodiffuser_amd/distributed.py).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(torch.distributed.run, one process per GPU, before this process touches a GPU); under torchrun it is one rank.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement); extra objects:
-  roofline     -- the dominant kernel (fused resblock implicit-GEMM): algorithmic bytes / flops per launch
-                  (SURVEY.md 8d definition) over its HIP-event-timed launch duration
-  cpu_baseline -- the CPU oracle (a port of the reference PyTorch path) timed on a bounded sample
+  roofline     -- the dominant kernel (fused resblock implicit GEMM): algorithmic bytes / flops per launch
+                  over its HIP-event-timed launch duration, replayed exactly as the network pass issues it on rotating
+                  operand copies (adf_bench_resblock); `traffic` = HBM bytes per launch from two rocprofv3 --pmc passes
+                  (FETCH_SIZE, WRITE_SIZE) of `bench.py --roofline-only` run as child processes, or null
+  cpu_baseline -- the CPU oracle (a port of the reference PyTorch path) timed on the host cores: the same workload on a
+                  bounded sample (`value`), and SURVEY.md 8(d)'s protocol on BASELINE configs[0] (`config1`)
+  bf16_vs_fp32 -- deviation of the timed (bf16) run's first waveforms from the fp32 (parity-grade) mode on the same noise
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WORKLOADS = {"c1": "BASELINE configs[0] network", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2] network (attention from the 16x level)"}
+WORKLOADS = {"c1": "BASELINE configs[0] network", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2]", "tiny": "unit-test network"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+SURVEY_REFERENCE_CONFIG1_S = 3.81    # the reference itself, config 1, in the build container (8 threads)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -42,32 +55,66 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="waveforms per GPU")
     ap.add_argument("--length", type=int, default=16384)
     ap.add_argument("--num-steps", type=int, default=50, help="sigma schedule length N (Heun => 2N-1 NFE)")
-    ap.add_argument("--sampler", default="heun", choices=["heun", "dpm"])
+    ap.add_argument("--sampler", default=None, choices=["heun", "dpm"], help="default: heun, dpm for --config c3")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-iters", type=int, default=50)
-    ap.add_argument("--roofline-only", action="store_true", help="only replay the dominant kernel (for rocprofv3)")
-    return ap.parse_args()
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-precision-check", action="store_true", help="skip the fp32 run behind bf16_vs_fp32")
+    ap.add_argument("--roofline-iters", type=int, default=60)
+    ap.add_argument("--roofline-only", action="store_true", help="only replay the resblock kernels (for rocprofv3)")
+    ap.add_argument("--roofline-level", type=int, default=-1, help="with --roofline-only: replay this resblock only")
+    ap.add_argument("--roofline-conv", type=int, default=0, choices=[0, 1, 2], help="with --roofline-level: only conv1 / conv2 of the block")
+    a = ap.parse_args(argv)
+    if a.sampler is None:
+        a.sampler = "dpm" if a.config == "c3" else "heun"
+    return a
 
 
-def roofline(net, hd, batch, length, dtype, iters, device):
-    """Replay each recorded resblock kernel pair with HIP events on the launch stream and report the
-    one that dominates the NFE (largest total time)."""
+# ---------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(n: int, argv) -> int:
+    """Start n ranks of this script (one per GPU) with torch.distributed.run and return its exit code.  Called BEFORE
+    anything in this process touches a GPU (torch.cuda.device_count() does not initialise it)."""
+    from audiodiffuser_amd.distributed import launch_ranks as _launch
+    return _launch(os.path.abspath(__file__), n, argv)
+
+
+# ---------------------------------------------------------------------------------------------------- roofline
+def replay_rows(hd, batch, length, iters, device, only_level=-1, only_conv=0):
+    """HIP-event replay of the resblock GEMM launches of the last forward (adf_bench_resblock / adf_bench_layer)."""
+    import torch
     lib = hd.lib
     stream = torch.cuda.current_stream(device).cuda_stream
-    best, total_ms, rows = None, 0.0, []
-    idx = 0
+    if only_level >= 0 and only_conv in (1, 2):
+        ms, by, fl, cp = C.c_float(), C.c_double(), C.c_double(), C.c_int()
+        rc = lib.adf_bench_layer(hd.h, batch, length, only_level, only_conv, iters, C.byref(ms), C.byref(by), C.byref(fl), C.byref(cp),
+                                 C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("adf_bench_layer: " + lib.adf_last_error(hd.h).decode())
+        return [{"resblock": only_level, "kernel": only_conv, "ms": ms.value, "bytes": by.value, "flops": fl.value, "copies": cp.value}]
+    rows, idx = [], 0 if only_level < 0 else only_level
     while True:
         ms1, ms2 = C.c_float(), C.c_float()
         b1, b2, f1, f2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         rc = lib.adf_bench_resblock(hd.h, batch, length, idx, iters, C.byref(ms1), C.byref(ms2), C.byref(b1), C.byref(b2),
                                     C.byref(f1), C.byref(f2), C.c_void_p(stream))
         if rc != 0:
-            break
+            msg = lib.adf_last_error(hd.h).decode()
+            if "out of range" in msg and only_level < 0:
+                break
+            raise RuntimeError("adf_bench_resblock: " + msg)
         for k, (ms, by, fl) in enumerate(((ms1.value, b1.value, f1.value), (ms2.value, b2.value, f2.value))):
-            rows.append({"resblock": idx, "kernel": k + 1, "ms": ms, "bytes": by, "flops": fl})
-            total_ms += ms
+            if ms > 0:
+                rows.append({"resblock": idx, "kernel": k + 1, "ms": ms, "bytes": by, "flops": fl})
+        if only_level >= 0:
+            break
         idx += 1
+    return rows
+
+
+def roofline(hd, batch, length, dtype, iters, device):
+    """Replay every resblock's two GEMM launches (as the network pass issues them, rotating operand copies) with HIP events
+    on the launch stream and report the launch that dominates the pass (largest time)."""
+    rows = replay_rows(hd, batch, length, iters, device)
     if not rows:
         return None
     dom = max(rows, key=lambda r: r["ms"])
@@ -75,34 +122,29 @@ def roofline(net, hd, batch, length, dtype, iters, device):
     ridge = MFMA_PEAK_TFLOPS[dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
     gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
     tfs = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    total_ms = sum(r["ms"] for r in rows)
     all_bytes = sum(r["bytes"] for r in rows)
     all_flops = sum(r["flops"] for r in rows)
+    # SURVEY.md 8(d) defines the figure per RESBLOCK (conv1 + conv2 launches of one block): report the dominant launch's block too
+    pair = [r for r in rows if r["resblock"] == dom["resblock"]]
+    pair_ms, pair_bytes = sum(r["ms"] for r in pair), sum(r["bytes"] for r in pair)
     out = {
         "bound": "hbm" if ai < ridge else "mfma",
-        "kernel": f"conv_gemm (resblock {dom['resblock']} conv{dom['kernel']})",
+        "kernel": f"fused resblock implicit-GEMM (resblock {dom['resblock']} conv{dom['kernel']})",
+        "definition": "dominant single launch: SURVEY.md 8(d) algorithmic bytes of that conv / its mean duration, HIP events, "
+                      "in-pass launch form (GroupNorm table + statistics epilogue on), operands rotated over >= 320 MiB",
+        "level": dom["resblock"], "conv": dom["kernel"],
         "ms_per_launch": dom["ms"],
-        "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"],
+        "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"], "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
         "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
         "mfma_TFLOPs": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS[dtype],
+        "resblock_pair": {"ms": pair_ms, "algorithmic_bytes": pair_bytes, "hbm_GBps": pair_bytes / (pair_ms * 1e-3) / 1e9,
+                          "hbm_frac": pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "all_resblocks": {"ms": total_ms, "hbm_GBps": all_bytes / (total_ms * 1e-3) / 1e9,
                           "hbm_frac": all_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "mfma_TFLOPs": all_flops / (total_ms * 1e-3) / 1e12},
         "traffic": None,
     }
-    # HBM bytes per launch of the dominant kernel from the PMC counters: collected in a separate rocprofv3 run
-    # (counters cannot be read from inside this process), committed under profiles/ with the command that made it
-    tpath = os.path.join(ROOT, "profiles", "r01_dominant_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            # same layer shape and conv (several resblocks share the dominant shape; which replay is slowest varies by box)
-            same = tj.get("kernel") == out["kernel"] or (tj.get("algorithmic_bytes") == out["algorithmic_bytes"] and
-                                                         str(tj.get("kernel", "")).split()[-1] == out["kernel"].split()[-1])
-            if same and tj.get("workload") == f"{net.cfg_name} {dtype} batch {batch} length {length}":
-                out["traffic"] = tj["hbm_bytes_per_launch"]
-                out["traffic_source"] = "profiles/r01_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-        except (ValueError, KeyError):
-            pass
     if os.environ.get("ADF_BENCH_VERBOSE"):
         out["rows"] = rows
     if out["bound"] == "hbm":
@@ -112,33 +154,190 @@ def roofline(net, hd, batch, length, dtype, iters, device):
     return out
 
 
-def cpu_baseline(cfg, length, nfe_per_waveform):
-    """Time the CPU oracle (port of the reference PyTorch path) on a bounded sample of the same workload."""
+def pmc_traffic(a, level: int, conv: int):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured now: two child runs of
+    `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --roofline-only --roofline-level K` (FETCH_SIZE and WRITE_SIZE
+    need separate passes), read from the counter CSV.  gfx950: FETCH_SIZE counts a 16-B/lane streaming read at half its bytes
+    (MI355X_MICROARCH.md, HBM) -> read bytes = 2 * FETCH_SIZE KB; WRITE_SIZE is exact.  Returns (bytes, detail) or (None, why)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="adf_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
+               "--roofline-only", "--roofline-level", str(level), "--roofline-conv", str(conv), "--roofline-iters", "4", "--config", a.config, "--dtype", a.dtype,
+               "--batch", str(a.batch), "--length", str(a.length), "--no-cpu-baseline", "--no-pmc"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+        per = {}
+        for row in csv.DictReader(open(files[0])):
+            if row.get("Counter_Name") != counter or "conv_gemm" not in row.get("Kernel_Name", ""):
+                continue
+            per.setdefault(row["Dispatch_Id"], [row["Kernel_Name"], 0.0])[1] += float(row["Counter_Value"])
+        shutil.rmtree(tmp, ignore_errors=True)
+        # the child's last launches are the 4 timed replays of (level, conv): the last 4 conv_gemm dispatches of the trace
+        seq = [v for _, v in sorted(per.items(), key=lambda kv: int(kv[0]))]
+        if len(seq) < 4:
+            return None, f"no conv_gemm dispatch in the {counter} pass"
+        tail = seq[-4:]
+        if len({nm for nm, _ in tail}) != 1:
+            return None, f"the {counter} pass ended on mixed kernels"
+        vals[counter] = (statistics.median(v for _, v in tail), tail[-1][0])
+    fetch_kb, write_kb = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return (2.0 * fetch_kb + write_kb) * 1024.0, {"FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "kernel": vals["FETCH_SIZE"][1].split("(")[0],
+                                                   "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count correction)"}
+
+
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        avail = len(os.sched_getaffinity(0))
+        return max(1, min(len(seen), avail)) if seen else avail
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
+    """The CPU oracle (port of the reference PyTorch path, pinned against the reference) on the host cores.
+    (1) the SAME workload as the GPU line on a bounded sample: the denoiser of this network at batch 2, 1 warm-up + 3 x 3
+        evaluations, median per-evaluation time, scaled to the sampler's evaluation count;
+    (2) SURVEY.md 8(d) / BASELINE.md section 3: BASELINE configs[0] exactly (16 ch, B = 4, N = 18 Heun = 35 NFE, fp32, full
+        sampler via oracle.samplers.edm_sampler), k = all physical cores and k = 8 threads, 1 warm-up + 3 runs, median."""
+    import torch
+    import audiodiffuser_amd as A
     from audiodiffuser_amd.weights import generate_weights, generate_noise
-    from oracle import edm as E
-    w = generate_weights(cfg, seed=0)
-    fn = E.make_denoiser(w, cfg, 0.2)
-    b = 2
-    x = generate_noise(0, b, length) * 3.0
-    cores = torch.get_num_threads()
-    with torch.no_grad():
-        fn(x, sigma=torch.tensor(3.0))           # warm-up
+    from oracle import edm as E, samplers as S
+    cores = physical_cores()
+    prev = torch.get_num_threads()
+    out = {"unit": "audio-samples/s", "kind": "port", "cpu_model": cpu_model(), "physical_cores": cores}
+    try:
+        torch.set_num_threads(cores)
+        w = generate_weights(cfg, seed=0)
+        fn = E.make_denoiser(w, cfg, 0.2)
+        b = 2
+        x = generate_noise(0, b, length) * 3.0
+        reps = []
+        with torch.no_grad():
+            fn(x, sigma=torch.tensor(3.0))           # warm-up
+            for rep in range(3):
+                t0 = time.perf_counter()
+                for i in range(3):
+                    fn(x, sigma=torch.tensor(3.0 / (3 * rep + i + 1)))
+                reps.append((time.perf_counter() - t0) / 3)
+        dt = statistics.median(reps)
+        wps = b / (dt * nfe_per_waveform)
+        out.update({"value": wps * length, "waveforms_per_s": wps, "cores": cores,
+                    "sample": f"same network and sampler as the GPU line: oracle denoiser at batch {b}, 1 warm-up + 3 x 3 evaluations, median "
+                              f"{dt:.3f} s per evaluation (repeats {', '.join('%.3f' % r for r in reps)}), scaled to {nfe_per_waveform} evaluations per waveform"})
+        del w, fn
+        # ---- SURVEY.md 8(d) protocol on configs[0] ------------------------------------------------------------------
+        c1 = A.config_c1()
+        w1 = generate_weights(c1, seed=0)
+        fn1 = E.make_denoiser(w1, c1, 0.2)
+        sig = A.KarrasSchedule(0.002, 80.0, 7.0, 18)()
+        noise = generate_noise(1234, 4, 16384)
+        proto = {"workload": "BASELINE configs[0]: UNet1d 16 ch, B=4, L=16384, KarrasSchedule N=18 Heun (35 NFE), fp32, oracle.samplers.edm_sampler",
+                 "protocol": "1 warm-up + 3 timed runs, median", "reference_in_build_container_s_per_batch_8_threads": SURVEY_REFERENCE_CONFIG1_S}
+        for k in sorted({cores, min(8, cores)}, reverse=True):
+            torch.set_num_threads(k)
+            runs = []
+            with torch.no_grad():
+                for i in range(4):
+                    t0 = time.perf_counter()
+                    S.edm_sampler(noise, fn1, sig, 18, s_churn=0.0, s_noise=1.0)
+                    if i:
+                        runs.append(time.perf_counter() - t0)
+            med = statistics.median(runs)
+            proto[f"threads_{k}"] = {"s_per_batch_median": med, "runs_s": runs, "waveforms_per_s": 4.0 / med, "audio_samples_per_s": 4.0 * 16384 / med}
+        out["config1"] = proto
+    finally:
+        torch.set_num_threads(prev)
+    out["gpu_over_cpu_same_workload"] = gpu_value / out["value"] if out.get("value") else None
+    return out
+
+
+def gpu_config1(device):
+    """The HIP path on BASELINE configs[0] exactly (fp32 parity mode, B = 4, N = 18 Heun): waveforms / s, for the ratio against
+    cpu_baseline.config1 on the identical workload."""
+    import torch
+    import audiodiffuser_amd as A
+    from audiodiffuser_amd.weights import generate_weights, generate_noise
+    cfg = A.config_c1()
+    net = A.UNet1dBase.from_config(cfg, compute_dtype="fp32")
+    net.load_state_dict(generate_weights(cfg, seed=0))
+    net = net.to(device)
+    diff = A.EluDiffusion(sigma_data=0.2)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 18)()
+    smp = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=18, use_heun=True)
+    noise = generate_noise(1234, 4, 16384).to(device)
+    smp(noise, fn=diff.denoise_fn, net=net, sigmas=sig)
+    torch.cuda.synchronize()
+    runs = []
+    for _ in range(5):
         t0 = time.perf_counter()
-        n = 0
-        while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 20):
-            fn(x, sigma=torch.tensor(3.0 / (n + 1)))
-            n += 1
-        dt = (time.perf_counter() - t0) / n
-    wps = b / (dt * nfe_per_waveform)
-    return {"value": wps * length, "unit": "audio-samples/s", "waveforms_per_s": wps, "cores": cores, "kind": "port",
-            "sample": f"oracle denoiser on the same net, batch {b}, {n} NFEs timed ({dt:.3f} s/NFE), scaled to {nfe_per_waveform} NFE per waveform"}
+        smp(noise, fn=diff.denoise_fn, net=net, sigmas=sig)
+        torch.cuda.synchronize()
+        runs.append(time.perf_counter() - t0)
+    med = statistics.median(runs)
+    return {"s_per_batch_median": med, "waveforms_per_s": 4.0 / med, "audio_samples_per_s": 4.0 * 16384 / med, "dtype": "fp32"}
+
+
+# ---------------------------------------------------------------------------------------------------- main
+def make_sampler(A, a):
+    if a.sampler == "heun":
+        return A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=a.num_steps, use_heun=True, use_graph=not a.no_graph), 2 * a.num_steps - 1
+    return A.DPMSampler(1.0, order=3, num_steps=a.num_steps, multisteps=True, x0_pred=True, log_time_spacing=False,
+                        use_graph=not a.no_graph), a.num_steps - 1
 
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and env_world is None:
+        # not under a launcher: start the ranks (this parent never touches a GPU)
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {have} device(s) visible", file=sys.stderr)
+            raise SystemExit(2)
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
+    import torch
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} does not match WORLD_SIZE {world}", file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local)
@@ -147,8 +346,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f"# note: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     import audiodiffuser_amd as A
     from audiodiffuser_amd.weights import generate_weights
@@ -156,18 +353,11 @@ def main():
 
     cfg = A.PRESETS[a.config]()
     net = A.UNet1dBase.from_config(cfg, compute_dtype=a.dtype)
-    net.cfg_name = a.config
     net.load_state_dict(generate_weights(cfg, seed=0))     # every rank regenerates the same weights
     net = net.to(device)
     diff = A.EluDiffusion(sigma_data=0.2)
     sigmas = A.KarrasSchedule(0.002, 80.0, 7.0, a.num_steps)()
-    if a.sampler == "heun":
-        sampler = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=a.num_steps, use_heun=True, use_graph=not a.no_graph)
-        nfe = 2 * a.num_steps - 1
-    else:
-        sampler = A.DPMSampler(1.0, order=3, num_steps=a.num_steps, multisteps=True, x0_pred=True, log_time_spacing=False,
-                               use_graph=not a.no_graph)
-        nfe = a.num_steps - 1
+    sampler, nfe = make_sampler(A, a)
     global_batch = a.batch * world
     noise = rank_noise(global_batch, a.length, rank, world).to(device)
 
@@ -183,8 +373,9 @@ def main():
     hd = net.native(device)
     if a.roofline_only:
         net(noise[:a.batch], torch.zeros(a.batch, device=device))
-        r = roofline(net, hd, a.batch, a.length, a.dtype, max(a.roofline_iters, 200), device)
-        print(json.dumps({"roofline": r}))
+        torch.cuda.synchronize()
+        rows = replay_rows(hd, a.batch, a.length, a.roofline_iters, device, a.roofline_level, a.roofline_conv)
+        print(json.dumps({"rows": rows}))
         return
 
     for _ in range(a.warmup):
@@ -199,24 +390,56 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max()) <= 1.0 + 1e-6 if a.sampler == "heun" else True
+    finite = bool(torch.isfinite(out).all().item())
+    clamped = float(out.abs().max()) <= 1.0 + 1e-6
     waveforms = global_batch * a.steps
     value = waveforms * a.length / dt
+    sname = "Heun" if a.sampler == "heun" else "DPM-Solver multistep"
     res = {
-        "metric": "audio samples/sec (16384-sample waveform, 50-step Heun)", "value": value, "unit": "audio-samples/s",
+        "metric": f"audio samples/sec ({a.length}-sample waveform, {a.num_steps}-step {sname})", "value": value, "unit": "audio-samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "waveforms_per_s": waveforms / dt, "nfe_per_waveform": nfe, "finite_and_clamped": ok,
+        "waveforms_per_s": waveforms / dt, "nfe_per_waveform": nfe, "finite": finite, "clamped": clamped,
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
         "config": {"workload": f"{WORKLOADS.get(a.config, a.config)}: UNet1d {cfg.channels} ch ({a.config}), {a.length}-sample waveforms, "
                                f"KarrasSchedule N={a.num_steps} {a.sampler}, batch {a.batch}/GPU, random-init weights",
                    "global_batch": global_batch, "sampler": a.sampler, "num_steps": a.num_steps, "nfe": nfe,
                    "hipgraph": not a.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
     }
     if rank == 0:
-        res["roofline"] = roofline(net, hd, a.batch, a.length, a.dtype, a.roofline_iters, device)
+        net(noise[:a.batch], torch.zeros(a.batch, device=device))       # one eager pass: the replay reads its operands
+        torch.cuda.synchronize()
+        rf = roofline(hd, a.batch, a.length, a.dtype, a.roofline_iters, device)
+        res["roofline"] = rf
+        if rf and world == 1 and not a.no_pmc:
+            traffic, detail = pmc_traffic(a, rf["level"], rf["conv"])
+            rf["traffic"] = traffic
+            rf["traffic_source"] = detail
+        if a.dtype == "bf16" and not a.no_precision_check:
+            # the parity-grade (fp32) mode on the first waveforms of the same noise: what the storage precision costs the audio
+            nb = min(2, a.batch)
+            net32 = A.UNet1dBase.from_config(cfg, compute_dtype="fp32")
+            net32.load_state_dict(generate_weights(cfg, seed=0))
+            net32 = net32.to(device)
+            t1 = time.perf_counter()
+            y32 = sampler(noise[:nb].contiguous(), fn=diff.denoise_fn, net=net32, sigmas=sigmas)
+            torch.cuda.synchronize()
+            t32 = time.perf_counter() - t1
+            y16 = out[:nb].to(torch.float64)
+            d = y16 - y32.to(torch.float64)
+            res["bf16_vs_fp32"] = {"waveforms": nb, "rel_l2": float(d.norm() / y32.to(torch.float64).norm()),
+                                   "max_abs_over_max": float(d.abs().max() / y32.abs().max()),
+                                   "note": "bf16 run (the timed one) against the fp32 mode (held to the CPU oracle at <= 1e-3 by tests/test_gpu_parity.py) on the same noise",
+                                   "fp32_first_run_s_incl_setup": t32}
+            res["bf16_vs_fp32_rel_err"] = res["bf16_vs_fp32"]["rel_l2"]
+            del net32
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, a.length, nfe)
-            res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+            res["cpu_baseline"] = cpu_baseline(cfg, a.length, nfe, value)
+            res["gpu_over_cpu"] = res["cpu_baseline"]["gpu_over_cpu_same_workload"]
+            g1 = gpu_config1(device)
+            res["cpu_baseline"]["config1"]["gpu_hip_fp32"] = g1
+            k = max(int(key.split("_")[1]) for key in res["cpu_baseline"]["config1"] if key.startswith("threads_"))
+            res["cpu_baseline"]["config1"]["gpu_over_cpu"] = g1["waveforms_per_s"] / res["cpu_baseline"]["config1"][f"threads_{k}"]["waveforms_per_s"]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

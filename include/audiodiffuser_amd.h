@@ -20,6 +20,10 @@
  *     is enqueued there, nothing synchronises the device except adf_load_weight's final packing, which is
  *     also stream-ordered.
  *   - one handle is not thread-safe; distinct handles are independent.
+ *   - a handle belongs to the device that was current at adf_create: every entry point makes that device current for
+ *     its duration (and restores the caller's), so pointers and the stream must belong to that device.
+ *   - memory the library keeps grows only up to a cap: at most 4 (B, L) workspaces per handle and 8 captured sampler
+ *     graphs per workspace are retained (least recently used ones are released).
  */
 #ifndef AUDIODIFFUSER_AMD_H
 #define AUDIODIFFUSER_AMD_H
@@ -105,11 +109,12 @@ int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, fl
                 float* out, int B, int L, void* stream);
 
 /* Full sampling loop.  sigmas_host: the schedule tensor (host, n_sigmas entries) the reference passes as
- * `sigmas`; noise: unit-variance [B][C][L]; injected_noise: [num_steps][B][C][L] draws replacing
+ * `sigmas`; noise: unit-variance [B][C][L]; injected_noise: [n_injected][B][C][L] draws replacing
  * randn_like, one per step in the reference's order (required when the EDM / DPM2 sampler churns and always for
- * ADPM2, which adds noise every step; may be NULL otherwise). */
+ * ADPM2, which adds noise every step; may be NULL otherwise).  n_injected = number of [B][C][L] draws behind the
+ * pointer: fewer than the sampler consumes (num_steps for EDM, num_steps - 1 for DPM2 / ADPM2) is an error. */
 int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas,
-                    const float* noise, const float* injected_noise, float* out, int B, int L, void* stream);
+                    const float* noise, const float* injected_noise, int n_injected, float* out, int B, int L, void* stream);
 int adf_sampler_nfe(const adf_sampler_desc* desc, const float* sigmas_host, int n_sigmas);
 
 /* Parity-test support: copy an internal activation of the LAST adf_net_forward/adf_denoise call, converted to
@@ -122,11 +127,17 @@ const char* adf_debug_tap_name(adf_handle* h, int index);
 /* Bytes of device memory held by the handle (weights + workspaces). */
 int64_t adf_device_bytes(const adf_handle* h);
 
-/* Instrumentation for bench.py: time launches [first, last) of the last eager forward is not exposed;
- * instead a single fused-resblock pair can be replayed in isolation with HIP events on `stream`. */
+/* Instrumentation for bench.py: the two GEMM launches of resblock `level` of the last forward are replayed `iters` times
+ * with HIP events on `stream`, exactly as the network pass issues them (GroupNorm table from the input statistics,
+ * output statistics in the epilogue), each iteration on another copy of the operands (>= 3 copies, >= 320 MiB in
+ * rotation) so that the 256 MiB Infinity Cache cannot serve them.  *_block1 = conv1, *_block2 = conv2 (+ residual). */
 int adf_bench_resblock(adf_handle* h, int B, int L, int level, int iters, float* ms_block1, float* ms_block2,
                        double* algo_bytes_block1, double* algo_bytes_block2, double* flops_block1,
                        double* flops_block2, void* stream);
+/* One of the two launches only (conv = 1 | 2); *copies = number of operand copies in rotation = number of untimed warm-up
+ * launches that precede the `iters` timed ones (lets a profiler pass pick out the timed dispatches). */
+int adf_bench_layer(adf_handle* h, int B, int L, int level, int conv, int iters, float* ms, double* algo_bytes, double* flops,
+                    int* copies, void* stream);
 
 #ifdef __cplusplus
 }

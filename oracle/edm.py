@@ -48,11 +48,13 @@ def denoise(net: Callable[..., torch.Tensor], x_noisy: torch.Tensor,
 
 
 def make_denoiser(p: P, cfg: UNet1dConfig, sigma_data: float, classes: Optional[torch.Tensor] = None,
-                  cond_scale: float = 1.0) -> Callable:
+                  cond_scale: float = 1.0, storage: str = "fp32") -> Callable:
     """fn(x, sigma) -> denoised, the closure the samplers call (module call site:
-    src/models/diffunet_complex_module.py:86-89); ``classes`` / ``cond_scale`` as the module forwards them."""
+    src/models/diffunet_complex_module.py:86-89); ``classes`` / ``cond_scale`` as the module forwards them.
+    ``storage="bf16"``: the network in the bf16-storage arithmetic of oracle/unet1d.py (the preconditioning, the
+    clamp and the sampler state stay fp32, as on the device)."""
     def net(xi, t, cond_drop_prob=0.0):
-        return unet1d_forward(p, cfg, xi, t, classes=classes, cond_drop_prob=cond_drop_prob)
+        return unet1d_forward(p, cfg, xi, t, classes=classes, cond_drop_prob=cond_drop_prob, storage=storage)
 
     def fn(x, sigma=None, sigmas=None):
         return denoise(net, x, sigma_data, sigma=sigma, sigmas=sigmas, cond_scale=cond_scale)

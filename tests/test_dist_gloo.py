@@ -59,3 +59,31 @@ def test_sharded_sampling_matches_single_process(gb):
         assert torch.equal(got[r], want), f"rank {r} gathered result differs from the unsharded run"
     lo, hi = shard_range(gb, 1, world)
     assert hi == gb and lo == (gb + 1) // 2
+
+
+def test_launch_ranks_path(tmp_path):
+    """The launcher bench.py --gpus N uses (audiodiffuser_amd.distributed.launch_ranks -> torch.distributed.run, rendezvous on
+    127.0.0.1) with 2 CPU ranks over gloo: both ranks come up, the gathered result equals the unsharded run."""
+    import json
+    import subprocess
+    from audiodiffuser_amd.distributed import launch_ranks
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag", "dist_launcher_probe.py")
+    log = tmp_path / "out.txt"
+    with open(log, "w") as f:
+        rc = launch_ranks(probe, 2, ["6", "128"], stdout=f, timeout=300)
+    assert rc == 0
+    line = [l for l in open(log).read().splitlines() if l.startswith("{")][-1]
+    rep = json.loads(line)
+    assert rep["n_ranks"] == 2 and rep["env_world"] == 2 and rep["master"] == "127.0.0.1" and rep["shape"] == [6, 1, 128]
+    want = _run_local(generate_noise(0, 6, 128))
+    assert abs(rep["sum"] - float(want.double().sum())) < 1e-9 * max(1.0, abs(float(want.double().sum())))
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """bench.py --gpus N must not silently run on fewer devices: with no (or too few) GPUs visible it exits non-zero."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "--gpus 64" in r.stderr

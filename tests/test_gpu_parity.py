@@ -1,9 +1,16 @@
 """GPU (MI355X) parity tests: the HIP path, called through the C ABI via the plugin classes, against
 (a) the golden fixtures = outputs of the reference itself, and (b) the CPU oracle on the same seeded inputs.
 
-Tolerances.  north_star: <= 1e-3 relative (fp32) to the reference CPU path.  fp32 (parity) mode is held to
-FP32_TOL below; bf16 (throughput) mode is a reduced-precision storage mode whose own measured error is bounded
-by BF16_TOL and is not a parity claim.  Relative error = max|a-b| / max|b| over the whole tensor."""
+Tolerances.  north_star: <= 1e-3 relative (fp32) to the reference CPU path.
+  * fp32 (parity) mode is held to FP32_TOL (measured ~2e-6, guarded at FP32_TIGHT); error = max|a-b| / max|b|.
+  * bf16 (throughput) mode -- the mode bench.py times -- is held against the bf16-STORAGE oracle (oracle/unet1d.py,
+    storage="bf16": the pinned fp32 restatement with a bf16 rounding wherever the device stores bf16), in relative L2
+    (a max-norm figure sits at one bf16 ulp = 2^-8 as soon as one rounding flips):
+      BF16_LAYER_TOL  every recorded layer, teacher-forced (the oracle layer gets the device's own previous outputs):
+                      what is left is summation order inside fp32 accumulations and the few roundings it flips;
+      BF16_CHAIN_TOL  the oracle running free from the same input: those deviations compounded through ~60 tensors.
+    A wrong halo row, a mis-scaled skip segment or a dropped bias shows up at >= 1e-2 in the teacher-forced figure.
+  * BF16_TOL is kept only for bf16 against fp32 (the storage precision itself: ~1e-2 by the end of the net)."""
 import ctypes as C
 import os
 
@@ -14,12 +21,14 @@ import torch
 import audiodiffuser_amd as A
 from audiodiffuser_amd import _lib
 from audiodiffuser_amd.weights import generate_noise, generate_weights
-from gpu_helpers import make_net, rel_err, tap_errors, golden_inputs
+from gpu_helpers import make_net, rel_err, rel_l2, tap_errors, tap_errors_bf16, golden_inputs
 
 pytestmark = pytest.mark.gpu
 FP32_TOL = 1e-3       # the north-star bar; measured ~2e-6
 FP32_TIGHT = 5e-5     # what fp32 mode actually achieves (regression guard)
 BF16_TOL = 6e-2
+BF16_LAYER_TOL = 1e-3
+BF16_CHAIN_TOL = 4e-3
 T = torch.from_numpy
 CASES = [("tiny", A.config_tiny), ("c1", A.config_c1)]
 
@@ -41,12 +50,39 @@ def test_every_layer_fp32(tag, mk, flags):
     assert not bad, bad
 
 
+def _assert_bf16_parity(cfg, x, t, chained=True, flags=0):
+    """bf16 device path vs the bf16-storage oracle: every layer teacher-forced, and (chained) free-running."""
+    forced, chain, y, y_f, y_c = tap_errors_bf16(cfg, x, t, flags=flags, chained=chained)
+    assert len(forced) > 10
+    bad = {k: v for k, v in forced.items() if not v < BF16_LAYER_TOL}
+    assert not bad, ("teacher-forced", bad)
+    bad = {k: v for k, v in chain.items() if not v < BF16_CHAIN_TOL}
+    assert not bad, ("free-running", bad)
+    assert torch.isfinite(y).all()
+    return forced, chain
+
+
 @pytest.mark.parametrize("tag,mk", CASES)
-def test_every_layer_bf16(tag, mk):
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_SEPARATE_GN_STATS])
+def test_every_layer_bf16(tag, mk, flags):
     x, t = golden_inputs(tag)
-    errs, y, yo = tap_errors(mk(), x, t, "bf16", 0)
+    _assert_bf16_parity(mk(), x, t, flags=flags)
+    errs, y, yo = tap_errors(mk(), x, t, "bf16", flags)      # and the storage precision itself against fp32
     bad = {k: v for k, v in errs.items() if not v < BF16_TOL}
     assert not bad, bad
+
+
+def test_c3_width_net_vs_reference_golden(golden):
+    """The reference's own forward at the 64-channel width / head dim 32 / attentions=[F,F,T,T,T,T] (B = 1, L = 2048)."""
+    cfg = A.config_c3()
+    net, _ = make_net(cfg, "fp32")
+    x, t = T(golden["net_c3_x"]).cuda(), T(golden["net_c3_t"]).cuda()
+    y = net(x, t)
+    assert rel_err(y.cpu(), T(golden["net_c3_y"])) < FP32_TIGHT
+    hd = net.native(y.device)
+    for name in hd.tap_names():
+        got = hd.tap(name, 1, y.device).cpu()
+        assert rel_err(got.reshape(1, -1)[:, ::61], T(golden[f"net_c3_tap_{name}"])) < FP32_TIGHT, name
 
 
 @pytest.mark.parametrize("tag,mk", CASES)
@@ -136,6 +172,64 @@ def test_error_behaviour():
     assert torch.isfinite(y).all()          # churn draws its own noise when none is injected
 
 
+def test_injected_noise_is_shape_checked_and_rng_advances_like_the_reference():
+    """(a) a draw tensor with too few steps / another batch or length raises before anything is copied (the C side reads
+    n * B * C * L floats from the pointer; the ABI carries n and rejects a short buffer itself);
+    (b) the reference's EDM step draws randn_like(x) every step even when gamma == 0 (sampler_edm.py:346): after a
+    deterministic run the global generator must be where the reference leaves it, so the next batch's noise matches."""
+    cfg = A.config_tiny()
+    net, _ = make_net(cfg, "fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 6)()
+    noise = generate_noise(0, 2, 128).cuda()
+    churn = A.EDMSampler(s_tmin=0.05, s_tmax=50.0, s_churn=20.0, s_noise=1.0, num_steps=6)
+    for bad in (torch.zeros(5, 2, 1, 128), torch.zeros(6, 3, 1, 128), torch.zeros(6, 2, 1, 64), torch.zeros(6, 2, 128)):
+        with pytest.raises(ValueError):
+            churn(noise, fn=d.denoise_fn, net=net, sigmas=sig, injected_noise=bad.cuda())
+    with pytest.raises(ValueError):
+        A.ADPM2Sampler(num_steps=6)(noise, fn=d.denoise_fn, net=net, sigmas=sig, injected_noise=torch.zeros(4, 2, 1, 128).cuda())
+    hd = net.native(noise.device)
+    with pytest.raises(_lib.AdfError):          # straight through the C ABI: 3 draws where 6 are consumed
+        hd.sampler_run(churn._desc(0.2), sig, noise, torch.zeros(3, 2, 1, 128, device="cuda"))
+    ode = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=6)
+    torch.manual_seed(5)
+    ode(noise, fn=d.denoise_fn, net=net, sigmas=sig)
+    after_native = torch.randn(8, device="cuda")
+    torch.manual_seed(5)
+    for _ in range(6):
+        torch.randn_like(noise)
+    assert torch.equal(after_native, torch.randn(8, device="cuda"))
+
+
+def test_plan_and_graph_caches_are_bounded():
+    """A long-running caller with varying batch sizes and schedules must not accumulate workspaces / captured graphs:
+    device bytes held by the handle stay bounded and old shapes still work after they were evicted."""
+    cfg = A.config_tiny()
+    net, _ = make_net(cfg, "fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+    first = None
+    sizes = []
+    for rep in range(3):
+        for B in (1, 2, 3, 4, 5, 6):
+            x = generate_noise(0, B, 256).cuda()
+            y = net(x, torch.zeros(B, device="cuda"))
+            if B == 1 and first is None:
+                first = y.clone()
+            sizes.append(hd.lib.adf_device_bytes(hd.h))
+    assert max(sizes[6:]) <= max(sizes[:6])                     # no growth after the first sweep
+    assert rel_err(net(generate_noise(0, 1, 256).cuda(), torch.zeros(1, device="cuda")), first) < 1e-6
+    noise = generate_noise(3, 2, 256).cuda()
+    base = None
+    for n in range(4, 16):                                       # 12 different schedules through one (B, L) plan
+        smp = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=n, use_graph=True)
+        y = smp(noise, fn=d.denoise_fn, net=net, sigmas=A.KarrasSchedule(0.002, 80.0, 7.0, n)())
+        if n == 4:
+            base = y.clone()
+    smp = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=4, use_graph=True)                      # evicted by now: re-captured
+    assert rel_err(smp(noise, fn=d.denoise_fn, net=net, sigmas=A.KarrasSchedule(0.002, 80.0, 7.0, 4)()), base) < 1e-6
+
+
 # ---- full BASELINE sizes: size-independent properties -------------------------------------------------------
 def test_c1_full_length_vs_reference_golden(golden):
     cfg = A.config_c1()
@@ -188,6 +282,8 @@ def test_config3_every_layer_short(dtype, tol):
     assert sum("attn" in k for k in errs) == 9
     bad = {k: v for k, v in errs.items() if not v < tol}
     assert not bad, bad
+    if dtype == "bf16":
+        _assert_bf16_parity(A.config_c3(), x, torch.tensor([-0.9, 0.35]))
 
 
 def test_config3_attention_at_1024_tokens_vs_oracle():
@@ -203,11 +299,72 @@ def test_config3_attention_at_1024_tokens_vs_oracle():
     assert rel_err(y.cpu(), yo) < FP32_TIGHT
 
 
+def test_config3_bf16_attention_at_1024_tokens_vs_bf16_oracle():
+    """BASELINE config 3 in the benched (bf16) mode: the MFMA attention kernel's 32-key-tile loop at N = 1024 tokens (the
+    16x level, down2.attn / up3.attn) and every other layer, one waveform at full length, against the bf16-storage oracle."""
+    forced, chain = _assert_bf16_parity(A.config_c3(), generate_noise(3, 1, 16384) * 0.6, torch.tensor([0.2]))
+    assert "down2.attn" in forced and "up3.attn" in forced
+
+
+def test_config3_dpm_sampler_full_length_vs_oracle():
+    """BASELINE config 3's sampler on its network: DPMSampler(order 3, multistep, 50 sigmas = 49 NFE) on the C3 net, one
+    16384-sample waveform, fp32 mode, against oracle.samplers.dpm_multistep_sampler on the CPU."""
+    from oracle import edm as E, samplers as S
+    cfg = A.config_c3()
+    net, w = make_net(cfg, "fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 50)()
+    noise = generate_noise(4321, 1, 16384)
+    smp = A.DPMSampler(cond_scale=1.0, order=3, num_steps=50, multisteps=True, x0_pred=True, log_time_spacing=False)
+    y = smp(noise.cuda(), fn=d.denoise_fn, net=net, sigmas=sig)
+    with torch.no_grad():
+        yo = S.dpm_multistep_sampler(noise, E.make_denoiser(w, cfg, 0.2), sig, 50, order=3)
+    assert rel_err(y.cpu(), yo) < FP32_TOL
+
+
+def test_bf16_heun_sampler_against_fp32_and_bf16_oracle():
+    """The benched mode through the sampler.  (a) 8-step Heun (15 NFE) on the C2 net, two full-length waveforms: the bf16
+    device run against the SAME sampler over the bf16-storage oracle on the CPU -- trajectories stay within compounded
+    accumulation-order noise; (b) the full 50-step Heun schedule (99 NFE) of BASELINE configs[1]: bf16 device run against the
+    fp32 device run (which the other tests hold to the oracle at 1e-3): the storage precision's effect on the final audio."""
+    from oracle import edm as E, samplers as S
+    cfg = A.config_c2()
+    net16, w = make_net(cfg, "bf16")
+    net32, _ = make_net(cfg, "fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    noise = generate_noise(777, 2, 16384)
+    sig8 = A.KarrasSchedule(0.002, 80.0, 7.0, 8)()
+    y16 = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=8)(noise.cuda(), fn=d.denoise_fn, net=net16, sigmas=sig8).cpu()
+    with torch.no_grad():
+        yo = S.edm_sampler(noise, E.make_denoiser(w, cfg, 0.2, storage="bf16"), sig8, 8, s_churn=0.0, s_noise=1.0)
+    assert rel_l2(y16, yo) < 5e-3, rel_l2(y16, yo)
+    sig50 = A.KarrasSchedule(0.002, 80.0, 7.0, 50)()
+    smp = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=50)
+    a = smp(noise.cuda(), fn=d.denoise_fn, net=net16, sigmas=sig50).cpu()
+    b = smp(noise.cuda(), fn=d.denoise_fn, net=net32, sigmas=sig50).cpu()
+    assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
+    assert rel_l2(a, b) < 5e-2, rel_l2(a, b)             # measured value: profiles/r02_bf16_parity_report.json
+    assert rel_err(a, b) < 1.5e-1, rel_err(a, b)
+
+
+def test_config2_batch64_full_length_bf16_vs_bf16_oracle():
+    """The benched configuration itself: C2, batch 64, 16384 samples, bf16 -- one forward, every recorded layer teacher-forced
+    against the bf16-storage oracle (the routes the launcher picks at 64 x L rows are the ones the bench times)."""
+    x = generate_noise(0, 64, 16384) * 0.7
+    forced, chain, y, y_f, y_c = tap_errors_bf16(A.config_c2(), x, torch.linspace(-1.2, 0.6, 64), chained=False)
+    bad = {k: v for k, v in forced.items() if not v < BF16_LAYER_TOL}
+    assert not bad, bad
+    assert torch.isfinite(y).all()
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
 def test_config2_batch8_every_layer_large_tile_routes(dtype, tol):
     """BASELINE config 2 at batch 8, full length: >= 256 row tiles per layer, the size from which the launcher picks
     the persistent weight-stationary / LDS-DMA GEMM kernels.  Every recorded layer against the oracle."""
     x = generate_noise(0, 8, 16384) * 0.7
+    if dtype == "bf16":
+        _assert_bf16_parity(A.config_c2(), x, torch.linspace(-1.0, 0.5, 8))
+        return
     errs, y, yo = tap_errors(A.config_c2(), x, torch.linspace(-1.0, 0.5, 8), dtype, 0)
     bad = {k: v for k, v in errs.items() if not v < tol}
     assert not bad, bad
@@ -458,6 +615,9 @@ def test_config2_shape_sweep_vs_oracle(B, L):
     net16, _ = make_net(cfg, "bf16")
     y16 = net16(x.cuda(), t.cuda()).cpu()
     assert torch.isfinite(y16).all() and rel_err(y16, yo) < BF16_TOL
+    with torch.no_grad():
+        yo16 = O.unet1d_forward(w, cfg, x, t, storage="bf16")
+    assert rel_l2(y16, yo16) < BF16_CHAIN_TOL, rel_l2(y16, yo16)
 
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
@@ -465,6 +625,9 @@ def test_config2_batch32_every_layer_splitk_64_tiles(dtype, tol):
     """Batch 32 at full length: the 64-row level has 2048 rows, the size from which the split-K kernel switches to
     64 x 64 tiles (>= 128 blocks).  Every recorded layer against the oracle."""
     x = generate_noise(200, 32, 16384) * 0.7
+    if dtype == "bf16":
+        _assert_bf16_parity(A.config_c2(), x, torch.linspace(-1.0, 0.5, 32), chained=False)
+        return
     errs, y, yo = tap_errors(A.config_c2(), x, torch.linspace(-1.0, 0.5, 32), dtype, 0)
     bad = {k: v for k, v in errs.items() if not v < tol}
     assert not bad, bad

@@ -50,9 +50,10 @@ def test_state_dict_layout_matches_reference():
     assert lay["c1"]["num_params"] == 1510040 and lay["c2"]["num_params"] == 23937632
 
 
-@pytest.mark.parametrize("tag", ["tiny", "c1"])
+@pytest.mark.parametrize("tag", ["tiny", "c1", "c3"])
 def test_unet_forward_and_taps(golden, tag):
-    cfg = config_tiny() if tag == "tiny" else config_c1()
+    """tiny / c1, and c3 = the 64-channel width, head dim 32 and attention placement of BASELINE configs[1] / [2]."""
+    cfg = {"tiny": config_tiny, "c1": config_c1, "c3": config_c3}[tag]()
     w = generate_weights(cfg, seed=0)
     x, t = T(golden[f"net_{tag}_x"]), T(golden[f"net_{tag}_t"])
     taps = {}
@@ -64,6 +65,58 @@ def test_unet_forward_and_taps(golden, tag):
         ref = T(golden[f"net_{tag}_tap_{name}"])
         got = v.reshape(v.shape[0], -1)[:, ::stride]
         assert rel(got, ref) < 1e-5, name
+
+
+def test_bf16_storage_rounding_is_round_to_nearest_even():
+    q = O.Storage("bf16")
+    x = torch.tensor([1.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 1.0 + 2.0 ** -8 + 2.0 ** -20, -3.0e-5, 65504.0])
+    # 1 + 2^-8 is a tie between 1 and 1 + 2^-7 -> even mantissa (1.0); 1 + 3*2^-8 ties to the even 1 + 2^-6; just above a tie rounds up
+    want = torch.tensor([1.0, 1.0, 1.015625, 1.0078125, -3.0040740966796875e-05, 65536.0])
+    assert torch.equal(q.r(x), want)
+    assert O.Storage("fp32").r(x) is x
+
+
+@pytest.mark.parametrize("tag", ["tiny", "c1"])
+def test_bf16_storage_oracle_is_statistically_consistent_with_fp32(golden, tag):
+    """The bf16-storage mode is the fp32 restatement plus roundings: its distance from fp32 must look like compounded bf16
+    rounding noise (2^-9 per stored tensor, ~60 tensors deep: 1e-3 .. 3e-2 relative L2), at every recorded layer."""
+    cfg = config_tiny() if tag == "tiny" else config_c1()
+    w = generate_weights(cfg, seed=0)
+    x, t = T(golden[f"net_{tag}_x"]), T(golden[f"net_{tag}_t"])
+    t32, t16 = {}, {}
+    with torch.no_grad():
+        y32 = O.unet1d_forward(w, cfg, x, t, taps=t32)
+        y16 = O.unet1d_forward(w, cfg, x, t, taps=t16, storage="bf16")
+    assert set(t32) == set(t16)
+    errs = {k: O.rel_l2(t16[k], t32[k]) for k in t32 if k != "temb"}
+    assert all(1e-3 < v < 3e-2 for v in errs.values()), errs
+    assert O.rel_l2(t16["temb"], t32["temb"]) == 0.0           # the sigma embedding stays fp32
+    assert 2e-3 < O.rel_l2(y16, y32) < 3e-2
+    for k, v in t16.items():                                    # every stored activation is a bf16 value
+        if k != "temb":
+            assert torch.equal(v, v.to(torch.bfloat16).float()), k
+
+
+def test_teacher_forcing_isolates_layers(golden):
+    """force= replaces each recorded activation: forcing a run's own taps reports zero error everywhere; a perturbation
+    of ONE forced tap shows up at that tap and at its two direct consumers (the next block and the up-path block that
+    takes it as its skip input, whose forced outputs here come from the unperturbed run) and nowhere else."""
+    cfg = config_tiny()
+    w = generate_weights(cfg, seed=0)
+    x, t = T(golden["net_tiny_x"]), T(golden["net_tiny_t"])
+    for storage in ("fp32", "bf16"):
+        taps, errs = {}, {}
+        with torch.no_grad():
+            y = O.unet1d_forward(w, cfg, x, t, taps=taps, storage=storage)
+            y2 = O.unet1d_forward(w, cfg, x, t, storage=storage, force=dict(taps), errs=errs)
+        assert max(errs.values()) == 0.0 and torch.equal(y, y2)
+        bad = dict(taps)
+        bad["down1.block0"] = taps["down1.block0"] * 1.01
+        errs = {}
+        with torch.no_grad():
+            O.unet1d_forward(w, cfg, x, t, storage=storage, force=bad, errs=errs)
+        wrong = {k for k, v in errs.items() if v > 0}
+        assert wrong == {"down1.block0", "down1.block1", "up1.block2"}, wrong
 
 
 def test_inputs_regenerate_identically(golden):
