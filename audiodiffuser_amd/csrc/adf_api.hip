@@ -506,6 +506,7 @@ struct Walker {
             g1.seg[0].gn = f1;           // launch_conv_gemm derives the table (in the DMA kernel) or launches gn_finalize
         }
         run_gemm(g1, h1, true);
+        tap(name + ".h1", h1);        // the block's stored intermediate (not there when the whole block is one launch)
         double* sh = ensure_stats(h1);
         float* ab2 = (float*)alloc((size_t)B * r.cout * 2 * 4);
         GnFinalizeArgs f2;

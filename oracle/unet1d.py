@@ -102,14 +102,17 @@ def label_embedding(p: P, classes: torch.Tensor, cond_drop_prob: float) -> torch
 
 
 def resnet_block(p: P, pre: str, x: torch.Tensor, temb: torch.Tensor, groups: int, q: Storage = FP32,
-                 x_raw: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 x_raw: Optional[torch.Tensor] = None, rec_h1=None) -> torch.Tensor:
     """unet1d.py:297-316.  FiLM (scale, shift) = chunk(Linear(SiLU(cat(time_embed, class_embed)))) feeds block2 only
     (the caller passes the concatenation as ``temb``).  ``x_raw``: the input as the residual 1x1 conv reads it
     (bf16 storage rounds the scaled skip half of a concatenation there; the GroupNorm path folds the scale into
-    its affine and never materialises it)."""
+    its affine and never materialises it).  ``rec_h1``: callback recording (and possibly forcing) the stored intermediate
+    h1 = conv1 output, the tap "<block>.h1" of the device's two-launch resblocks."""
     cond = F.linear(F.silu(temb), p[f"{pre}.to_cond_embedding.1.weight"], p[f"{pre}.to_cond_embedding.1.bias"])
     scale, shift = cond[:, :, None].chunk(2, dim=1)
     h = q.r(conv_block(p, f"{pre}.block1", x, groups, q=q))
+    if rec_h1 is not None:
+        h = rec_h1(h)
     h = conv_block(p, f"{pre}.block2", h, groups, scale, shift, q=q)
     key = f"{pre}.to_out.weight"
     xr = x if x_raw is None else x_raw
@@ -207,6 +210,9 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
             return force[name].to(torch.float32)
         return v
 
+    def h1rec(block):
+        return lambda v: rec(block + ".h1", v)
+
     h = rec("to_in", q.r(F.conv1d(x, p["unet.to_in.to_in.weight"], stride=cfg.stride, padding=pad)))  # :584-591 (fp32 weights on the device too)
     temb = rec("temb", time_embedding(p, t))
     if classes is not None:                                                       # :877, resblocks :306-308
@@ -217,16 +223,16 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
         h = rec(f"down{i}.conv", downsample_conv(p, f"{pre}.downsample", h, cfg.factors[i], cfg.kernel_multiplier_downsample, q))
         skips = []
         for j in range(cfg.num_blocks[i]):
-            h = rec(f"down{i}.block{j}", resnet_block(p, f"{pre}.blocks.{j}", h, temb, g, q))
+            h = rec(f"down{i}.block{j}", resnet_block(p, f"{pre}.blocks.{j}", h, temb, g, q, rec_h1=h1rec(f"down{i}.block{j}")))
             skips.append(h)
         if cfg.attentions[i]:
             h = rec(f"down{i}.attn", transformer_block(p, f"{pre}.transformer", h, heads, q))
             skips.append(h)
         skips_list.append(skips)
-    h = rec("mid.pre", resnet_block(p, "unet.bottleneck.pre_block", h, temb, g, q))    # :374-379
+    h = rec("mid.pre", resnet_block(p, "unet.bottleneck.pre_block", h, temb, g, q, rec_h1=h1rec("mid.pre")))    # :374-379
     if cfg.use_attention_bottleneck:
         h = rec("mid.attn", transformer_block(p, "unet.bottleneck.transformer", h, heads, q))
-    h = rec("mid.post", resnet_block(p, "unet.bottleneck.post_block", h, temb, g, q))
+    h = rec("mid.post", resnet_block(p, "unet.bottleneck.post_block", h, temb, g, q, rec_h1=h1rec("mid.post")))
     skip_scale = 2 ** -0.5 if cfg.use_skip_scale else 1.0
     for u, i in enumerate(reversed(range(n))):                                    # :807-812, :542-566
         pre = f"unet.upsamples.{u}"
@@ -236,7 +242,7 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
             sk = skips.pop() * skip_scale
             hx = torch.cat([h, sk], dim=1)                                        # :539-540
             hraw = torch.cat([h, q.r(sk)], dim=1) if q.bf16 else None
-            h = rec(f"up{u}.block{j}", resnet_block(p, f"{pre}.blocks.{j}", hx, temb, g, q, x_raw=hraw))
+            h = rec(f"up{u}.block{j}", resnet_block(p, f"{pre}.blocks.{j}", hx, temb, g, q, x_raw=hraw, rec_h1=h1rec(f"up{u}.block{j}")))
         if cfg.attentions[i]:
             h = rec(f"up{u}.attn", transformer_block(p, f"{pre}.transformer", h, heads, q))
         h = rec(f"up{u}.conv", upsample_conv(p, f"{pre}.upsample", h, cfg.factors[i], q))

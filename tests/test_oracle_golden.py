@@ -62,6 +62,8 @@ def test_unet_forward_and_taps(golden, tag):
     assert rel(y, T(golden[f"net_{tag}_y"])) < 1e-5
     stride = 7 if tag == "tiny" else 61
     for name, v in taps.items():
+        if name.endswith(".h1"):          # conv1 output inside a resblock: no module boundary in the reference to hook
+            continue
         ref = T(golden[f"net_{tag}_tap_{name}"])
         got = v.reshape(v.shape[0], -1)[:, ::stride]
         assert rel(got, ref) < 1e-5, name
@@ -100,7 +102,8 @@ def test_bf16_storage_oracle_is_statistically_consistent_with_fp32(golden, tag):
 def test_teacher_forcing_isolates_layers(golden):
     """force= replaces each recorded activation: forcing a run's own taps reports zero error everywhere; a perturbation
     of ONE forced tap shows up at that tap and at its two direct consumers (the next block and the up-path block that
-    takes it as its skip input, whose forced outputs here come from the unperturbed run) and nowhere else."""
+    takes it as its skip input, whose forced outputs here come from the unperturbed run) and nowhere else.  (On the GPU
+    box every forced tap is the device's own, so a faulty layer is flagged at its own tap only.)"""
     cfg = config_tiny()
     w = generate_weights(cfg, seed=0)
     x, t = T(golden["net_tiny_x"]), T(golden["net_tiny_t"])
@@ -111,12 +114,13 @@ def test_teacher_forcing_isolates_layers(golden):
             y2 = O.unet1d_forward(w, cfg, x, t, storage=storage, force=dict(taps), errs=errs)
         assert max(errs.values()) == 0.0 and torch.equal(y, y2)
         bad = dict(taps)
-        bad["down1.block0"] = taps["down1.block0"] * 1.01
+        bad["down1.block0"] = taps["down1.block0"] + 0.01 * taps["down1.block0"].flip(-1)   # (a pure rescale would vanish in the GroupNorm)
         errs = {}
         with torch.no_grad():
             O.unet1d_forward(w, cfg, x, t, storage=storage, force=bad, errs=errs)
         wrong = {k for k, v in errs.items() if v > 0}
-        assert wrong == {"down1.block0", "down1.block1", "up1.block2"}, wrong
+        # (the consumers read it twice: conv1 -> h1, and the residual -- identity in down1.block1, the 1x1 conv in up1.block2)
+        assert wrong == {"down1.block0", "down1.block1.h1", "down1.block1", "up1.block2.h1", "up1.block2"}, wrong
 
 
 def test_inputs_regenerate_identically(golden):
