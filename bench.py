@@ -240,13 +240,24 @@ def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
     prev = torch.get_num_threads()
     out = {"unit": "audio-samples/s", "kind": "port", "cpu_model": cpu_model(), "physical_cores": cores}
     try:
-        torch.set_num_threads(cores)
         w = generate_weights(cfg, seed=0)
         fn = E.make_denoiser(w, cfg, 0.2)
         b = 2
         x = generate_noise(0, b, length) * 3.0
         reps = []
         with torch.no_grad():
+            # torch's CPU convolutions do not scale to every core of a large host (oversubscription): give the CPU its best
+            # thread count -- one evaluation at each candidate after a warm-up, keep the fastest
+            scan = {}
+            for k in sorted({min(c, cores) for c in (8, 16, 32, 64, cores)}):
+                torch.set_num_threads(k)
+                fn(x, sigma=torch.tensor(3.0))
+                t0 = time.perf_counter()
+                fn(x, sigma=torch.tensor(2.0))
+                scan[k] = time.perf_counter() - t0
+            best_k = min(scan, key=scan.get)
+            torch.set_num_threads(best_k)
+            out["thread_scan_s_per_evaluation"] = scan
             fn(x, sigma=torch.tensor(3.0))           # warm-up
             for rep in range(3):
                 t0 = time.perf_counter()
@@ -255,7 +266,7 @@ def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
                 reps.append((time.perf_counter() - t0) / 3)
         dt = statistics.median(reps)
         wps = b / (dt * nfe_per_waveform)
-        out.update({"value": wps * length, "waveforms_per_s": wps, "cores": cores,
+        out.update({"value": wps * length, "waveforms_per_s": wps, "cores": best_k,
                     "sample": f"same network and sampler as the GPU line: oracle denoiser at batch {b}, 1 warm-up + 3 x 3 evaluations, median "
                               f"{dt:.3f} s per evaluation (repeats {', '.join('%.3f' % r for r in reps)}), scaled to {nfe_per_waveform} evaluations per waveform"})
         del w, fn
@@ -438,8 +449,8 @@ def main():
             res["gpu_over_cpu"] = res["cpu_baseline"]["gpu_over_cpu_same_workload"]
             g1 = gpu_config1(device)
             res["cpu_baseline"]["config1"]["gpu_hip_fp32"] = g1
-            k = max(int(key.split("_")[1]) for key in res["cpu_baseline"]["config1"] if key.startswith("threads_"))
-            res["cpu_baseline"]["config1"]["gpu_over_cpu"] = g1["waveforms_per_s"] / res["cpu_baseline"]["config1"][f"threads_{k}"]["waveforms_per_s"]
+            best = max(v["waveforms_per_s"] for key, v in res["cpu_baseline"]["config1"].items() if key.startswith("threads_"))
+            res["cpu_baseline"]["config1"]["gpu_over_cpu"] = g1["waveforms_per_s"] / best      # against the FASTER of the two thread counts
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
