@@ -1,10 +1,12 @@
 // Tile-shape dispatch for the fused implicit-GEMM kernel (see adf_gemm.h).
 #include "adf_gemm.h"
 #include "adf_gemm_pp.h"
+#include "adf_gemm_rb.h"
 #include "adf_gemm_up.h"
 #include "adf_kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #ifdef ADF_PP_STAMP
@@ -12,6 +14,13 @@ namespace adf { __device__ unsigned long long adf_pp_stamps[8 * 32]; }
 // diagnostic build only: copies the stamps of the last DMA-kernel launch to the host
 extern "C" int adf_debug_pp_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adf::adf_pp_stamps), sizeof(unsigned long long) * 8 * 32);
+}
+#endif
+
+#ifdef ADF_RB_STAMP
+namespace adf { __device__ unsigned long long adf_rb_stamps[8 * 16]; }
+extern "C" int adf_debug_rb_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adf::adf_rb_stamps), sizeof(unsigned long long) * 8 * 16);
 }
 #endif
 
@@ -128,6 +137,83 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
     const long long grid = tiles_total < num_cu ? tiles_total : num_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kPpLds, stream, a, (int)tiles_total, tm_shift, tiles_n);
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_pp: launch failed";
+}
+
+// Resblock conv kernel (adf_gemm_rb.h): fills the K-block table of one tile and launches one 512-thread block per CU.
+// Returns false (and launches nothing) when the shape is not one the kernel is written for.
+bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hipStream_t stream, const char** err) {
+    *err = nullptr;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const GemmSeg& g0 = a.seg[0];
+    if (a.scatter_f || a.gelu || a.flat || a.mrows % 256 || a.lin != a.mrows || a.out_rows != a.mrows) return false;
+    if (a.n != a.n_pad || a.out_c != a.n || (a.n != 128 && a.n != 256) || a.bias_mod != a.n) return false;
+    if (!pow2(a.mrows / 256)) return false;
+    if (!g0.gn.gamma || !g0.act || g0.taps != 3 || g0.off0 != -1 || g0.stride != 1 || g0.step != 1) return false;
+    if (g0.c0 % 64 || g0.c1 % 64 || g0.c0 + g0.c1 > kPpMaxCin || ((g0.c0 + g0.c1) / 64) % 2) return false;
+    if (a.res && a.nseg > 1) return false;
+    RbArgs r;
+    memset(&r, 0, sizeof(r));
+    int nb = 0;
+    auto add_seg = [&](const void* s0, const void* s1, int c0, int c1, const void* w, int taps, bool table, float scale1) {
+        for (int c = 0; c < c0 + c1; c += 64, ++nb) {
+            const bool from1 = c >= c0;
+            RbBlk& e = r.blk[nb];
+            e.src = (const char*)(from1 ? s1 : s0) + (size_t)(from1 ? c - c0 : c) * 2;
+            e.pitch = (unsigned)(from1 ? c1 : c0) * 2u;
+            e.w = (const char*)w + (size_t)(c / 64) * taps * a.n_pad * kRowBytes;
+            e.tab = table ? c * 8 : -1;
+            e.scale = from1 ? scale1 : 1.0f;
+        }
+    };
+    add_seg(g0.src0, g0.src1, g0.c0, g0.c1, g0.w, 3, true, 1.0f);
+    r.nb3 = nb;
+    if (a.nseg > 1) {
+        const GemmSeg& g1 = a.seg[1];
+        if (g1.taps != 1 || g1.off0 != 0 || g1.stride != 1 || g1.step != 1 || g1.ab || g1.gn.gamma || g1.act) return false;
+        if (g1.c0 % 64 || g1.c1 % 64 || ((g1.c0 + g1.c1) / 64) % 2 || nb + (g1.c0 + g1.c1) / 64 > kRbMaxBlk) return false;
+        add_seg(g1.src0, g1.src1, g1.c0, g1.c1, g1.w, 1, false, g1.scale1);
+    } else if (a.res) {
+        if (!ident) return false;
+        add_seg(a.res, nullptr, a.n, 0, ident, 1, false, 1.0f);        // identity residual = raw 1-tap segment against the packed identity
+    }
+    r.nb1 = nb - r.nb3;
+    r.B = a.B; r.L = a.mrows;
+    r.tm_shift = 0;
+    while ((1 << r.tm_shift) < a.mrows / 256) ++r.tm_shift;
+    // n = 256: one 256 x 256 tile per 256 rows (the activations are fetched and activated once) when that still gives
+    // every CU a tile, else two 256 x 128 tiles
+    const int nh = (a.n == 256 && (long long)a.B * (a.mrows / 256) >= min_tiles) ? 2 : 1;
+    r.tiles_n = a.n / (kPpTN * nh);
+    const long long tiles_total = (long long)a.B * (a.mrows / 256) * r.tiles_n;
+    if (tiles_total < min_tiles || tiles_total > (1 << 22)) return false;       // fewer tiles than CUs: the 128-row kernel fills the chip better
+    r.tiles_total = (int)tiles_total;
+    r.n = a.n;
+    r.gn = g0.gn;
+    r.bias0 = a.bias0; r.bias1 = a.bias1;
+    r.out = a.out;
+    r.stats = nullptr; r.stats_groups = 0;
+    if (a.stats) {
+        const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
+        if (!(gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
+        r.stats = a.stats; r.stats_groups = a.stats_groups;
+    }
+    static bool attr_done[kMaxDevices] = {};
+    static int num_cu_dev[kMaxDevices] = {};
+    const int dev = current_device();
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess) {
+            *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize, rb) failed";
+            return true;
+        }
+        if (hipDeviceGetAttribute(&num_cu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu_dev[dev] < 1) num_cu_dev[dev] = 256;
+        attr_done[dev] = true;
+    }
+    const long long grid = tiles_total < num_cu_dev[dev] ? tiles_total : num_cu_dev[dev];
+    if (nh == 2) hipLaunchKernelGGL(conv_gemm_rb_kernel<2>, dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
+    else hipLaunchKernelGGL(conv_gemm_rb_kernel<1>, dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
+    if (hipGetLastError() != hipSuccess) *err = "conv_gemm_rb: launch failed";
+    return true;
 }
 
 // shapes the pipelined kernel is written for (see the header of adf_gemm_pp.h); an identity residual counts as a
@@ -384,6 +470,24 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             const long long need = use_pp >= 2 ? 128 : 256;
             if (t256 >= need) ptm = 256;
             else if (t128 >= need && use_pp != 3) ptm = 128;       // ADF_GEMM_PP=3: 256-row tiles only (A/B)
+        }
+        {
+            // resblock convs (GroupNorm + SiLU prologue derived in the kernel) on 256-row tiles: adf_gemm_rb.h.  ADF_GEMM_RB=0
+            // leaves them to the routes below (A/B; the tests compare the two).
+            static int use_rb = -1;
+            if (use_rb < 0) { const char* e = getenv("ADF_GEMM_RB"); use_rb = e ? atoi(e) : 1; }
+            if (use_rb && dtype_bf16 && !flat && gn_pending && gn_in_kernel && !a.gn_ready) {
+                const char* err = nullptr;
+                const void* ident = nullptr;
+                if (a.res && a.nseg == 1 && (a.n == 128 || a.n == 256)) { ident = pp_identity(a.n, stream, &err); if (!ident) return err; }
+                GemmArgs b = a;
+                b.stats = a_in.stats;
+                if (try_launch_rb(b, ident, use_rb >= 2 ? 32 : 256, stream, &err)) {     // ADF_GEMM_RB=2: also small batches (tests)
+                    if (stats_fused) *stats_fused = a_in.stats != nullptr;
+                    trace_route("rb", a, 256, 128);
+                    return err;
+                }
+            }
         }
         if (ptm) {
             // identity-residual 3-tap layers stay with the weight-stationary kernel; the transformer's 1x1 projections

@@ -1,0 +1,680 @@
+// Resblock conv kernel (bf16): the GroupNorm + SiLU -> 3-tap conv (+ 1x1 residual conv / identity residual) launches of
+// ResnetBlock1d (reference: src/models/backbones/unet1d.py:193-207, :297-316) on 256 x 128 tiles, persistent, all staging by
+// LDS-DMA.  Same data path as adf_gemm_pp.h (ring of 3 activation stages of 64 channels, 2 weight stages of one tap slab,
+// 128-byte LDS rows with the 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) applied on the DMA source side, prologue in
+// place on the chunks a wave fetched itself, wave-local epilogue through LDS with fp64 statistics atomics), rebuilt around
+// what the SQ counters of that kernel said (profiles/r01_pp_kernel_sq_counters.txt: 10.3 scalar + 10.1 vector + 1.4 branch
+// instructions per MFMA, the matrix pipe busy 24 % of the time): the instruction stream, not bytes, is what bounds it.
+//   * the K blocks of a tile (source tensor, channel offset, weight slab, table offset, kind) are the SAME for every tile: the
+//     host writes them into the kernel arguments once (RbArgs::blk) and the kernel reads the next one with a scalar load
+//     -- no per-block descriptor arithmetic (that and the 64-bit address arithmetic of every DMA were most of the scalar work);
+//   * tile geometry (sample, first row, N tile) is advanced once per tile, all byte offsets are 32 bit (tensors < 4 GiB);
+//   * a DMA is s_mov m0 + s_nop + global_load_lds with a uniform base in SGPRs and a per-lane 32-bit offset that is computed
+//     once per K block; the two weight pieces / the activation pieces of a step go out in one asm statement;
+//   * the loop is specialised: 3-tap blocks in a loop unrolled by two (the weight stage parity is then a compile-time constant
+//     and the fragment addresses are VGPR + immediate), 1-tap residual blocks in their own loop, no run-time kind tests
+//     inside a sub-step; the fragment base addresses of a block are computed once per block (12 adds) instead of per read;
+//   * the prologue elements ride between the MFMAs of the wave's own sub-step (as in adf_gemm_pp.h), emitted as
+//     straight-line code per (tap, parity) with the loads of a part at the head of the sub-step.
+// Shapes (checked by launch_rb): bf16, mrows = lin = out_rows a multiple of 256 with a power-of-two tile count per sample,
+// n = n_pad = out_c in {128, 256}, segment 0 = 3 taps (off0 -1) over one or two sources with the GroupNorm table derived in
+// the kernel and SiLU, channels per source a multiple of 64, at most 512 input channels; optional segment 1 = 1 tap raw over
+// one or two sources (source 1 scaled), or an identity residual (becomes a 1-tap segment against a packed identity).
+#pragma once
+#include "adf_gemm.h"
+#include "adf_gemm_pp.h"
+#include <type_traits>
+
+namespace adf {
+
+#ifdef ADF_RB_STAMP
+// diagnostic build only (tools/build_variant.sh rbstamp -DADF_RB_STAMP; tools/rb_stamps.py): s_memtime of every wave of thread
+// block 0 at the phase boundaries of one steady-state 3-tap K block; the product build contains none of this
+extern __device__ unsigned long long adf_rb_stamps[8 * 16];
+#endif
+
+constexpr int kRbMaxBlk = 24;
+// timing knock-outs of diagnostic builds only (tools/build_variant.sh NAME -DADF_RB_STAMP -DADF_RB_KNOCK=bits; results are wrong by
+// construction): 1 no prologue work in the gaps, 2 no activation DMA, 4 no weight DMA, 8 no MFMA, 16 no fragment reads
+#ifndef ADF_RB_KNOCK
+#define ADF_RB_KNOCK 0
+#endif
+// where a sub-step issues its DMA instructions: 0 = after each K step (weights after step 0, activations after 1 .. 3);
+// 1 = waves 0-3 all of them before the first MFMA, waves 4-7 all of them after K step 1 (the two waves of a SIMD then stall
+// on the issue at different times)
+#ifndef ADF_RB_STAGGER
+#define ADF_RB_STAGGER 0
+#endif
+
+struct RbBlk {
+    const char* src;      // source tensor + byte offset of the block's first channel
+    const char* w;        // packed weights of (block, tap 0), N tile 0
+    unsigned pitch;       // bytes per row of the source tensor
+    int tab;              // byte offset of the block's first channel inside a table slot, or -1 = raw input
+    float scale;          // raw input: multiplier (the skip scale of a concatenated source 1)
+    int pad_;
+};
+
+struct RbArgs {
+    RbBlk blk[kRbMaxBlk];     // K blocks of one tile, in order: nb3 three-tap blocks (GroupNorm + SiLU), then nb1 one-tap raw blocks
+    int nb3, nb1;
+    int B, L;                 // samples, rows per sample
+    int tm_shift;             // log2(256-row tiles per sample)
+    int tiles_n;              // N tiles (1 or 2), N tile index fastest
+    int tiles_total;
+    int n;                    // output channels (= n_pad = out_c)
+    GnFinalizeArgs gn;        // GroupNorm (+ FiLM) of segment 0: the affine table is derived here from the statistics
+    const float* bias0; const float* bias1;
+    void* out;
+    double* stats; int stats_groups;
+};
+
+// two DMA pieces of 1 KB from one uniform base: lane offsets va / vb, LDS destinations la / lb (+ 16 * lane)
+__device__ __forceinline__ void rb_dma2(const char* base, unsigned va, unsigned vb, unsigned la, unsigned lb) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+                 :: "s"(base), "v"(va), "v"(vb), "s"(la), "s"(lb) : "memory");
+}
+__device__ __forceinline__ void rb_dma1(const char* base, unsigned va, unsigned la) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(base), "v"(va), "s"(la) : "memory");
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void rb_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        rb_static_for<I + 1, N>(f);
+    }
+}
+
+// NH = 128-column halves of the N tile: 1 -> 256 x 128 tiles (n = 128); 2 -> 256 x 256 tiles (n = 256): the activations of a K
+// block are fetched and activated ONCE and multiplied with the two half slabs of each tap in turn (twice the MFMAs per
+// prologue element and per activation byte -- the vector issue slots and the DMA path are what bound the kernel)
+template <int NH>
+__global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
+    typedef bf16_t T;
+    constexpr int TM = 256, HP = 32;
+    constexpr int TNB = kPpTN * NH;                      // columns of the block tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsScr = smem + kPpOffScr;
+    char* const ldsTab = smem + kPpOffTab;
+    float* const ldsBias = (float*)(smem + kPpOffBias);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);     // logical 16-byte chunk stored at this lane's slot
+    const int srow = wave * 8 + lrow;                                            // staged row of this lane in unit 0 (+64 per unit)
+    const unsigned lane_lds = (unsigned)lane * 16u;
+
+    const int nblk_grid = (int)gridDim.x, bidx = (int)blockIdx.x;
+    // (tiles_total <= 2^22 and the grid <= 256 blocks: the products fit 32 bits)
+    const int t_lo = (int)((unsigned)bidx * (unsigned)a.tiles_total / (unsigned)nblk_grid);
+    const int t_hi = (int)((unsigned)(bidx + 1) * (unsigned)a.tiles_total / (unsigned)nblk_grid);
+    const int ntiles = t_hi - t_lo;
+    if (ntiles <= 0) return;
+    const int nb3 = a.nb3, nb1 = a.nb1, nb = nb3 + nb1;
+    const int ctot0 = a.gn.c0 + a.gn.c1;
+    const int tn_shift = a.tiles_n > 1 ? 1 : 0;
+    const int tm_mask = (1 << a.tm_shift) - 1;
+
+    // ---- tile geometry: advanced once per tile ------------------------------------------------------------------
+    struct Tile { int b0, m0, n0; };
+    auto tile_of = [&](int tseq) __attribute__((always_inline)) -> Tile {
+        const int t = t_lo + tseq;
+        const int tml = t >> tn_shift;
+        Tile g;
+        g.n0 = (t & (a.tiles_n - 1)) * TNB;
+        g.b0 = tml >> a.tm_shift;
+        g.m0 = (tml & tm_mask) * TM;
+        return g;
+    };
+    const int b_first = tile_of(0).b0;
+
+    // ---- run-time description of one K block of one tile (all wave-uniform, SGPRs) -------------------------------
+    struct Blk {
+        const char* abase;    // row p_lo of the tile in the block's source (+ channel offset)
+        const char* w;        // weight slab of tap 0 for the tile's N tile
+        unsigned pitch;
+        int tab;              // byte offset into ldsTab (slot included) or -1
+        float scale;
+        int edge;             // bit 0: staged row 0 is before the sample; bit 1: staged row TM + 1 is past it (3-tap blocks)
+        int taps;
+    };
+    // Every block goes through the same prologue code: y = act ? silu(a x + b) : a x + b with (a, b) from the GroupNorm table,
+    // or (scale, 0) for a raw block (a raw block with scale 1 comes back bit for bit: bf16 * 1.0 + 0 rounds to itself).  One code
+    // path = one register assignment for the accumulators over the whole loop (an if / else around two copies of a sub-step
+    // made the register allocator move accumulator tiles through scratch).
+    int d_t = 0, d_k = 0;                              // (tile, block) cursor of the descriptor stream
+    Tile d_tile = tile_of(0);
+    auto make_desc = [&]() __attribute__((always_inline)) -> Blk {
+        const RbBlk& e = a.blk[d_k];
+        Blk d;
+        const int three = d_k < nb3;
+        const int p_lo = d_tile.m0 - three;
+        d.pitch = e.pitch;
+        d.abase = e.src + (long long)(d_tile.b0 * a.L + p_lo) * (long long)e.pitch;
+        d.w = e.w + (unsigned)d_tile.n0 * (unsigned)kRowBytes;
+        d.tab = e.tab >= 0 ? ((d_tile.b0 - b_first) & 1) * kPpTab + e.tab : -1;
+        d.scale = e.scale;
+        d.taps = three ? 3 : 1;
+        d.edge = three ? ((d_tile.m0 == 0 ? 1 : 0) | (d_tile.m0 + TM >= a.L ? 2 : 0)) : 0;
+        return d;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++d_k == nb) {
+            d_k = 0;
+            if (++d_t < ntiles) d_tile = tile_of(d_t);    // past the end: a valid but unused descriptor
+        }
+    };
+    const unsigned slab = (unsigned)a.n * (unsigned)kRowBytes;           // one tap of packed weights
+
+    // ---- DMA ----------------------------------------------------------------------------------------------------
+    const unsigned colbytes = (unsigned)chunk * 16u;
+    // activations of block d into ring stage offset `st` (bytes): pieces 0-1 / 2-3 / halo
+    auto issue_a01 = [&](const Blk& d, unsigned st) __attribute__((always_inline)) {
+        if (ADF_RB_KNOCK & 2) return;
+        const unsigned v = (unsigned)srow * d.pitch + colbytes;
+        const unsigned v0 = ((d.edge & 1) && srow == 0) ? v + d.pitch : v;      // row -1 of the sample: fetch row 0, zeroed later
+        const unsigned l = st + (unsigned)wave * 1024u;
+        rb_dma2(d.abase, v0, v + 64u * d.pitch, l, l + 8192u);
+    };
+    auto issue_a23 = [&](const Blk& d, unsigned st) __attribute__((always_inline)) {
+        if (ADF_RB_KNOCK & 2) return;
+        const unsigned v = (unsigned)(srow + 128) * d.pitch + colbytes;
+        const unsigned l = st + (unsigned)wave * 1024u + 16384u;
+        rb_dma2(d.abase, v, v + 64u * d.pitch, l, l + 8192u);
+    };
+    auto issue_halo = [&](const Blk& d, unsigned st) __attribute__((always_inline)) {
+        if (ADF_RB_KNOCK & 2) return;
+        if (wave == 0 && d.taps == 3) {
+            // rows TM, TM + 1 of the tile; past the end of the sample both lane rows fetch row TM (zeroed later)
+            const unsigned vh = (unsigned)TM * d.pitch + ((d.edge & 2) ? 0u : (unsigned)lrow * d.pitch) + colbytes;
+            if (lane < 16) rb_dma1(d.abase, vh, st + (unsigned)HP * 1024u);
+        }
+    };
+    const unsigned wlane = (unsigned)srow * (unsigned)kRowBytes + colbytes;
+    auto issue_w = [&](const char* wsrc, int wst) __attribute__((always_inline)) {
+        if (ADF_RB_KNOCK & 4) return;
+        const unsigned l = (unsigned)(kPpOffW + wst * kPpWStage) + (unsigned)wave * 1024u;
+        rb_dma2(wsrc, wlane, wlane + 64u * (unsigned)kRowBytes, l, l + 8192u);
+    };
+
+    // ---- GroupNorm table of one sample: two channels per thread (the arithmetic of gn_finalize_kernel) -------------
+    auto fill_table = [&](int b, int slot) __attribute__((always_inline)) {
+        // (the thread index goes through an empty asm: otherwise the per-lane 64-bit addresses of gamma / beta / FiLM / statistics
+        //  are computed at kernel entry and kept -- spilled -- across the whole tile loop)
+        int t2 = tid * 2;
+        asm volatile("" : "+v"(t2));
+        if (t2 < ctot0) {
+            float A0, B0, A1, B1;
+            gn_affine<true>(a.gn, b, t2, A0, B0);
+            gn_affine<true>(a.gn, b, t2 + 1, A1, B1);
+            *(f32x4_t*)(ldsTab + slot * kPpTab + t2 * 8) = f32x4_t{A0, B0, A1, B1};
+        }
+    };
+
+    // ---- prologue arithmetic on one 8-byte half (4 elements) of a chunk this lane fetched ----------------------------
+    // act:  y = v * rcp(1 + exp2(-log2(e) v));  no act: the exponent is the constant -200 instead, exp2 underflows to 0 and
+    // y = v * rcp(1) = v exactly -- the same instructions, no select
+    auto silu4 = [&](const u32x2_t& raw, const float* fa, const float* fb, bool act) __attribute__((always_inline)) -> u32x2_t {
+        float v[4], ex[4];
+        const float ec = act ? -1.4426950408889634f : 0.0f, ed = act ? 0.0f : -200.0f;
+        v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+        v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fa[e], fb[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ex[e] = __builtin_amdgcn_exp2f(fmaf(v[e], ec, ed));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ex[e] = __builtin_amdgcn_rcpf(ex[e] + 1.0f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= ex[e];
+        u32x2_t o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        return o;
+    };
+    // (a, b) of the lane's channels [c_lo, c_lo + n) of block d: table entries, or (scale, 0) for a raw block
+    auto load_ab = [&](const Blk& d, int c_lo, int n, float* fa, float* fb) __attribute__((always_inline)) {
+        if (d.tab >= 0) {                                                 // uniform
+            const f32x4_t* tp = (const f32x4_t*)(ldsTab + d.tab + chunk * 64 + c_lo * 8);
+            for (int e = 0; e < n / 2; ++e) {
+                const f32x4_t t = tp[e];
+                fa[2 * e] = t.x; fb[2 * e] = t.y; fa[2 * e + 1] = t.z; fb[2 * e + 1] = t.w;
+            }
+        } else {
+            for (int e = 0; e < n; ++e) { fa[e] = d.scale; fb[e] = 0.f; }
+        }
+    };
+    // zero padding of the activated tensor: staged row 0 / staged row TM + 1 of an edge tile
+    auto zero_fill = [&](const Blk& d, unsigned st) __attribute__((always_inline)) {
+        if (d.edge) {                                                     // uniform
+            const u32x4_t z = u32x4_t{0u, 0u, 0u, 0u};
+            if ((d.edge & 1) && srow == 0) *(u32x4_t*)(smem + st + wave * 1024 + lane_lds) = z;
+            if ((d.edge & 2) && wave == 0 && lane >= 8 && lane < 16) *(u32x4_t*)(smem + st + HP * 1024 + lane_lds) = z;
+        }
+    };
+    // whole prologue of block d (stage st) at once: the pipeline fill, and the block after a 1-tap block
+    auto transform_all = [&](const Blk& d, unsigned st) __attribute__((always_inline)) {
+        char* const ldsA = smem + st + wave * 1024 + lane_lds;
+        if (d.tab < 0) {                                                 // uniform: raw block
+            if (d.scale != 1.0f) {                                       // scaled skip channels; else the bytes go to the MFMAs untouched
+                const float sc = d.scale;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const u32x4_t q = *(const u32x4_t*)(ldsA + u * 8192);
+                    u32x4_t o;
+                    o.x = pack_bf16x2(__uint_as_float(q.x << 16) * sc, __uint_as_float(q.x & 0xffff0000u) * sc);
+                    o.y = pack_bf16x2(__uint_as_float(q.y << 16) * sc, __uint_as_float(q.y & 0xffff0000u) * sc);
+                    o.z = pack_bf16x2(__uint_as_float(q.z << 16) * sc, __uint_as_float(q.z & 0xffff0000u) * sc);
+                    o.w = pack_bf16x2(__uint_as_float(q.w << 16) * sc, __uint_as_float(q.w & 0xffff0000u) * sc);
+                    *(u32x4_t*)(ldsA + u * 8192) = o;
+                }
+            }
+            return;
+        }
+        char* const ldsH = smem + st + HP * 1024 + lane_lds;
+        const bool halo = wave == 0 && d.taps == 3 && lane < 16;
+        const bool act = true;
+        float fa[8], fb[8];
+        load_ab(d, 0, 8, fa, fb);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32x4_t q = *(const u32x4_t*)(ldsA + u * 8192);
+            const u32x2_t lo = silu4(u32x2_t{q.x, q.y}, fa, fb, act), hi = silu4(u32x2_t{q.z, q.w}, fa + 4, fb + 4, act);
+            *(u32x4_t*)(ldsA + u * 8192) = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+        }
+        if (halo) {
+            const u32x4_t q = *(const u32x4_t*)ldsH;
+            const u32x2_t lo = silu4(u32x2_t{q.x, q.y}, fa, fb, act), hi = silu4(u32x2_t{q.z, q.w}, fa + 4, fb + 4, act);
+            *(u32x4_t*)ldsH = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+        }
+        zero_fill(d, st);
+    };
+
+    // ---- accumulators and fragment addresses ----------------------------------------------------------------------
+    f32x16_t acc[NH][2][2];
+    // fragment chunk (ks*2 + h) of staged row R sits at byte R*128 + (((ks*2 + h) ^ f) << 4), f = (R >> 1) & 7
+    //   = (R*128 + ((h ^ (f & 1)) << 4) + ((f >> 1) << 5)) ^ (ks << 5)
+    unsigned abase0[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int row = wm * 64 + r + t, f = (row >> 1) & 7;
+        abase0[t] = (unsigned)(row * kPpRow + ((h ^ (f & 1)) << 4) + ((f >> 1) << 5));
+    }
+    const int fw = (r >> 1) & 7;
+    const unsigned wbase0 = (unsigned)((wn * 64 + r) * kPpRow + ((h ^ (fw & 1)) << 4) + ((fw >> 1) << 5));
+    unsigned wadr[4];                                   // weight fragment addresses of the 4 K steps (stage 0; + kPpWStage for stage 1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wadr[ks] = (unsigned)kPpOffW + (wbase0 ^ (unsigned)(ks << 5));
+
+    // One sub-step: the 16 MFMAs of tap TAP over the 64 channels of the block in stage `sa_` with the weight slab in stage
+    // WST.  `work(q)` (q = 0 .. 15) is emitted after MFMA q: prologue elements of the next block; `mid(ks)` after the four
+    // MFMAs of K step ks: the DMA instructions of the step.
+    auto substep = [&](auto tapc, auto wstc, auto nhc, unsigned sa_, auto work, auto mid) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int WST = decltype(wstc)::value;
+        constexpr int H = decltype(nhc)::value;
+        const char* const pw = smem + WST * kPpWStage;
+        unsigned aadr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) aadr[ks] = sa_ + (abase0[TAP] ^ (unsigned)(ks << 5));
+        bf16x8_t fa[2][2], fb[2][2];
+        if (ADF_RB_STAGGER && wave < 4) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) mid(ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[0][i] = *(const bf16x8_t*)(smem + aadr[0] + i * 32 * kPpRow);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8_t*)(pw + wadr[0] + j * 32 * kPpRow);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[nxt][i] = *(const bf16x8_t*)(smem + aadr[ks + 1] + i * 32 * kPpRow);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[nxt][j] = *(const bf16x8_t*)(pw + wadr[ks + 1] + j * 32 * kPpRow);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!(ADF_RB_KNOCK & 8)) acc[H][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[H][i][j], 0, 0, 0);
+                    else { asm volatile("" :: "v"(fa[cur][i]), "v"(fb[cur][j])); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ADF_RB_KNOCK & 1)) work(ks * 4 + i * 2 + j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if (!ADF_RB_STAGGER) mid(ks);
+            else if (ks == 1 && wave >= 4) {
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) mid(k2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Prologue of block dn (stage sn) as per-gap work in the three sub-steps of the block before it.  Parts 0 / 1 take the even /
+    // odd 8-byte halves of the wave's pieces 0-2 (so each needs the (a, b) of 4 channels only), part 2 piece 3 and the two
+    // halves of the halo chunk (wave 0; the other waves run the same instructions on their own piece 0 and do not store).
+    // A half = 4 elements = one GROUP; a group goes through 8 stages of 4 INDEPENDENT instructions each (unpack, affine,
+    // exponent, exp2, 1 + t, rcp, product, pack + store): 32 slots per group, 6 slots per MFMA gap.  Measured with per-wave
+    // stamps (tools/rb_stamps.py): one element per gap as a dependent chain (unpack -> fma -> fma -> exp2 | add -> rcp -> mul)
+    // ran at ~9 cycles per instruction -- with two waves per SIMD nothing hides the latency of a dependent vector instruction
+    // -- and the 16 MFMAs of a sub-step took 1700-2100 cycles; four independent elements per stage issue back to back.
+    struct Part {
+        u32x2_t raw[4];
+        float ta[8], tb[8];
+        float x[4], u[4];
+        u32x2_t pk;
+        float ec, ed;          // exponent = ec * v + ed: (-log2 e, 0) with SiLU, (0, -200) without (see silu4)
+    };
+    auto half_of = [](int P, int k) constexpr -> int { return P < 2 ? P + 2 * k : 6 + k; };
+    auto part_begin = [&](auto partc, const Blk& dn, unsigned sn, Part& p) __attribute__((always_inline)) {
+        constexpr int P = decltype(partc)::value;
+        char* const ldsN = smem + sn + wave * 1024 + lane_lds;
+        if (P == 0) {
+            load_ab(dn, 0, 4, p.ta, p.tb);
+            p.ec = dn.tab >= 0 ? -1.4426950408889634f : 0.0f;
+            p.ed = dn.tab >= 0 ? 0.0f : -200.0f;
+        } else if (P == 1) load_ab(dn, 4, 4, p.ta + 4, p.tb + 4);
+        constexpr int NOWN = P < 2 ? 3 : 2;
+#pragma unroll
+        for (int k = 0; k < NOWN; ++k) {
+            const int hh = half_of(P, k);
+            p.raw[k] = *(const u32x2_t*)(ldsN + (hh >> 1) * 8192 + (hh & 1) * 8);
+        }
+        if (P == 2) {
+            // the halo chunk (rows TM, TM + 1: lanes 0-15 of wave 0); every other lane re-reads its own piece 0 and drops the result
+            const bool halo = wave == 0 && dn.taps == 3 && lane < 16;
+            const u32x4_t q = *(const u32x4_t*)(halo ? smem + sn + HP * 1024 + lane_lds : ldsN);
+            p.raw[2] = u32x2_t{q.x, q.y};
+            p.raw[3] = u32x2_t{q.z, q.w};
+        }
+    };
+    auto part_gap = [&](auto partc, const Blk& dn, unsigned sn, Part& p, int q) __attribute__((always_inline)) {
+        constexpr int P = decltype(partc)::value;
+        constexpr int NG = P < 2 ? 3 : 4;             // groups of the part
+        constexpr int OPG = (P < 2 ? 6 : 8) / NH;     // slots per gap: 16 NH gaps x OPG = NG x 32   (q = 0 .. 16 NH - 1)
+        char* const ldsN = smem + sn + wave * 1024 + lane_lds;
+#pragma unroll
+        for (int n = q * OPG; n < (q + 1) * OPG; ++n) {
+            const int k = n >> 5, st = (n >> 2) & 7, j = n & 3;
+            if (k >= NG) continue;
+            // channel of element j of group k inside the lane's 8-channel chunk
+            const int hh = (P == 2 && k >= 2) ? k - 2 : half_of(P, k);
+            const int ch = (hh & 1) * 4 + j;
+            switch (st) {
+                case 0: {
+                    const unsigned w = (j & 2) ? p.raw[k].y : p.raw[k].x;
+                    p.x[j] = __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));
+                    break;
+                }
+                case 1: p.x[j] = fmaf(p.x[j], p.ta[ch], p.tb[ch]); break;
+                case 2: p.u[j] = fmaf(p.x[j], p.ec, p.ed); break;
+                case 3: p.u[j] = __builtin_amdgcn_exp2f(p.u[j]); break;
+                case 4: p.u[j] = p.u[j] + 1.0f; break;
+                case 5: p.u[j] = __builtin_amdgcn_rcpf(p.u[j]); break;
+                case 6: p.x[j] = p.x[j] * p.u[j]; break;
+                default:
+                    if (j == 0) p.pk.x = pack_bf16x2(p.x[0], p.x[1]);
+                    else if (j == 1) p.pk.y = pack_bf16x2(p.x[2], p.x[3]);
+                    else if (j == 2) {
+                        if (P == 2 && k >= 2) {
+                            if (wave == 0 && dn.taps == 3 && lane < 16) *(u32x2_t*)(smem + sn + HP * 1024 + lane_lds + (k - 2) * 8) = p.pk;
+                        } else {
+                            *(u32x2_t*)(ldsN + (hh >> 1) * 8192 + (hh & 1) * 8) = p.pk;
+                        }
+                    }
+                    break;
+            }
+        }
+        // keep the slots of this gap in this gap (IR passes move pure arithmetic across sched_barrier)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(p.x[j])); asm volatile("" : "+v"(p.u[j])); }
+    };
+    // what does not ride in the gaps: the zero padding of an edge tile, after the MFMAs of part 2
+    auto part_end = [&](const Blk& dn, unsigned sn) __attribute__((always_inline)) { zero_fill(dn, sn); };
+
+    // ---- wave-local epilogue of one finished tile ---------------------------------------------------------------
+    const int cc = lane & 7, rsub = lane >> 3;
+    auto epilogue = [&](const Tile& g, int next_n0) __attribute__((always_inline)) {
+        float* sc = (float*)(ldsScr + wave * 2048);          // [8][64] fp32
+        float* scw = sc + (4 * h) * 64 + r;
+        const float* scr = sc + rsub * 64 + cc * 8;
+        T* out = (T*)a.out;
+        const bool stats_here = a.stats != nullptr;
+        const int gs = stats_here ? a.n / a.stats_groups : 8;
+        const int tpg = gs / 8;
+        const int mw0 = g.m0 + wm * 64;
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+        const int n = g.n0 + hf * kPpTN + wn * 64 + cc * 8;
+        f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+        float nb_[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) nb_[j] = ldsBias[next_n0 + hf * kPpTN + wn * 64 + j * 32 + r];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int e = 4 * p4 + e4;
+                        scw[e4 * 64 + j * 32] = acc[hf][i][j][e];
+                        acc[hf][i][j][e] = nb_[j];
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int m = mw0 + i * 32 + 8 * p4 + rsub;
+                const unsigned off = (unsigned)((g.b0 * a.L + m) * a.n + n);
+                float v[8];
+                {
+                    const float4 q0 = *(const float4*)(scr), q1 = *(const float4*)(scr + 4);
+                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                }
+                *(u32x4_t*)(out + off) = pack16<T>(v);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2_t v2 = {v[e], v[e + 1]};
+                    s1v += v2;
+                    s2v += v2 * v2;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (stats_here) {
+            float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
+            for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            for (int o = 8; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (lane < 8 && (cc & (tpg - 1)) == 0) {
+                double* sp = a.stats + ((size_t)g.b0 * a.stats_groups + n / gs) * 2;
+                atomicAdd(sp, (double)s1);
+                atomicAdd(sp + 1, (double)s2);
+            }
+        }
+        }
+    };
+
+    // ---- start-up: bias vector, the first sample's table, first DMAs -------------------------------------------------
+    float bias_v = 0.f;
+    if (tid < a.n) {
+        if (a.bias0) bias_v += a.bias0[tid];
+        if (a.bias1) bias_v += a.bias1[tid];
+    }
+    GnRaw gr0 = {}, gr1 = {};
+    if (tid * 2 < ctot0) { gr0 = gn_affine_load(a.gn, b_first, tid * 2); gr1 = gn_affine_load(a.gn, b_first, tid * 2 + 1); }
+    Blk dc = make_desc();
+    advance();
+    issue_a01(dc, 0u); issue_a23(dc, 0u); issue_halo(dc, 0u);
+    issue_w(dc.w, 0);
+    Blk d1 = make_desc();
+    advance();
+    issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage);
+    Blk d2 = make_desc();
+    advance();
+    if (tid < a.n) ldsBias[tid] = bias_v;
+    if (tid * 2 < ctot0) {
+        float A0, B0, A1, B1;
+        gn_affine_finish<true>(a.gn, tid * 2, gr0, A0, B0);
+        gn_affine_finish<true>(a.gn, tid * 2 + 1, gr1, A1, B1);
+        *(f32x4_t*)(ldsTab + tid * 16) = f32x4_t{A0, B0, A1, B1};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    Tile cur_tile = tile_of(0);
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+        float bias_r[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias_r[j] = ldsBias[cur_tile.n0 + hf * kPpTN + wn * 64 + j * 32 + r];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[hf][i][j][e] = bias_r[j];
+    }
+    transform_all(dc, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- pipeline -----------------------------------------------------------------------------------------------------
+    // K blocks are numbered over the whole thread block; block g lives in A stage g % 3 (fetched while block g-2 computes,
+    // prepared in place while block g-1 computes), the weight slab of a sub-step in W stage (sub-step count) & 1.
+    unsigned sa = 0u, sa1 = (unsigned)kPpAStage, sa2 = 2u * (unsigned)kPpAStage;       // stage byte offsets of blocks g, g+1, g+2
+    const std::integral_constant<int, 0> c0{};
+    const std::integral_constant<int, 1> c1{};
+    const std::integral_constant<int, 2> c2{};
+    auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto rotate = [&]() __attribute__((always_inline)) {
+        const unsigned t = sa; sa = sa1; sa1 = sa2; sa2 = t;
+        dc = d1; d1 = d2; d2 = make_desc();
+        advance();
+    };
+    int tseq = 0, kb = 0;                              // tile / block of the block being computed
+    bool prev_one = false;                             // the block before this one was a 1-tap block
+    int remaining = ntiles * nb;                       // K blocks still to compute (this one included)
+
+    // The sub-steps of one K block: u = 0 .. TAPS * NH - 1 = (tap u / NH, N half u % NH), reading W stage (WP + u) & 1 and
+    // fetching the slab of sub-step u + 1 (the first one of block g+1 at the end).  The activations of block g+2 go out behind
+    // the slabs of sub-steps 0 (halo, pieces 0-1) and 1 (pieces 2-3): spread over time, a slab is never queued behind more
+    // than two HBM pieces of its own wave (tools/micro/dma_mix.hip: the two streams share the CU's miss slots, they do not
+    // overlap), and the end-of-sub-step wait leaves exactly the pieces issued in that sub-step in flight.
+    auto next_slab = [&](int u, int taps_) __attribute__((always_inline)) -> const char* {
+        return dc.w + (unsigned)(u / NH) * slab + (unsigned)(u % NH) * (unsigned)kPpWStage;
+    };
+    // one 3-tap block whose first sub-step reads W stage WP; the prologue of block g+1 (any kind) rides in its gaps
+    auto block3 = [&](auto wpc) __attribute__((always_inline)) {
+        constexpr int WP = decltype(wpc)::value;
+        constexpr int U = 3 * NH;
+#ifdef ADF_RB_STAMP
+        const bool stamp_on = bidx == 0 && tseq == 1 && kb == 2 && WP == 0;
+        auto stamp = [&](int id) __attribute__((always_inline)) {
+            if (stamp_on && id < 16) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) ((unsigned long long*)(smem + kPpOffBias + 1024))[wave * 16 + id] = t;
+            }
+        };
+#else
+        auto stamp = [&](int) __attribute__((always_inline)) {};
+#endif
+        const bool has1 = remaining > 1, has2 = remaining > 2;
+        // after a 1-tap block the activations of block g+1 (issued one sub-step ago) may still be in flight: the prologue
+        // parts below read them from the head of this block on
+        if (prev_one) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Part part;
+        stamp(0);
+        rb_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int TAP = u / NH, HF = u % NH;
+            const std::integral_constant<int, TAP> tapc{};
+            const std::integral_constant<int, (WP + u) & 1> wstc{};
+            const std::integral_constant<int, HF> hfc{};
+            if (HF == 0) part_begin(tapc, d1, sa1, part);
+            substep(tapc, wstc, hfc, sa, [&](int q) __attribute__((always_inline)) { part_gap(tapc, d1, sa1, part, HF * 16 + q); },
+                    [&](int ks) __attribute__((always_inline)) {
+                        if (ks == 0) {
+                            if (u + 1 < U) issue_w(next_slab(u + 1, 3), (WP + u + 1) & 1);
+                            else if (has1) issue_w(d1.w, (WP + u + 1) & 1);
+                        } else if (ks == 1 && has2) {
+                            if (u == 0) { issue_halo(d2, sa2); issue_a01(d2, sa2); }
+                            else if (u == 1) issue_a23(d2, sa2);
+                        }
+                    });
+            if (u == U - 1) part_end(d1, sa1);
+            stamp(3 * u + 1);
+            // the next slab has landed; the activation pieces issued in this sub-step (the 2 youngest) may still fly
+            if (u < 2 && has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(3 * u + 2);
+            if (u == 2 && kb == 0 && tseq + 1 < ntiles) {            // first block of a tile: the next tile's sample
+                const Tile nt = tile_of(tseq + 1);
+                if (nt.b0 != cur_tile.b0) fill_table(nt.b0, (nt.b0 - b_first) & 1);     // nothing else is in flight here
+            }
+            lds_barrier();
+            stamp(3 * u + 3);
+        });
+#ifdef ADF_RB_STAMP
+        if (stamp_on && lane < 16) adf_rb_stamps[wave * 16 + lane] = ((const unsigned long long*)(smem + kPpOffBias + 1024))[wave * 16 + lane];
+#endif
+    };
+    // one 1-tap (raw) block reading W stage WP first: everything of the next block is needed after its NH sub-steps
+    auto block1 = [&](auto wpc) __attribute__((always_inline)) {
+        constexpr int WP = decltype(wpc)::value;
+        const bool has1 = remaining > 1, has2 = remaining > 2;
+        rb_static_for<0, NH>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const std::integral_constant<int, (WP + u) & 1> wstc{};
+            const std::integral_constant<int, u> hfc{};
+            substep(c0, wstc, hfc, sa, [](int) __attribute__((always_inline)) {},
+                    [&](int ks) __attribute__((always_inline)) {
+                        if (ks == 0) {
+                            if (u + 1 < NH) issue_w(next_slab(u + 1, 1), (WP + u + 1) & 1);
+                            else if (has1) issue_w(d1.w, (WP + u + 1) & 1);
+                        } else if (u == NH - 1 && has2) {
+                            if (ks == 1) issue_a01(d2, sa2); else if (ks == 2) issue_a23(d2, sa2); else issue_halo(d2, sa2);
+                        }
+                    });
+            if (u == NH - 1) {
+                // block g+1's activations (issued one block ago) and its first slab have landed; block g+2's may still fly
+                if (has2) { if (wave == 0 && d2.taps == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (has1) transform_all(d1, sa1);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lds_barrier();
+        });
+    };
+    constexpr int kPar3 = (3 * NH) & 1, kPar1 = NH & 1;       // weight stage parity after one 3-tap / 1-tap block
+
+    for (; tseq < ntiles; ++tseq) {
+        cur_tile = tile_of(tseq);
+        // the previous tile's accumulators leave, this tile's start from its bias
+        if (tseq > 0) epilogue(tile_of(tseq - 1), cur_tile.n0);
+        // blocks come in pairs (nb3 and nb1 are even): the weight stage parity is a compile-time constant
+        for (kb = 0; kb < nb3; kb += 2) {
+            block3(c0); rotate(); --remaining; prev_one = false;
+            block3(std::integral_constant<int, kPar3>{}); rotate(); --remaining;
+        }
+        for (int k1 = 0; k1 < nb1; k1 += 2) {
+            block1(c0); rotate(); --remaining;
+            block1(std::integral_constant<int, kPar1>{}); rotate(); --remaining; prev_one = true;
+        }
+    }
+    {
+        const Tile last = tile_of(ntiles - 1);
+        epilogue(last, 0);
+    }
+}
+
+}  // namespace adf
