@@ -67,6 +67,16 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
     return q;
 }
 
+// Pack a chunk for storing AND leave in f[] the values the tensor then holds: the GroupNorm statistics of a produced tensor are
+// reduced from the STORED (bf16-rounded) values, i.e. they are the statistics of the tensor the next layer reads -- what the
+// reference's GroupNorm computes on its input -- not of the fp32 accumulators behind it.  fp32 storage: values unchanged.
+template <typename T> __device__ __forceinline__ u32x4_t pack16_stored(float* f) {
+    const u32x4_t q = pack16<T>(f);
+    if constexpr (sizeof(T) == 2) unpack16<T>(q, f);
+    return q;
+}
+__device__ __forceinline__ float bf16_stored(float v) { return bf16_to_f32(f32_to_bf16_hw(v)); }
+
 // GroupNorm(+FiLM) folded to a per-(sample, channel) affine y = A*x + Bc of the (possibly concatenated) input
 // [src0 ; scale1*src1]: statistics [B][G][2] (sum, sumsq in fp64) per source tensor, gamma / beta, optional FiLM
 // (scale + 1, shift) with an optional second addend.  Shared by gn_finalize_kernel, gn_norm_apply_kernel and the GEMM

@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
                 for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
             }
             if (okv[k]) {
-                *(u32x4_t*)(out + off[k]) = pack16<T>(v);
+                *(u32x4_t*)(out + off[k]) = pack16_stored<T>(v);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
             }
@@ -926,7 +926,7 @@ __global__ void __launch_bounds__(512) conv_gemm_ws_kernel(const GemmArgs a, int
                                 for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
                             }
                             if (ok) {
-                                *(u32x4_t*)(out + off) = pack16<T>(v);
+                                *(u32x4_t*)(out + off) = pack16_stored<T>(v);
 #pragma unroll
                                 for (int e = 0; e < EPC; e += 2) {
                                     const f32x2_t v2 = {v[e], v[e + 1]};
@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) v[e] = gelu_erf_f(v[e]);
                 }
-                *(u32x4_t*)(out + off) = pack16<T>(v);
+                *(u32x4_t*)(out + off) = pack16_stored<T>(v);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
             }

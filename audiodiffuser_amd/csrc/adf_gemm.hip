@@ -148,8 +148,13 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     if (a.scatter_f || a.gelu || a.flat || a.mrows % 256 || a.lin != a.mrows || a.out_rows != a.mrows) return false;
     if (a.n != a.n_pad || a.out_c != a.n || (a.n != 128 && a.n != 256) || a.bias_mod != a.n) return false;
     if (!pow2(a.mrows / 256)) return false;
-    if (!g0.gn.gamma || !g0.act || g0.taps != 3 || g0.off0 != -1 || g0.stride != 1 || g0.step != 1) return false;
-    if (g0.c0 % 64 || g0.c1 % 64 || g0.c0 + g0.c1 > kPpMaxCin || ((g0.c0 + g0.c1) / 64) % 2) return false;
+    // segment 0: GroupNorm + SiLU with the table derived in the kernel, or raw (the folded down convs)
+    const bool raw0 = !g0.gn.gamma && !g0.ab && !g0.act && g0.c1 == 0;
+    if (!raw0 && (!g0.gn.gamma || !g0.act)) return false;
+    if (g0.taps != 3 || g0.off0 != -1 || g0.stride != 1 || g0.step != 1) return false;
+    if (g0.c0 % 64 || g0.c1 % 64 || ((g0.c0 + g0.c1) / 64) % 2 || (g0.c0 + g0.c1) / 64 > kRbMaxBlk) return false;
+    if (!raw0 && g0.c0 + g0.c1 > kPpMaxCin) return false;
+    if (raw0 && (a.nseg > 1 || a.res)) return false;
     if (a.res && a.nseg > 1) return false;
     RbArgs r;
     memset(&r, 0, sizeof(r));
@@ -165,17 +170,16 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
             e.scale = from1 ? scale1 : 1.0f;
         }
     };
-    add_seg(g0.src0, g0.src1, g0.c0, g0.c1, g0.w, 3, true, 1.0f);
+    add_seg(g0.src0, g0.src1, g0.c0, g0.c1, g0.w, 3, !raw0, 1.0f);
     r.nb3 = nb;
     if (a.nseg > 1) {
         const GemmSeg& g1 = a.seg[1];
         if (g1.taps != 1 || g1.off0 != 0 || g1.stride != 1 || g1.step != 1 || g1.ab || g1.gn.gamma || g1.act) return false;
         if (g1.c0 % 64 || g1.c1 % 64 || ((g1.c0 + g1.c1) / 64) % 2 || nb + (g1.c0 + g1.c1) / 64 > kRbMaxBlk) return false;
         add_seg(g1.src0, g1.src1, g1.c0, g1.c1, g1.w, 1, false, g1.scale1);
-    } else if (a.res) {
-        if (!ident) return false;
-        add_seg(a.res, nullptr, a.n, 0, ident, 1, false, 1.0f);        // identity residual = raw 1-tap segment against the packed identity
     }
+    r.res = a.nseg == 1 ? a.res : nullptr;                             // identity residual: added in the epilogue (fp32, before the rounding)
+    (void)ident;
     r.nb1 = nb - r.nb3;
     r.B = a.B; r.L = a.mrows;
     r.tm_shift = 0;
@@ -201,8 +205,10 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     static int num_cu_dev[kMaxDevices] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess) {
             *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize, rb) failed";
             return true;
         }
@@ -210,8 +216,10 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
         attr_done[dev] = true;
     }
     const long long grid = tiles_total < num_cu_dev[dev] ? tiles_total : num_cu_dev[dev];
-    if (nh == 2) hipLaunchKernelGGL(conv_gemm_rb_kernel<2>, dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
-    else hipLaunchKernelGGL(conv_gemm_rb_kernel<1>, dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
+    if (nh == 2 && raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, true>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
+    else if (nh == 2) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, false>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
+    else if (raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<1, true>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
+    else hipLaunchKernelGGL((conv_gemm_rb_kernel<1, false>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
     if (hipGetLastError() != hipSuccess) *err = "conv_gemm_rb: launch failed";
     return true;
 }
@@ -476,10 +484,10 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             // leaves them to the routes below (A/B; the tests compare the two).
             static int use_rb = -1;
             if (use_rb < 0) { const char* e = getenv("ADF_GEMM_RB"); use_rb = e ? atoi(e) : 1; }
-            if (use_rb && dtype_bf16 && !flat && gn_pending && gn_in_kernel && !a.gn_ready) {
+            const bool rb_raw = !gn_pending && !a.seg[0].ab && !a.seg[0].act && a.nseg == 1 && !a.res && a.seg[0].taps == 3;
+            if (use_rb && dtype_bf16 && !flat && ((gn_pending && gn_in_kernel && !a.gn_ready) || rb_raw)) {
                 const char* err = nullptr;
                 const void* ident = nullptr;
-                if (a.res && a.nseg == 1 && (a.n == 128 || a.n == 256)) { ident = pp_identity(a.n, stream, &err); if (!ident) return err; }
                 GemmArgs b = a;
                 b.stats = a_in.stats;
                 if (try_launch_rb(b, ident, use_rb >= 2 ? 32 : 256, stream, &err)) {     // ADF_GEMM_RB=2: also small batches (tests)

@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
                 }
-                if (!(dbg & 1)) *(u32x4_t*)(out + off) = pack16<T>(v);
+                if (!(dbg & 1)) *(u32x4_t*)(out + off) = pack16_stored<T>(v);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2_t v2 = {v[e], v[e + 1]};

@@ -66,6 +66,7 @@ struct RbArgs {
     GnFinalizeArgs gn;        // GroupNorm (+ FiLM) of segment 0: the affine table is derived here from the statistics
     const float* bias0; const float* bias1;
     void* out;
+    const void* res;          // identity residual (same layout as out), added in the epilogue in fp32 before the rounding, or nullptr
     double* stats; int stats_groups;
 };
 
@@ -90,7 +91,9 @@ __device__ __forceinline__ void rb_static_for(F&& f) {
 // NH = 128-column halves of the N tile: 1 -> 256 x 128 tiles (n = 128); 2 -> 256 x 256 tiles (n = 256): the activations of a K
 // block are fetched and activated ONCE and multiplied with the two half slabs of each tap in turn (twice the MFMAs per
 // prologue element and per activation byte -- the vector issue slots and the DMA path are what bound the kernel)
-template <int NH>
+// RAW: segment 0 has no prologue (the folded strided convs of Downsample1d): its bytes go HBM -> LDS -> MFMA untouched, the gaps
+// stay empty and no table is derived; only the zero padding of the edge tiles is applied.
+template <int NH, bool RAW>
 __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     typedef bf16_t T;
     constexpr int TM = 256, HP = 32;
@@ -453,6 +456,16 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         const int gs = stats_here ? a.n / a.stats_groups : 8;
         const int tpg = gs / 8;
         const int mw0 = g.m0 + wm * 64;
+        const T* resp = (const T*)a.res;
+        const bool has_res = resp != nullptr;                                   // uniform
+        // the identity residual chunk of a pass is fetched one pass ahead (the queue of this wave is empty here: every DMA of the
+        // finished tile has been waited for, the next ones are issued after the epilogue)
+        auto res_off = [&](int hf, int pass) __attribute__((always_inline)) -> unsigned {
+            const int m = mw0 + (pass >> 2) * 32 + 8 * (pass & 3) + rsub;
+            return (unsigned)((g.b0 * a.L + m) * a.n + g.n0 + hf * kPpTN + wn * 64 + cc * 8);
+        };
+        u32x4_t rnext = u32x4_t{0u, 0u, 0u, 0u};
+        if (has_res) rnext = *(const u32x4_t*)(resp + res_off(0, 0));
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
         const int n = g.n0 + hf * kPpTN + wn * 64 + cc * 8;
@@ -481,7 +494,16 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                     const float4 q0 = *(const float4*)(scr), q1 = *(const float4*)(scr + 4);
                     v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
                 }
-                *(u32x4_t*)(out + off) = pack16<T>(v);
+                if (has_res) {
+                    const u32x4_t rc = rnext;
+                    const int nxt = hf * 8 + i * 4 + p4 + 1;
+                    if (nxt < NH * 8) rnext = *(const u32x4_t*)(resp + res_off(nxt >> 3, nxt & 7));
+                    float rf[8];
+                    unpack16<T>(rc, rf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                }
+                *(u32x4_t*)(out + off) = pack16_stored<T>(v);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2_t v2 = {v[e], v[e + 1]};
@@ -512,7 +534,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         if (a.bias1) bias_v += a.bias1[tid];
     }
     GnRaw gr0 = {}, gr1 = {};
-    if (tid * 2 < ctot0) { gr0 = gn_affine_load(a.gn, b_first, tid * 2); gr1 = gn_affine_load(a.gn, b_first, tid * 2 + 1); }
+    if (!RAW && tid * 2 < ctot0) { gr0 = gn_affine_load(a.gn, b_first, tid * 2); gr1 = gn_affine_load(a.gn, b_first, tid * 2 + 1); }
     Blk dc = make_desc();
     advance();
     issue_a01(dc, 0u); issue_a23(dc, 0u); issue_halo(dc, 0u);
@@ -523,7 +545,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     Blk d2 = make_desc();
     advance();
     if (tid < a.n) ldsBias[tid] = bias_v;
-    if (tid * 2 < ctot0) {
+    if (!RAW && tid * 2 < ctot0) {
         float A0, B0, A1, B1;
         gn_affine_finish<true>(a.gn, tid * 2, gr0, A0, B0);
         gn_affine_finish<true>(a.gn, tid * 2 + 1, gr1, A1, B1);
@@ -544,7 +566,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[hf][i][j][e] = bias_r[j];
     }
-    transform_all(dc, 0u);
+    if (RAW) zero_fill(dc, 0u); else transform_all(dc, 0u);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- pipeline -----------------------------------------------------------------------------------------------------
@@ -599,8 +621,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             const std::integral_constant<int, TAP> tapc{};
             const std::integral_constant<int, (WP + u) & 1> wstc{};
             const std::integral_constant<int, HF> hfc{};
-            if (HF == 0) part_begin(tapc, d1, sa1, part);
-            substep(tapc, wstc, hfc, sa, [&](int q) __attribute__((always_inline)) { part_gap(tapc, d1, sa1, part, HF * 16 + q); },
+            if (HF == 0 && !RAW) part_begin(tapc, d1, sa1, part);
+            substep(tapc, wstc, hfc, sa, [&](int q) __attribute__((always_inline)) { if (!RAW) part_gap(tapc, d1, sa1, part, HF * 16 + q); },
                     [&](int ks) __attribute__((always_inline)) {
                         if (ks == 0) {
                             if (u + 1 < U) issue_w(next_slab(u + 1, 3), (WP + u + 1) & 1);
@@ -616,7 +638,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             if (u < 2 && has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(3 * u + 2);
-            if (u == 2 && kb == 0 && tseq + 1 < ntiles) {            // first block of a tile: the next tile's sample
+            if (!RAW && u == 2 && kb == 0 && tseq + 1 < ntiles) {    // first block of a tile: the next tile's sample
                 const Tile nt = tile_of(tseq + 1);
                 if (nt.b0 != cur_tile.b0) fill_table(nt.b0, (nt.b0 - b_first) & 1);     // nothing else is in flight here
             }

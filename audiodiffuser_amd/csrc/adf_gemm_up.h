@@ -116,9 +116,10 @@ __global__ void __launch_bounds__(512) conv_gemm_up_kernel(const GemmArgs a, int
                     for (int e = 0; e < 16; ++e) {
                         const int row = row_of(i, e);
                         const int orow = (m0 + row) * F + phase - F / 2;
-                        const float v = acc[i][e] + bv;
+                        const unsigned short qv = f32_to_bf16_hw(acc[i][e] + bv);
+                        const float v = bf16_to_f32(qv);                 // statistics of the stored values (adf_common.h pack16_stored)
                         if (m0 + row <= L && orow >= 0 && orow < Lout) { s1 += v; s2 = fmaf(v, v, s2); }
-                        *(unsigned short*)(bufO + row * PO + (wc * 32 + r) * 2) = f32_to_bf16_hw(v);
+                        *(unsigned short*)(bufO + row * PO + (wc * 32 + r) * 2) = qv;
                     }
                 if (a.stats) {
                     constexpr int GS = COUT / 8;           // channels per group (8, 16 or 32): the wave's 32 columns hold 32 / GS groups

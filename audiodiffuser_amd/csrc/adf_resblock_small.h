@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float v = acch[i][e] + bias;
+                const float v = bf16_stored(acch[i][e] + bias);        // h1 as it is stored / read back: statistics of the stored values
                 acch[i][e] = v;
                 if (row_of(i, e) < NTOK) { s1 += v; s2 = fmaf(v, v, s2); }
             }
@@ -276,9 +276,10 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row_of(i, e);
-                const float v = accy[i][e] + bias;
+                const unsigned short qv = f32_to_bf16_hw(accy[i][e] + bias);
+                const float v = bf16_to_f32(qv);
                 if (row < NTOK) { s1 += v; s2 = fmaf(v, v, s2); }
-                *(unsigned short*)(bufX + (row + 1) * PX + col * 2) = f32_to_bf16_hw(v);
+                *(unsigned short*)(bufX + (row + 1) * PX + col * 2) = qv;
             }
         if (a.stats) {
             double d1 = (double)s1, d2 = (double)s2;

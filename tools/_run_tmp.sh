@@ -1,6 +1,3 @@
-for v in rbk9 rbstag rbk1b; do echo "=== $v"; ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_$v.so timeout -k 10 120 python tools/rb_stamps.py 27 1 2>&1 | grep -E "^rc|^T0|^T1 mfma|^T1 barrier|^T2 mfma|^T2 barrier" ; done
-echo "=== product vs stagger (no stamps), per layer"
-for v in "" audiodiffuser_amd/build/variants/libadf_hip_rbstag0.so; do ADF_HIP_LIB=$v ADF_BENCH_VERBOSE=1 timeout -k 10 300 python bench.py --roofline-only --roofline-iters 30 2>/dev/null | tail -1 | python3 -c "
-import json,sys
-rows=json.loads(sys.stdin.read())['rows']
-print(' '.join('%d.%d:%.1f'%(r['resblock'],r['kernel'],r['ms']*1e3) for r in rows if r['resblock'] in (0,2,4,23,25,27)), 'total %.1f'%(sum(r['ms'] for r in rows)*1e3))"; done
+mkdir -p gpurun_out
+python tests/diag/gpu_bf16_parity_report.py > gpurun_out/parity_report.log 2>&1; tail -9 gpurun_out/parity_report.log | cut -c1-200
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/gputests.log 2>&1; echo "gpu tests rc=$?"; tail -5 gpurun_out/gputests.log | cut -c1-600
