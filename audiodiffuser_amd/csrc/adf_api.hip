@@ -590,20 +590,31 @@ struct Walker {
                 check(launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
                 check(launch_transformer_tiles(fa, (int)rows, x.L, 2, s));
             }
+            tap(name + ".qkv", qkv);
+            tap(name + ".att", att);
             tap(name, x2);
             return x2;
         }
+        // the nine-launch path: every stored tensor of the block is a recorded activation (the parity tests hold each launch to
+        // the oracle on its own; the fused kernels above are then held to this path)
         Act xn = new_act(t.c, x.L);
         if (live()) check(launch_ln_rows(x.p, xn.p, h->bf16, rows, t.c, t.lnw, t.lnb, 1e-5f, s));
+        tap(name + ".ln", xn);
         Act qkv = linear(xn, t.qkv, nullptr, 0, false);
+        tap(name + ".qkv", qkv);
         Act att = new_act(t.c, x.L);
         if (live()) check(launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
+        tap(name + ".att", att);
         Act x1 = linear(att, t.proj, x.p, 0, false);
+        tap(name + ".x1", x1);
         Act n1 = new_act(t.c, x.L);
         if (live()) check(launch_ln_rows(x1.p, n1.p, h->bf16, rows, t.c, t.g0, nullptr, 1e-5f, s));
+        tap(name + ".n1", n1);
         Act f1 = linear(n1, t.ff1, nullptr, 1, false);
+        tap(name + ".f1", f1);
         Act n2 = new_act(t.mid, x.L);
         if (live()) check(launch_ln_rows(f1.p, n2.p, h->bf16, rows, t.mid, t.g3, nullptr, 1e-5f, s));
+        tap(name + ".n2", n2);
         Act x2 = linear(n2, t.ff2, x1.p, 0, true);
         tap(name, x2);
         return x2;

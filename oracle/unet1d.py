@@ -128,7 +128,7 @@ def channel_layer_norm(x: torch.Tensor, g: torch.Tensor, eps: float = 1e-5) -> t
     return (x - mean) * (var + eps).rsqrt() * g
 
 
-def self_attention(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP32) -> torch.Tensor:
+def self_attention(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP32, rec=None) -> torch.Tensor:
     """src/models/backbones/attention_utils.py:113-184, plain self-attention branch
     (no context, no RoPE, no mask).  x: [B, N, C].
     bf16 storage: q | k | v are stored tensors (rounded); scores and the softmax statistics are fp32; the
@@ -139,6 +139,9 @@ def self_attention(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP3
     d = c // heads
     qq = q.r(F.linear(x, q.w(p[f"{pre}.to_q.weight"])))
     kv = q.r(F.linear(x, q.w(p[f"{pre}.to_kv.weight"])))
+    if rec is not None:                       # the device stores q | k | v as one [B, N, 3C] tensor (tap "<block>.qkv")
+        qkv = rec("qkv", torch.cat((qq, kv), dim=-1).transpose(1, 2)).transpose(1, 2)
+        qq, kv = qkv[..., :c], qkv[..., c:]
     k, v = kv.chunk(2, dim=-1)
     qq, k, v = (z.reshape(b, n, heads, d).permute(0, 2, 1, 3) for z in (qq, k, v))
     sim = torch.matmul(qq, k.transpose(-1, -2)) * (d ** -0.5)
@@ -149,21 +152,27 @@ def self_attention(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP3
         attn = sim.softmax(dim=-1, dtype=torch.float32)
         o = torch.matmul(attn, v)
     o = q.r(o.permute(0, 2, 1, 3).reshape(b, n, c))
+    if rec is not None:
+        o = rec("att", o.transpose(1, 2)).transpose(1, 2)
     return F.linear(o, q.w(p[f"{pre}.to_out.weight"]))
 
 
-def transformer_block(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP32) -> torch.Tensor:
+def transformer_block(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP32, rec=None) -> torch.Tensor:
     """unet1d.py:106-122 with FeedForward1d :49-61.  bf16 storage rounds every tensor the device stores: both
-    LayerNorm outputs, the attention residual sum, the GELU output, the block output."""
+    LayerNorm outputs, the attention residual sum, the GELU output, the block output.  ``rec(suffix, tensor [B, C, N])``
+    records (and may force) the block's stored intermediates: ln, qkv, att, x1, n1, f1, n2 -- the taps "<block>.<suffix>" of
+    the device's nine-launch path."""
+    r_ = rec if rec is not None else (lambda name, v: v)
     c = x.shape[1]
     y = x.transpose(1, 2)
     ln = q.r(F.layer_norm(y, (c,), p[f"{pre}.norm.weight"], p[f"{pre}.norm.bias"], 1e-5))
-    y = q.r(self_attention(p, f"{pre}.attention", ln, heads, q) + y)
-    x = y.transpose(1, 2)
-    h = q.r(channel_layer_norm(x, p[f"{pre}.feed_forward.0.g"]))
+    ln = r_("ln", ln.transpose(1, 2)).transpose(1, 2)
+    y = q.r(self_attention(p, f"{pre}.attention", ln, heads, q, rec=rec) + y)
+    x = r_("x1", y.transpose(1, 2))
+    h = r_("n1", q.r(channel_layer_norm(x, p[f"{pre}.feed_forward.0.g"])))
     h = F.conv1d(h, q.w(p[f"{pre}.feed_forward.1.weight"]))
-    h = q.r(F.gelu(h))
-    h = q.r(channel_layer_norm(h, p[f"{pre}.feed_forward.3.g"]))
+    h = r_("f1", q.r(F.gelu(h)))
+    h = r_("n2", q.r(channel_layer_norm(h, p[f"{pre}.feed_forward.3.g"])))
     h = F.conv1d(h, q.w(p[f"{pre}.feed_forward.4.weight"]))
     return q.r(h + x)
 
@@ -213,6 +222,9 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
     def h1rec(block):
         return lambda v: rec(block + ".h1", v)
 
+    def subrec(block):
+        return lambda suffix, v: rec(block + "." + suffix, v)
+
     h = rec("to_in", q.r(F.conv1d(x, p["unet.to_in.to_in.weight"], stride=cfg.stride, padding=pad)))  # :584-591 (fp32 weights on the device too)
     temb = rec("temb", time_embedding(p, t))
     if classes is not None:                                                       # :877, resblocks :306-308
@@ -226,12 +238,12 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
             h = rec(f"down{i}.block{j}", resnet_block(p, f"{pre}.blocks.{j}", h, temb, g, q, rec_h1=h1rec(f"down{i}.block{j}")))
             skips.append(h)
         if cfg.attentions[i]:
-            h = rec(f"down{i}.attn", transformer_block(p, f"{pre}.transformer", h, heads, q))
+            h = rec(f"down{i}.attn", transformer_block(p, f"{pre}.transformer", h, heads, q, rec=subrec(f"down{i}.attn")))
             skips.append(h)
         skips_list.append(skips)
     h = rec("mid.pre", resnet_block(p, "unet.bottleneck.pre_block", h, temb, g, q, rec_h1=h1rec("mid.pre")))    # :374-379
     if cfg.use_attention_bottleneck:
-        h = rec("mid.attn", transformer_block(p, "unet.bottleneck.transformer", h, heads, q))
+        h = rec("mid.attn", transformer_block(p, "unet.bottleneck.transformer", h, heads, q, rec=subrec("mid.attn")))
     h = rec("mid.post", resnet_block(p, "unet.bottleneck.post_block", h, temb, g, q, rec_h1=h1rec("mid.post")))
     skip_scale = 2 ** -0.5 if cfg.use_skip_scale else 1.0
     for u, i in enumerate(reversed(range(n))):                                    # :807-812, :542-566
@@ -244,7 +256,7 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
             hraw = torch.cat([h, q.r(sk)], dim=1) if q.bf16 else None
             h = rec(f"up{u}.block{j}", resnet_block(p, f"{pre}.blocks.{j}", hx, temb, g, q, x_raw=hraw, rec_h1=h1rec(f"up{u}.block{j}")))
         if cfg.attentions[i]:
-            h = rec(f"up{u}.attn", transformer_block(p, f"{pre}.transformer", h, heads, q))
+            h = rec(f"up{u}.attn", transformer_block(p, f"{pre}.transformer", h, heads, q, rec=subrec(f"up{u}.attn")))
         h = rec(f"up{u}.conv", upsample_conv(p, f"{pre}.upsample", h, cfg.factors[i], q))
     # :611-622; the device's bf16 MFMA route (num_filters a multiple of 16, <= 128) rounds the weight as an operand
     w_out = p["unet.to_out.to_out.weight"]

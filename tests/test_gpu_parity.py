@@ -11,10 +11,19 @@ Tolerances.  north_star: <= 1e-3 relative (fp32) to the reference CPU path.
       elements flips by one ulp), so every rounding stage between the forced input and the tap turns fp32-level noise
       (1e-7: GroupNorm folded to a*x+b, hardware exp2 / rcp, summation order) into 2e-5 -> 3e-4 -> 9e-4 -> 1.5e-3 ...:
         BF16_CONV_TOL   one or two stages behind the forced input: to_in, every down / up conv, a resblock's conv1 output
-                        ("<block>.h1") and the block output computed from the forced h1 (measured 2e-5 .. 3e-4);
-        BF16_RB1_TOL    a resblock that is ONE launch (64- / 16-position levels): four stages, no h1 tap (measured 1.0e-3 .. 1.5e-3);
-        BF16_TR_TOL     a transformer block (eight stored tensors deep; measured 2.0e-3 .. 3.1e-3).
+                        ("<block>.h1"), the block output computed from the forced h1, and -- on the nine-launch transformer path --
+                        each LayerNorm / projection / feed-forward tensor ("<block>.attn.ln", ".qkv", ".x1", ".n1", ".f1", ".n2") and
+                        the block output computed from the forced n2 (measured 2e-5 .. 1.4e-4);
+        BF16_ATT_TOL    the attention output ("<block>.attn.att") from the forced q | k | v: the device rounds the probabilities
+                        against the running maximum of its online softmax, the oracle against the final one (measured <= 9.3e-4);
+        BF16_RB1_TOL    a resblock that is ONE launch (64- / 16-position levels): four stages, no h1 tap (measured 2.8e-4 .. 4.4e-4);
+        BF16_TR_TOL     a fused transformer block (up to nine stored tensors between two taps: the compounding saturates at the
+                        level of independent roundings; measured 2.0e-3 .. 3.3e-3).  test_unfused_launches_* checks the same blocks
+                        launch by launch, and test_fused_transformer_block_* holds the fused kernels to that path.
       A wrong halo row, a mis-scaled skip segment or a dropped bias shows up at >= 1e-2 in these figures.
+      (The device reduces the GroupNorm statistics from the STORED values, adf_common.h pack16_stored: with statistics of the
+      fp32 accumulators the mean / variance differ from the oracle's by 2^-9 / sqrt(group elements) and every figure above
+      was 5-10x larger.)
     The oracle running FREE from the same input is as far from the device as bf16 is from fp32 (the rounding realisations
     decorrelate within a few layers: measured 1.0e-2 .. 1.5e-2 at the end of the net, profiles/r02_bf16_parity_report.json),
     so that comparison is held to BF16_TOL like bf16-vs-fp32 and adds nothing beyond it; the teacher-forced one is the test."""
@@ -34,8 +43,9 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 1e-3       # the north-star bar; measured ~2e-6
 FP32_TIGHT = 5e-5     # what fp32 mode actually achieves (regression guard)
 BF16_TOL = 6e-2
-BF16_CONV_TOL = 1e-3
-BF16_RB1_TOL = 2.5e-3
+BF16_CONV_TOL = 5e-4
+BF16_RB1_TOL = 1e-3
+BF16_ATT_TOL = 1.5e-3
 BF16_TR_TOL = 5e-3
 T = torch.from_numpy
 CASES = [("tiny", A.config_tiny), ("c1", A.config_c1)]
@@ -71,8 +81,10 @@ def _assert_bf16_parity(cfg, x, t, chained=True, flags=0):
 
 
 def _bf16_tol(name, forced):
+    if name.endswith(".attn.att"):
+        return BF16_ATT_TOL
     if name.endswith(".attn"):
-        return BF16_TR_TOL
+        return BF16_CONV_TOL if name + ".n2" in forced else BF16_TR_TOL     # every intermediate forced: one stage left
     if ".block" in name or name.startswith("mid."):
         if name.endswith(".h1") or name + ".h1" in forced:
             return BF16_CONV_TOL
@@ -90,6 +102,29 @@ def test_every_layer_bf16(tag, mk, flags):
     assert not bad, bad
 
 
+def test_unfused_launches_every_stored_tensor_vs_bf16_oracle():
+    """With the one-launch resblock / transformer kernels switched off (ADF_RB_FUSED=0, ADF_TR_FUSED=0; read once per
+    process, hence the child) EVERY tensor the bf16 path stores is a recorded activation: each launch -- LayerNorm rows,
+    q|k|v projection, attention (VALU and MFMA kernels), output projection + residual, feed-forward convs with GELU, every
+    resblock conv -- is held to the bf16-storage oracle on the device's own inputs.  C3 hyper-parameters (attention from the
+    16x level: 256 / 64 / 16 / 4 / 4 tokens at L = 4096, head dim 32)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADF_RB_FUSED="0", ADF_TR_FUSED="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_forced_report.py"), "c3", "2", "4096"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    forced = rep["forced"]
+    assert rep["finite"]
+    assert sum(k.endswith(".attn.att") for k in forced) == 9 and sum(k.endswith(".h1") for k in forced) == 30
+    bad = {k: (v, _bf16_tol(k, forced)) for k, v in forced.items() if not v < _bf16_tol(k, forced)}
+    assert not bad, bad
+    assert all(_bf16_tol(k, forced) <= BF16_ATT_TOL for k in forced)          # nothing is left at a multi-stage bound
+
+
 def test_c3_width_net_vs_reference_golden(golden):
     """The reference's own forward at the 64-channel width / head dim 32 / attentions=[F,F,T,T,T,T] (B = 1, L = 2048)."""
     cfg = A.config_c3()
@@ -99,7 +134,7 @@ def test_c3_width_net_vs_reference_golden(golden):
     assert rel_err(y.cpu(), T(golden["net_c3_y"])) < FP32_TIGHT
     hd = net.native(y.device)
     for name in hd.tap_names():
-        if name.endswith(".h1"):
+        if name.endswith(".h1") or ".attn." in name:
             continue                                     # inside a reference module: not in the fixture
         got = hd.tap(name, 1, y.device).cpu()
         assert rel_err(got.reshape(1, -1)[:, ::61], T(golden[f"net_c3_tap_{name}"])) < FP32_TIGHT, name
@@ -300,7 +335,7 @@ def test_config3_every_layer_short(dtype, tol):
     bf16, including partial query/key tiles), every recorded layer against the oracle."""
     x = generate_noise(0, 2, 4096) * 0.7
     errs, y, yo = tap_errors(A.config_c3(), x, torch.tensor([-0.9, 0.35]), dtype, 0)
-    assert sum("attn" in k for k in errs) == 9
+    assert sum(k.endswith(".attn") for k in errs) == 9
     bad = {k: v for k, v in errs.items() if not v < tol}
     assert not bad, bad
     if dtype == "bf16":
