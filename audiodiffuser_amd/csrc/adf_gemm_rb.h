@@ -16,6 +16,13 @@
 //     inside a sub-step; the fragment base addresses of a block are computed once per block (12 adds) instead of per read;
 //   * the prologue elements ride between the MFMAs of the wave's own sub-step (as in adf_gemm_pp.h), emitted as
 //     straight-line code per (tap, parity) with the loads of a part at the head of the sub-step.
+// What bounds it now (per-wave s_memtime stamps and knock-out builds, tools/rb_stamps.py, profiles/README.md round 2): a sub-step
+// of two waves on a SIMD costs the SUM of its parts -- 32 MFMAs + fragment reads ~1280 cycles, the 2 x 100 prologue instructions
+// ~740, the DMA issues ~300 -- in whatever order they are arranged: the whole vector burst of waves 0-3 before their MFMAs and
+// of waves 4-7 after theirs, or the DMA issues of the two halves at different points of the sub-step, measured equal to the
+// woven form (those variants are not kept).  The CU's LDS-DMA path does not overlap its two streams either
+// (tools/micro/dma_mix.hip: 16 KB weight slabs from L2 alone 1536 cycles per K block, 32 KB of activations from HBM alone
+// 3043, together 5156).
 // Shapes (checked by launch_rb): bf16, mrows = lin = out_rows a multiple of 256 with a power-of-two tile count per sample,
 // n = n_pad = out_c in {128, 256}, segment 0 = 3 taps (off0 -1) over one or two sources with the GroupNorm table derived in
 // the kernel and SiLU, channels per source a multiple of 64, at most 512 input channels; optional segment 1 = 1 tap raw over
@@ -39,12 +46,7 @@ constexpr int kRbMaxBlk = 24;
 #ifndef ADF_RB_KNOCK
 #define ADF_RB_KNOCK 0
 #endif
-// where a sub-step issues its DMA instructions: 0 = after each K step (weights after step 0, activations after 1 .. 3);
-// 1 = waves 0-3 all of them before the first MFMA, waves 4-7 all of them after K step 1 (the two waves of a SIMD then stall
-// on the issue at different times)
-#ifndef ADF_RB_STAGGER
-#define ADF_RB_STAGGER 0
-#endif
+
 
 struct RbBlk {
     const char* src;      // source tensor + byte offset of the block's first channel
@@ -326,11 +328,6 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) aadr[ks] = sa_ + (abase0[TAP] ^ (unsigned)(ks << 5));
         bf16x8_t fa[2][2], fb[2][2];
-        if (ADF_RB_STAGGER && wave < 4) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) mid(ks);
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[0][i] = *(const bf16x8_t*)(smem + aadr[0] + i * 32 * kPpRow);
 #pragma unroll
@@ -354,11 +351,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                     if (!(ADF_RB_KNOCK & 1)) work(ks * 4 + i * 2 + j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            if (!ADF_RB_STAGGER) mid(ks);
-            else if (ks == 1 && wave >= 4) {
-#pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2) mid(k2);
-            }
+            mid(ks);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
