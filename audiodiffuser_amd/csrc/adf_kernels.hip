@@ -362,12 +362,23 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
 // (batch, head) pair.  S^T = K Q^T is computed (keys on the accumulator rows, the query on the lane), so the
 // softmax over keys is lane-local: 16 registers + one xor-32 exchange.  The P^T accumulator tile is converted
 // to bf16 in place and used directly as the B operand of O^T += V^T P^T (the k order inside a step is
-// 16s + 8(j>>2) + 4h + (j&3), and the V^T fragment is gathered from an LDS copy of V in exactly that order).
+// 16s + 8(j>>2) + 4h + (j&3)).
+// Round 2 (profiles/r01_attention_pmc.txt: 67 vector instructions per MFMA, 9.3 % MFMA utilisation at N = 1024):
+//   * V is staged TRANSPOSED, vt[d][key] with a row pitch of 2 N + 8 bytes (lane = head dim: 32 rows on 32 different
+//     bank pairs), so a V^T fragment is two 8-byte reads (keys 4h .. 4h+3 and 8 + 4h .. 8 + 4h+3 of the 16-key step)
+//     instead of sixteen 2-byte gathers and their shifts / ors;
+//   * the scores stay unscaled in the accumulator: p = exp2(s * c - m) with c = d^-1/2 log2(e) folded into ONE fma per
+//     score (the running maximum lives in that scaled log2 domain), v_exp_f32 directly instead of expf;
+//   * the accumulator rescale (16 multiplies + the alpha arithmetic) is skipped when no lane's maximum grew in the tile
+//     (wave vote; alpha would be exactly 1, so the results are bit for bit the same);
+//   * the key-range mask is only applied in the last, partial key tile.
 typedef __attribute__((ext_vector_type(8))) __bf16 att_bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float att_f32x16_t;
 
+//   * a wave walks `qrep` query tiles of its pair one after the other: the transposed copy of V is staged once per
+//     wpp * qrep query tiles (at N = 1024 the staging was ~1/6 of a block's time with one tile per wave).
 __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
-                                                                int C, int heads, float scale) {
+                                                                int C, int heads, float scale_log2e, int qrep) {
     constexpr int D = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -375,27 +386,38 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
     const int qtiles = (N + 31) >> 5;
     const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);   // waves that share one (b, head) pair
     const int ppb = 4 / wpp;                                    // pairs per block
-    const int qgroups = (qtiles + wpp - 1) / wpp;
+    const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
     const int qg = blockIdx.x % qgroups, pg = blockIdx.x / qgroups;
     const int pair = pg * ppb + wave / wpp;
-    const int qt = qg * wpp + wave % wpp;
     const bool pair_ok = pair < B * heads;
     const int pc = pair_ok ? pair : 0;
     const int b = pc / heads, hd = pc - b * heads;
     const size_t rowstride = (size_t)3 * C;
     const bf16_t* base = qkv + (size_t)b * N * rowstride + (size_t)hd * D;
-    // ---- V of this pair -> LDS [N][32] bf16, staged by the wpp waves of the pair -----------------------
-    char* vl = smem + (size_t)(wave / wpp) * N * 64;
+    // ---- V of this pair -> LDS transposed: vt[d][key], keys padded to a multiple of 32, staged by the wpp waves of the pair
+    const int npad = qtiles * 32;
+    const int pitch = npad * 2 + 8;
+    char* vt = smem + (size_t)(wave / wpp) * D * pitch;
     {
         const int tl = (wave % wpp) * 64 + lane, nthr = wpp * 64;
         const bf16_t* vb = base + 2 * C;
-        for (int idx = tl; idx < N * 4; idx += nthr) {
+        for (int idx = tl; idx < npad * 4; idx += nthr) {
             const int key = idx >> 2, c = idx & 3;
-            *(u32x4_t*)(vl + key * 64 + c * 16) = *(const u32x4_t*)(vb + (size_t)key * rowstride + c * 8);
+            const int krow = key < N ? key : N - 1;                 // padded keys: any finite value (their probability is 0)
+            const u32x4_t v = *(const u32x4_t*)(vb + (size_t)krow * rowstride + c * 8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *(unsigned short*)(vt + (c * 8 + j) * pitch + key * 2) = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
         }
     }
     __syncthreads();
-    if (!pair_ok || qt >= qtiles) return;
+    if (!pair_ok) return;
+    const bf16_t* kb = base + C;
+    const char* vrow = vt + r * pitch + hh * 8;         // this lane's head dim, first key group of a 16-key step
+    for (int rep = 0; rep < qrep; ++rep) {
+    const int qt = (qg * qrep + rep) * wpp + wave % wpp;
+    if (qt >= qtiles) break;
     // ---- Q^T fragments (B operand), query = qt*32 + r ----------------------------------------------------
     const int query = qt * 32 + r;
     const int qrow = query < N ? query : N - 1;
@@ -406,37 +428,49 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
     att_f32x16_t o;
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    const bf16_t* kb = base + C;
-    for (int kt = 0; kt < qtiles; ++kt) {
+    float m = -INFINITY, l = 0.f;                       // running maximum in the scaled log2 domain (s * c), running sum
+    // K fragments (A operand: lane = key) straight from global, one tile ahead of their use
+    auto load_k = [&](int kt, u32x4_t (&kq)[2]) __attribute__((always_inline)) {
         const int key_r = kt * 32 + r;
         const int krow = key_r < N ? key_r : N - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kq[ks] = *(const u32x4_t*)(kb + (size_t)krow * rowstride + ks * 16 + hh * 8);
+    };
+    u32x4_t kcur[2], knext[2];
+    load_k(0, kcur);
+    for (int kt = 0; kt < qtiles; ++kt) {
+        load_k(kt + 1 < qtiles ? kt + 1 : kt, knext);
         att_f32x16_t st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const att_bf16x8_t kf = __builtin_bit_cast(att_bf16x8_t, *(const u32x4_t*)(kb + (size_t)krow * rowstride + ks * 16 + hh * 8));
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
-        }
-        float mt = -INFINITY;
+        for (int ks = 0; ks < 2; ++ks)
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8_t, kcur[ks]), qf[ks], st, 0, 0, 0);
+        kcur[0] = knext[0]; kcur[1] = knext[1];
+        if (kt == qtiles - 1 && (N & 31)) {               // uniform: the partial key tile
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            const float sv = key < N ? st[e] * scale : -INFINITY;
-            st[e] = sv;
-            mt = fmaxf(mt, sv);
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                st[e] = key < N ? st[e] : -INFINITY;
+            }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mn = fmaxf(m, mt);
-        const float alpha = __expf(m - mn);
+        float mt = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+#pragma unroll
+        for (int e = 4; e < 16; e += 2) mt = fmaxf(mt, fmaxf(st[e], st[e + 1]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+        if (!__all(mt <= m)) {                            // some query's maximum grew: rescale (else alpha == 1 exactly)
+            const float mn = fmaxf(m, mt);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] *= alpha;
+            m = mn;
+        }
         float psum = 0.f;
+        const float negm = -m;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float pv = __expf(st[e] - mn); st[e] = pv; psum += pv; }
-        l = l * alpha + psum;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] *= alpha;
-        m = mn;
+        for (int e = 0; e < 16; ++e) { const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, negm)); st[e] = pv; psum += pv; }
+        l += psum;
 #pragma unroll
         for (int sgrp = 0; sgrp < 2; ++sgrp) {
             u32x4_t pw, vw;
@@ -444,17 +478,10 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
             pw.y = pack_bf16x2(st[8 * sgrp + 2], st[8 * sgrp + 3]);
             pw.z = pack_bf16x2(st[8 * sgrp + 4], st[8 * sgrp + 5]);
             pw.w = pack_bf16x2(st[8 * sgrp + 6], st[8 * sgrp + 7]);
-            unsigned short ve[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int key = kt * 32 + 16 * sgrp + 8 * (j >> 2) + 4 * hh + (j & 3);
-                key = key < N ? key : N - 1;             // its probability is 0; keep the value finite
-                ve[j] = *(const unsigned short*)(vl + key * 64 + r * 2);
-            }
-            vw.x = (unsigned)ve[0] | ((unsigned)ve[1] << 16);
-            vw.y = (unsigned)ve[2] | ((unsigned)ve[3] << 16);
-            vw.z = (unsigned)ve[4] | ((unsigned)ve[5] << 16);
-            vw.w = (unsigned)ve[6] | ((unsigned)ve[7] << 16);
+            // V^T fragment: elements j = 0 .. 3 = keys 16 s + 4 h + j, j = 4 .. 7 = keys 16 s + 8 + 4 h + (j - 4)
+            const u32x2_t v0 = *(const u32x2_t*)(vrow + (kt * 32 + 16 * sgrp) * 2);
+            const u32x2_t v1 = *(const u32x2_t*)(vrow + (kt * 32 + 16 * sgrp + 8) * 2);
+            vw.x = v0.x; vw.y = v0.y; vw.z = v1.x; vw.w = v1.y;
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8_t, vw), __builtin_bit_cast(att_bf16x8_t, pw), o, 0, 0, 0);
         }
     }
@@ -469,6 +496,7 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
             w.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
             *(uint2*)(orow + 8 * g + 4 * hh) = w;
         }
+    }
     }
 }
 
@@ -496,11 +524,20 @@ const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N,
         const int qtiles = (N + 31) / 32;
         const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);
         const int ppb = 4 / wpp;
-        const int qgroups = (qtiles + wpp - 1) / wpp;
+        // query tiles per wave: 2 from 8 tiles on, as long as >= 4 blocks per CU remain
+        const int qrep = (qtiles >= 8 && (long long)B * heads * (qtiles / 8) >= 1024) ? 2 : 1;
+        const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
         const long long blocks = (long long)((B * heads + ppb - 1) / ppb) * qgroups;
-        const size_t lds = (size_t)ppb * N * 64;
+        const size_t lds = (size_t)ppb * 32 * ((size_t)qtiles * 64 + 8);       // vt[32][keys padded to 32] + 8 bytes of row padding, per pair
+        static bool attr_done[kMaxDevices] = {};
+        bool& attr = attr_done[current_device()];
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)attention_mfma32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
+                return "attention_mfma: hipFuncSetAttribute failed";
+            attr = true;
+        }
         hipLaunchKernelGGL(attention_mfma32_kernel, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C,
-                           heads, 1.0f / sqrtf(32.0f));
+                           heads, (float)(1.4426950408889634 / sqrt(32.0)), qrep);
         return ADF_LAUNCH_CHECK("attention_mfma");
     }
     return bf16 ? attention_dispatch<bf16_t>(qkv, out, B, N, C, heads, s) : attention_dispatch<float>(qkv, out, B, N, C, heads, s);
@@ -546,11 +583,73 @@ __global__ void __launch_bounds__(256) to_in_kernel(const float* __restrict__ x,
     *(u32x4_t*)(out + ((size_t)b * Lo + m) * nf + (size_t)cc * EPC) = pack16<T>(acc);
 }
 
+// Fast path of the shipped shape (one waveform channel, window 8, stride 2): a thread owns one 16-byte output chunk column
+// (its EPC channels x 8 taps of weights stay in registers) and walks ROWS_PER_BLOCK / rows-per-iteration rows of one sample, so
+// the weight load is paid once per 1024 rows instead of once per 32 (the generic kernel above spends most of its 40 us per
+// call in the global -> LDS weight prologue of its 16 K small blocks); same arithmetic order as the generic kernel.
+template <typename T>
+__global__ void __launch_bounds__(256) to_in_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out, int L,
+                                                         int nf, int pad, const float* __restrict__ coef, int coef_bstride) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int WL = 8, STRIDE = 2, ROWS = 256;   // output rows per block
+    constexpr int WIN = ROWS * STRIDE + 8;           // staged waveform window: x[2 m0 - 4 .. 2 m0 + 2 ROWS + 4)
+    __shared__ __attribute__((aligned(16))) float xs[WIN];
+    const int b = blockIdx.y;
+    const int cpr = nf / EPC;                       // 16-byte chunks per output row (a power of two <= 256, checked by the launcher)
+    const int cc = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+    const int rpi = 256 / cpr;                      // rows per iteration
+    const int Lo = L / STRIDE;
+    const int m0 = blockIdx.x * ROWS;
+    const float cin = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
+    const float* xr = x + (size_t)b * L;
+    // c_in * x of the window, zero outside the waveform (one 16-byte load per thread: the 8 scalar loads per output chunk of a
+    // per-thread version made the kernel vector-memory-instruction bound at 30 us)
+    for (int i = threadIdx.x; i < WIN / 4; i += 256) {
+        const int p0 = m0 * STRIDE - 4 + i * 4;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 >= 0 && p0 + 3 < L) v = *(const float4*)(xr + p0);
+        else {
+            if (p0 >= 0 && p0 < L) v.x = xr[p0];
+            if (p0 + 1 >= 0 && p0 + 1 < L) v.y = xr[p0 + 1];
+            if (p0 + 2 >= 0 && p0 + 2 < L) v.z = xr[p0 + 2];
+            if (p0 + 3 >= 0 && p0 + 3 < L) v.w = xr[p0 + 3];
+        }
+        *(float4*)(xs + i * 4) = float4{cin * v.x, cin * v.y, cin * v.z, cin * v.w};
+    }
+    float wr[WL][EPC];
+#pragma unroll
+    for (int k = 0; k < WL; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) wr[k][e] = w[(size_t)(cc * EPC + e) * WL + k];
+    __syncthreads();
+    const int shift = 4 - pad;                      // x[m * STRIDE + k - pad] sits at xs[(m - m0) * STRIDE + k + shift]
+    for (int ml = rsub; ml < ROWS && m0 + ml < Lo; ml += rpi) {
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < WL; ++k) {
+            const float xv = xs[ml * STRIDE + k + shift];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = fmaf(wr[k][e], xv, acc[e]);
+        }
+        *(u32x4_t*)(out + ((size_t)b * Lo + m0 + ml) * nf + (size_t)cc * EPC) = pack16<T>(acc);
+    }
+}
+
 const char* launch_to_in(const float* x, const float* w, void* out, int bf16, int B, int in_ch, int L, int nf,
                          int wl, int stride, int pad, const float* coef, int coef_bstride, hipStream_t s) {
     const int epc = bf16 ? 8 : 4;
     if (nf % epc) return "to_in: num_filters must be a multiple of a 16-byte chunk";
     if (L % stride) return "to_in: L % stride != 0";
+    const int cpr_fast = nf / epc;
+    if (in_ch == 1 && wl == 8 && stride == 2 && pad >= 0 && pad <= 4 && L % 4 == 0 && cpr_fast <= 256 && (cpr_fast & (cpr_fast - 1)) == 0) {
+        const int Lo = L / stride;
+        dim3 grid((unsigned)((Lo + 255) / 256), B);
+        if (bf16) hipLaunchKernelGGL(to_in_rows_kernel<bf16_t>, grid, dim3(256), 0, s, x, w, (bf16_t*)out, L, nf, pad, coef, coef_bstride);
+        else hipLaunchKernelGGL(to_in_rows_kernel<float>, grid, dim3(256), 0, s, x, w, (float*)out, L, nf, pad, coef, coef_bstride);
+        return ADF_LAUNCH_CHECK("to_in_rows");
+    }
     const size_t lds = (size_t)nf * in_ch * wl * sizeof(float);
     if (lds > 60000) return "to_in: weight tile too large for LDS";
     const long long work = (long long)(L / stride) * (nf / epc);

@@ -146,8 +146,11 @@ def self_attention(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP3
     qq, k, v = (z.reshape(b, n, heads, d).permute(0, 2, 1, 3) for z in (qq, k, v))
     sim = torch.matmul(qq, k.transpose(-1, -2)) * (d ** -0.5)
     if q.bf16:
+        # the device's MFMA kernel (head dim 32, <= 1024 tokens) feeds the probabilities to the matrix cores as bf16; its
+        # vector kernel (other head sizes) keeps them in fp32
         pr = torch.exp(sim - sim.amax(dim=-1, keepdim=True))
-        o = torch.matmul(q.r(pr), v) / pr.sum(dim=-1, keepdim=True)
+        pv = q.r(pr) if (d == 32 and n <= 1024) else pr
+        o = torch.matmul(pv, v) / pr.sum(dim=-1, keepdim=True)
     else:
         attn = sim.softmax(dim=-1, dtype=torch.float32)
         o = torch.matmul(attn, v)

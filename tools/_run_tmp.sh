@@ -1,6 +1,5 @@
-ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbphs.so timeout -k 10 120 python tools/rb_stamps.py 27 1 2>&1 | grep -E "^rc|^T" | head -12
-for v in "" audiodiffuser_amd/build/variants/libadf_hip_rbph.so; do ADF_HIP_LIB=$v ADF_BENCH_VERBOSE=1 timeout -k 10 300 python bench.py --roofline-only --roofline-iters 30 2>/dev/null | tail -1 | python3 -c "
-import json,sys
-rows=json.loads(sys.stdin.read())['rows']
-print(' '.join('%d.%d:%.1f'%(r['resblock'],r['kernel'],r['ms']*1e3) for r in rows if r['resblock'] in (0,2,4,23,25,27)), 'total %.1f'%(sum(r['ms'] for r in rows)*1e3))"; done
-for v in "" audiodiffuser_amd/build/variants/libadf_hip_rbph.so; do ADF_HIP_LIB=$v timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-precision-check 2>/dev/null | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"; done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests -m gpu -q -x -k "config3_every or unfused or every_layer_bf16 or c1_full or test_net_and" 2>&1 | tail -3 | cut -c1-600
+rm -rf /tmp/p1; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 bench.py --config c3 --sampler dpm --steps 1 --warmup 1 --no-cpu-baseline --no-pmc --no-precision-check > /tmp/p1.log 2>&1 || { tail -5 /tmp/p1.log; exit 1; }
+grep ms_per_step /tmp/p1.log | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('c3 dpm ms_per_step', j['ms_per_step'])"
+python3 tools/trace_summary.py $(ls /tmp/p1/*/*kernel_trace.csv | head -1) 98 --grid | grep -E "attention|to_in|to_out|window" 
