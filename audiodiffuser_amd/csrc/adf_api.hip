@@ -450,7 +450,7 @@ struct Walker {
         double* s0 = ensure_stats(x);
         double* s1 = skip ? ensure_stats(*skip) : nullptr;
         static int short_max = -1;       // ADF_SHORT_LEVEL: longest level that materialises silu(GN(x)) for flat GEMM tiles
-        if (short_max < 0) { const char* e = getenv("ADF_SHORT_LEVEL"); short_max = e ? atoi(e) : 32; }
+        if (short_max < 0) short_max = (int)adf_tuning("ADF_SHORT_LEVEL", 32);
         const bool short_level = x.L <= short_max && (x.L & (x.L - 1)) == 0;
         float* ab1 = (float*)alloc((size_t)B * ctot * 2 * 4);
         GnFinalizeArgs f1;
@@ -459,7 +459,7 @@ struct Walker {
         f1.scale1 = sscale; f1.eps = 1e-5f; f1.gamma = r.g1w; f1.beta = r.g1b; f1.film = nullptr; f1.ab = ab1;
         // short levels in bf16 mode: the whole resblock in one launch (adf_resblock_small.h); ADF_RB_FUSED=0 keeps the separate launches
         static int rb_fused = -1;
-        if (rb_fused < 0) { const char* e = getenv("ADF_RB_FUSED"); rb_fused = e ? atoi(e) : 1; }
+        if (rb_fused < 0) rb_fused = adf_route_switch("ADF_RB_FUSED", 1);
         if (rb_fused && h->bf16 && (x.L == 16 || x.L == 64) && r.cout == 256 && x.C == 256 && (!skip || skip->C == 256) && G == 8 &&
             r.c1.wfrag && r.c2.wfrag && (!r.has_res || r.cr.wfrag) && r.c1.n_pad == 256 && !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) {
             Act y = new_act(r.cout, x.L);
@@ -474,20 +474,7 @@ struct Walker {
             fa.b1 = r.c1.bias; fa.b2 = r.c2.bias; fa.br = r.has_res ? r.cr.bias : nullptr;
             fa.skip_scale = sscale; fa.eps = 1e-5f;
             y.stats = alloc_stats(); fa.stats = y.stats;
-            static int rb_stamps = -1;    // ADF_TR_STAMPS=1 (eager runs only): stage times of workgroup 0
-            if (rb_stamps < 0) { const char* e = getenv("ADF_TR_STAMPS"); rb_stamps = e ? atoi(e) : 0; }
-            unsigned long long* dst = nullptr;
-            if (rb_stamps && live()) { if (hipMalloc((void**)&dst, 16 * 8) != hipSuccess) dst = nullptr; fa.stamps = dst; }
             if (live()) check(launch_resblock_small(fa, B, x.L, ctot, s));
-            if (dst) {
-                unsigned long long hst[8];
-                if (hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
-                    fprintf(stderr, "[adf resblock] %s L=%d cin=%d cycles: params+raw=%llu res=%llu act=%llu conv1=%llu gn2=%llu conv2=%llu out=%llu total=%llu\n",
-                            name.c_str(), x.L, ctot, hst[1] - hst[0], hst[2] - hst[1], hst[3] - hst[2], hst[4] - hst[3], hst[5] - hst[4],
-                            hst[6] - hst[5], hst[7] - hst[6], hst[7] - hst[0]);
-                }
-                (void)hipFree(dst);
-            }
             RbRec rec{name, GemmArgs{}, GemmArgs{}, r.cin, r.cout, x.L};
             rec.g1.nseg = 0;                               // marks a fused block for adf_bench_resblock (keeps the block numbering)
             p->rbs.push_back(rec);
@@ -543,7 +530,7 @@ struct Walker {
         const long long rows = (long long)p->B * x.L;
         // short levels in bf16 mode: the whole block in one launch (adf_transformer.h); ADF_TR_FUSED=0 keeps the nine launches
         static int tr_fused = -1;
-        if (tr_fused < 0) { const char* e = getenv("ADF_TR_FUSED"); tr_fused = e ? atoi(e) : 2; }
+        if (tr_fused < 0) tr_fused = adf_route_switch("ADF_TR_FUSED", 2);
         if (tr_fused && h->bf16 && t.c == 256 && t.mid == 512 && h->cfg.attention_heads == 8 && (x.L == 16 || x.L == 64) &&
             x.C == 256 && t.qkv.nchunk == 4 && t.ff2.nchunk == 8 && t.qkv.wfrag) {
             Act x2 = new_act(t.c, x.L);
@@ -555,20 +542,7 @@ struct Walker {
             fa.npad_qkv = t.qkv.n_pad; fa.npad_proj = t.proj.n_pad; fa.npad_ff1 = t.ff1.n_pad; fa.npad_ff2 = t.ff2.n_pad;
             fa.eps = 1e-5f;
             if (h->cfg.resnet_groups == 8 && !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) { x2.stats = alloc_stats(); fa.stats = x2.stats; }
-            static int tr_stamps = -1;    // ADF_TR_STAMPS=1 (eager runs only): print the stage times of workgroup 0 of every fused block
-            if (tr_stamps < 0) { const char* e = getenv("ADF_TR_STAMPS"); tr_stamps = e ? atoi(e) : 0; }
-            unsigned long long* dst = nullptr;
-            if (tr_stamps && live()) { if (hipMalloc((void**)&dst, 16 * 8) != hipSuccess) dst = nullptr; fa.stamps = dst; }
             if (live()) check(launch_transformer_small(fa, p->B, x.L, s));
-            if (dst) {
-                unsigned long long hst[11];
-                if (hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
-                    fprintf(stderr, "[adf transformer] %s L=%d cycles:", name.c_str(), x.L);
-                    for (int i = 1; i < 11; ++i) fprintf(stderr, " s%d=%llu", i, hst[i] - hst[i - 1]);
-                    fprintf(stderr, " total=%llu\n", hst[10] - hst[0]);
-                }
-                (void)hipFree(dst);
-            }
             tap(name, x2);
             return x2;
         }

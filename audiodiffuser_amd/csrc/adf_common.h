@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace adf {
 
@@ -189,6 +190,24 @@ static inline int current_device() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
     return d;
+}
+
+// Run-time switches.  ROUTE switches (which of two equivalent kernel routes a layer takes) are read from the environment
+// once per process: the parity tests run both sides of each (ADF_GEMM_PP / _RB / _UP / _WS, ADF_RB_FUSED, ADF_TR_FUSED, and
+// ADF_GEMM_TRACE, which prints the route of every launch).  TUNING thresholds are compile-time constants in the product
+// build; a build with -DADF_EXPERIMENTS reads them from the environment too (A/B runs inside one gpurun call).
+static inline int adf_route_switch(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static inline long long adf_tuning(const char* name, long long dflt) {
+#ifdef ADF_EXPERIMENTS
+    const char* e = getenv(name);
+    return e ? atoll(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

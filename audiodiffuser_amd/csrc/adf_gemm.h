@@ -64,7 +64,6 @@ struct GemmArgs {
     int scatter_f, scatter_pad;  // transposed conv: n = phase*out_c + co -> row m*f + phase - pad
     double* stats;       // optional [B][stats_groups][2] (sum, sumsq) of the produced tensor
     int stats_groups;
-    int dbg;             // timing experiments only (ADF_GEMM_DBG): 1 skip stores, 2 skip prologue math, 4 skip MFMA, 8 skip stats; pp kernel: 32 skip weight DMA, 64 skip activation DMA, 128 skip barriers
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -265,7 +264,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         const int tg = local % ntg;
         if (tg == 0) {
             const int nrows = nsegs * ((seg - 1) * sg.stride + sg.taps);
-            const bool act = sg.act != 0 && !(a.dbg & 2);
+            const bool act = sg.act != 0;
             const bool use_ab = sg.ab != nullptr;
             f32x2_t fa2[EPC / 2], fb2[EPC / 2];
 #pragma unroll
@@ -332,7 +331,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
             const int j = a.flat ? ti / seg : 0;
             abase[i] = j * segrows + (ti - j * seg) * sg.stride;
         }
-        if (a.dbg & 4) ntap = 0;
         for (int tap_l = 0; tap_l < ntap; ++tap_l) {
             const int aoff = sg.off0 + (tg * kTapGroup + tap_l) * sg.step - off_min;
             int arow[MT], wrow[NT];
@@ -427,7 +425,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     constexpr int CPR = TN / EPC;   // 16-byte chunks per tile row
     constexpr int P2 = (TM * CPR) / NTHR;   // chunks per thread (exact: TM*CPR is a multiple of NTHR)
     static_assert((TM * CPR) % NTHR == 0, "tile chunks must divide evenly over the block");
-    if (!(a.dbg & 1)) {
+    {
         unsigned off[P2];
         bool okv[P2];
         u32x4_t rres[P2];
@@ -471,7 +469,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
         // segment: reduce over the channels of a group inside the thread, over the threads of a group and over
         // the row-lanes of the wave with shuffles, then one fp64 atomic pair per (wave, group).
         constexpr int RPK = NTHR / CPR;                 // tile rows covered by one k step
-        const bool stats_here = do_stats && !(a.dbg & 8);
+        const bool stats_here = do_stats;
         const int gs = stats_here ? a.out_c / a.stats_groups : EPC;   // channels per group (>= EPC, power of two)
         const int tpg = gs / EPC;                       // threads (adjacent cc) per group
         float s1 = 0.f, s2 = 0.f;

@@ -9,13 +9,6 @@
 #include <cstring>
 #include <vector>
 
-#ifdef ADF_PP_STAMP
-namespace adf { __device__ unsigned long long adf_pp_stamps[8 * 32]; }
-// diagnostic build only: copies the stamps of the last DMA-kernel launch to the host
-extern "C" int adf_debug_pp_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adf::adf_pp_stamps), sizeof(unsigned long long) * 8 * 32);
-}
-#endif
 
 #ifdef ADF_RB_STAMP
 namespace adf { __device__ unsigned long long adf_rb_stamps[8 * 16]; }
@@ -154,6 +147,18 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     if (g0.taps != 3 || g0.off0 != -1 || g0.stride != 1 || g0.step != 1) return false;
     if (g0.c0 % 64 || g0.c1 % 64 || ((g0.c0 + g0.c1) / 64) % 2 || (g0.c0 + g0.c1) / 64 > kRbMaxBlk) return false;
     if (!raw0 && g0.c0 + g0.c1 > kPpMaxCin) return false;
+    if (!raw0) {
+        // the kernel's table fill sums one or two stored (fine) statistics groups per GroupNorm group: one source, or two equal ones
+        const GnFinalizeArgs& gn = g0.gn;
+        if (gn.G < 1 || (gn.c0 + gn.c1) % gn.G || gn.c0 % gn.G || gn.c1 % gn.G) return false;
+        const int gs = (gn.c0 + gn.c1) / gn.G;
+        if (gn.c0 % gs) return false;                                       // a group must not straddle the two sources
+        for (int cs : {gn.c0, gn.c1}) {
+            if (cs == 0) continue;
+            const int fg = cs / gn.G;
+            if (gs != fg && gs != 2 * fg) return false;
+        }
+    }
     if (raw0 && (a.nseg > 1 || a.res)) return false;
     if (a.res && a.nseg > 1) return false;
     RbArgs r;
@@ -301,7 +306,7 @@ const char* dispatch(const GemmArgs& a, int tm, int tn, hipStream_t s) {
 // ADF_GEMM_TRACE=1: print the kernel chosen for every launch (stderr)
 static void trace_route(const char* route, const GemmArgs& a, int tm, int tn) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("ADF_GEMM_TRACE"); on = e ? atoi(e) : 0; }
+    if (on < 0) on = adf_route_switch("ADF_GEMM_TRACE", 0);
     if (!on) return;
     fprintf(stderr, "[adf gemm] %-6s B=%d lin=%d mrows=%d n=%d/%d nseg=%d seg0(c=%d+%d taps=%d stride=%d off0=%d step=%d ab=%d act=%d)", route, a.B, a.lin, a.mrows,
             a.n, a.n_pad, a.nseg, a.seg[0].c0, a.seg[0].c1, a.seg[0].taps, a.seg[0].stride, a.seg[0].off0, a.seg[0].step, a.seg[0].ab != nullptr, a.seg[0].act);
@@ -313,7 +318,6 @@ static void trace_route(const char* route, const GemmArgs& a, int tm, int tn) {
 const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t stream, bool* stats_fused) {
     GemmArgs a = a_in;
     if (stats_fused) *stats_fused = false;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ADF_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     if (a.nseg < 1 || a.nseg > 2) return "conv_gemm: nseg must be 1 or 2";
     if (a.n_pad % 32) return "conv_gemm: n_pad must be a multiple of 32";
     const int epc = dtype_bf16 ? 8 : 4;
@@ -324,7 +328,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
     // less per GroupNorm: 4.7 us each, 44 per network pass before), every other route gets gn_finalize launched here
     const bool gn_pending = a.seg[0].gn.gamma != nullptr;
     static int gn_in_kernel = -1;     // ADF_GEMM_GN=0: always launch gn_finalize (A/B)
-    if (gn_in_kernel < 0) { const char* e = getenv("ADF_GEMM_GN"); gn_in_kernel = e ? atoi(e) : 1; }
+    if (gn_in_kernel < 0) gn_in_kernel = (int)adf_tuning("ADF_GEMM_GN", 1);
     auto settle_gn = [&](bool in_kernel) -> const char* {
         if (!gn_pending) return nullptr;
         in_kernel = in_kernel && gn_in_kernel;
@@ -372,14 +376,12 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         return tmn * ((a.n_pad + tn_ - 1) / tn_);
     };
     static int min_blocks = -1;
-    if (min_blocks < 0) { const char* e = getenv("ADF_GEMM_MINBLOCKS"); min_blocks = e ? atoi(e) : 512; }
+    if (min_blocks < 0) min_blocks = (int)adf_tuning("ADF_GEMM_MINBLOCKS", 512);
     while (nblocks(tm, tn) < min_blocks && tn > 32) tn >>= 1;
     while (nblocks(tm, tn) < min_blocks && tm > 32) {
         tm >>= 1;
         if (flat && a.mrows >= tm) flat = 0;   // a tile now lies inside one sample again
     }
-    { static int ftn = -1, ftm = -1; if (ftn < 0) { const char* e = getenv("ADF_GEMM_TN"); ftn = e ? atoi(e) : 0; e = getenv("ADF_GEMM_TM"); ftm = e ? atoi(e) : 0; }
-      if (ftn && a.n_pad >= 128 && a.mrows >= 1024) tn = ftn; if (ftm && a.mrows >= 1024 && !flat) { bool fits = true; for (int s = 0; s < a.nseg; ++s) if ((ftm - 1) * a.seg[s].stride + a.seg[s].taps > kARows) fits = false; if (fits) tm = ftm; } }
     a.flat = flat;
     a.seg_rows = flat ? a.mrows : tm;
     if (a.stats) {
@@ -395,7 +397,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
     {
         // transposed convs of the up path in bf16 (adf_gemm_up.h); ADF_GEMM_UP=0 leaves them to the plain / weight-stationary kernels
         static int use_up = -1;
-        if (use_up < 0) { const char* e = getenv("ADF_GEMM_UP"); use_up = e ? atoi(e) : 1; }
+        if (use_up < 0) use_up = adf_route_switch("ADF_GEMM_UP", 1);
         const GemmSeg& g = a.seg[0];
         const int f = a.scatter_f, cout = a.out_c, cin = g.c0;
         if (use_up && dtype_bf16 && (f == 2 || f == 4) && a.nseg == 1 && g.taps == 2 && g.stride == 1 && g.off0 == 0 && g.step == -1 && !g.ab &&
@@ -425,10 +427,10 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
     {
         // short levels (few rows, long K): intra-block split-K, 32 x 32 tiles, 4 waves x K/4 each
         static int use_ks = -1;
-        if (use_ks < 0) { const char* e = getenv("ADF_GEMM_KSPLIT"); use_ks = e ? atoi(e) : 1; }
+        if (use_ks < 0) use_ks = (int)adf_tuning("ADF_GEMM_KSPLIT", 1);
         int nit_total = 0;
         static long long ks_rows = -1;      // ADF_GEMM_KSPLIT_ROWS: largest B * rows the split-K kernel takes
-        if (ks_rows < 0) { const char* e = getenv("ADF_GEMM_KSPLIT_ROWS"); ks_rows = e ? atoll(e) : 4096; }
+        if (ks_rows < 0) ks_rows = adf_tuning("ADF_GEMM_KSPLIT_ROWS", 4096);
         bool ks_ok = use_ks && !a.scatter_f && (long long)a.B * a.mrows <= ks_rows;
         const int ks_flat = (can_flat && a.mrows < 32 && 32 % a.mrows == 0) ? 1 : 0;
         const int ks_seg = ks_flat ? a.mrows : 32;
@@ -440,7 +442,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             nit_total += g.nchunk;
         }
         static int ks_minit = -1;           // ADF_GEMM_KSPLIT_MINIT: fewest 64-channel K chunks (all segments) for which K is split over the waves
-        if (ks_minit < 0) { const char* e = getenv("ADF_GEMM_KSPLIT_MINIT"); ks_minit = e ? atoi(e) : 4; }
+        if (ks_minit < 0) ks_minit = (int)adf_tuning("ADF_GEMM_KSPLIT_MINIT", 4);
         if (ks_ok && nit_total >= ks_minit) {
             // 64 x 64 tiles when they still give >= 128 blocks: every tile row re-reads all weights and every tile column
             // all activations (from L2), so the bytes a CU pulls halve against 32 x 32 (ADF_GEMM_KSPLIT=32 forces the small tile)
@@ -469,7 +471,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         // no identity residual (those layers keep their weights resident in the weight-stationary kernel, which wins).
         // ADF_GEMM_PP=0 disables it, =2 also takes identity-residual layers and >= 128 tiles (used by the tests).
         static int use_pp = -1;
-        if (use_pp < 0) { const char* e = getenv("ADF_GEMM_PP"); use_pp = e ? atoi(e) : 1; }
+        if (use_pp < 0) use_pp = adf_route_switch("ADF_GEMM_PP", 1);
         // tile height: 256 rows when that gives every CU a tile, else 128 rows (the L = 256 level at batch 64)
         int ptm = 0;
         if (use_pp && dtype_bf16 && !flat && tm == 128) {
@@ -483,7 +485,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             // resblock convs (GroupNorm + SiLU prologue derived in the kernel) on 256-row tiles: adf_gemm_rb.h.  ADF_GEMM_RB=0
             // leaves them to the routes below (A/B; the tests compare the two).
             static int use_rb = -1;
-            if (use_rb < 0) { const char* e = getenv("ADF_GEMM_RB"); use_rb = e ? atoi(e) : 1; }
+            if (use_rb < 0) use_rb = adf_route_switch("ADF_GEMM_RB", 1);
             const bool rb_raw = !gn_pending && !a.seg[0].ab && !a.seg[0].act && a.nseg == 1 && !a.res && a.seg[0].taps == 3;
             if (use_rb && dtype_bf16 && !flat && ((gn_pending && gn_in_kernel && !a.gn_ready) || rb_raw)) {
                 const char* err = nullptr;
@@ -502,7 +504,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             // can come here with ADF_GEMM_PP_LINEAR=1 (residual as an identity K segment, GELU in the epilogue): measured
             // equal to the plain kernel end to end (388.6-393.9 vs 389.6-390.9 ms), so they stay there by default
             static int pp_linear = -1;
-            if (pp_linear < 0) { const char* e = getenv("ADF_GEMM_PP_LINEAR"); pp_linear = e ? atoi(e) : 0; }
+            if (pp_linear < 0) pp_linear = (int)adf_tuning("ADF_GEMM_PP_LINEAR", 0);
             const bool linear = a.seg[0].taps == 1 && a.nseg == 1;
             const bool take = linear ? pp_linear != 0 : (use_pp == 2 || !a.res);
             if (take) {
@@ -532,13 +534,13 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
     {
         // large stride-1 layers: weight-stationary persistent kernel when the weights of an N tile fit in LDS
         static int use_ws = -1;
-        if (use_ws < 0) { const char* e = getenv("ADF_GEMM_WS"); use_ws = e ? atoi(e) : 1; }
+        if (use_ws < 0) use_ws = adf_route_switch("ADF_GEMM_WS", 1);
         bool ws_ok = use_ws && !flat && tm == 128 && a.n_pad >= 64;
         for (int s = 0; s < a.nseg; ++s)
             if (a.seg[s].stride != 1 || 127 + a.seg[s].taps > kWsARows) ws_ok = false;
         const long long tiles_m_total = (long long)((a.mrows + 127) / 128) * a.B;
         static long long ws_min_m = -1;     // ADF_GEMM_WS_MINM: fewest 128-row tiles for the weight-stationary kernel
-        if (ws_min_m < 0) { const char* e = getenv("ADF_GEMM_WS_MINM"); ws_min_m = e ? atoll(e) : 256; }
+        if (ws_min_m < 0) ws_min_m = adf_tuning("ADF_GEMM_WS_MINM", 256);
         if (ws_ok && tiles_m_total >= ws_min_m) {
             // measured on MI355X: the weight-stationary kernel wins with 128-wide N tiles (Cin = Cout = 128 layers);
             // with 64-wide tiles (ADF_GEMM_WS=64 to force) the doubled activation staging loses to the plain kernel

@@ -35,11 +35,6 @@
 
 namespace adf {
 
-#ifdef ADF_PP_STAMP
-// diagnostic build only (tools/build_variant.sh stamp -DADF_PP_STAMP; tools/pp_stamps.py): s_memtime of every wave of
-// thread block 0 at the phase boundaries of one steady-state K block; the product build contains none of this
-extern __device__ unsigned long long adf_pp_stamps[8 * 32];
-#endif
 
 constexpr int kPpTM = 256, kPpTN = 128;                    // kPpTM: the larger of the two tile heights (MT = 2); MT = 1 gives 128
 constexpr int kPpRow = 128;                                 // bytes of K per staged row (64 bf16)
@@ -63,14 +58,8 @@ constexpr int kPpMaxN = kPpBias / 4;
 // (Dynamic LDS starts at byte 0: the kernel has no static __shared__.)
 __device__ __forceinline__ void pp_dma16(const char* base, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-#ifdef ADF_PP_VADDR
-    const char* g = base + voff;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
-#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(base), "v"(voff), "s"(lds_dst) : "memory", "vcc");   // (vcc is not accepted as the address pair)
-#endif
 }
 
 // wave-uniform description of one K block (64 channels of one segment) of one tile
@@ -104,15 +93,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-#ifdef ADF_PP_DBG
-    // timing knock-outs of a diagnostic build (tools/build_variant.sh dbg -DADF_PP_DBG; ADF_GEMM_DBG=bits): 1 no stores,
-    // 2 no prologue math, 4 no MFMA, 32 no weight DMA, 64 no activation DMA, 128 no barriers, 256 no fragment reads,
-    // 512 no epilogue, 1024 no descriptor updates.
-    // Results are wrong by construction; the product build folds every test away.
-    const int dbg = a.dbg;
-#else
-    constexpr int dbg = 0;
-#endif
     const bool early = (wave & 4) == 0;            // waves w and w+4 share a SIMD: they run prologue and MFMAs in opposite order
     const int lrow = lane >> 3;                     // row inside an 8-row DMA piece
     // logical 16-byte chunk stored at this lane's slot: slot ^ ((row >> 1) & 7), row = 8 * piece + lrow, piece = wave + 8 i
@@ -156,7 +136,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         }
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) {
-        if (dbg & 128) return;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     // wait until at most n of this wave's DMA instructions (the youngest ones) are still in flight
@@ -198,7 +177,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     // its first use is prepared).  Returns the number of DMA instructions this wave issued (0 / 4 / 5 / 6).
     // part: 0 = pieces 0-1, 1 = pieces 2-3, 2 = halo + table, -1 = everything (pipeline fill)
     auto issue_a = [&](const PpBlk& d, int st, int part) __attribute__((always_inline)) -> int {
-        if (dbg & 64) return 0;
         const unsigned colbytes = (unsigned)chunk * 16u;
         const unsigned ldsA = (unsigned)(st * kPpAStage) + (unsigned)wave * 1024u;
         // uniform base = row p_lo of the tile (may be row -1 of the sample: only wave 0's first row, which then fetches row
@@ -241,7 +219,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     // ---- DMA of one weight slab (tap slab at wsrc) into W stage st: 2 pieces per wave ---------------------
     const unsigned wlane = (unsigned)srow * (unsigned)kRowBytes + (unsigned)chunk * 16u;
     auto issue_w = [&](const char* wsrc, int st) __attribute__((always_inline)) {
-        if (dbg & 32) return;
         const unsigned ldsW = (unsigned)(kPpOffW + st * kPpWStage) + (unsigned)wave * 1024u;
         pp_dma16(wsrc, wlane, ldsW);
         pp_dma16(wsrc + 64 * kRowBytes, wlane, ldsW + 8192u);
@@ -262,7 +239,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         char* const ldsA = smem + st * kPpAStage + wave * 1024 + lane_lds;
         char* const ldsH = smem + st * kPpAStage + HP * 1024 + lane_lds;
         const bool halo = wave == 0 && d.taps == 3;
-        if (P != 3 && !(dbg & 2) && (d.tabofs >= 0 || d.act || d.scale != 1.0f)) {       // uniform
+        if (P != 3 && (d.tabofs >= 0 || d.act || d.scale != 1.0f)) {       // uniform
             float fa[8], fb[8];
             if (d.tabofs >= 0) {
                 const f32x4_t* tp = (const f32x4_t*)(ldsTab + d.tabofs + chunk * 64);
@@ -348,22 +325,14 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         const char* pa = smem + stA * kPpAStage;
         const char* pw = smem + kPpOffW + stW * kPpWStage;
         bf16x8_t fa[2][MT], fb[2][2];
-        if (dbg & 256) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[0][i] = fa[1][i] = bf16x8_t{};
+        for (int i = 0; i < MT; ++i) fa[0][i] = *(const bf16x8_t*)(pa + ab + i * 32 * kPpRow);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[0][j] = fb[1][j] = bf16x8_t{};
-        }
-        if (!(dbg & 256)) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[0][i] = *(const bf16x8_t*)(pa + ab + i * 32 * kPpRow);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8_t*)(pw + wbase + j * 32 * kPpRow);
-        }
+        for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8_t*)(pw + wbase + j * 32 * kPpRow);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < 4 && !(dbg & 256)) {
+            if (ks + 1 < 4) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) fa[nxt][i] = *(const bf16x8_t*)(pa + (ab ^ (unsigned)((ks + 1) << 5)) + i * 32 * kPpRow);
 #pragma unroll
@@ -373,7 +342,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (!(dbg & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
                     if constexpr (kGaps) {
                         __builtin_amdgcn_sched_barrier(0);
                         gap(ks * 2 * MT + i * 2 + j);
@@ -441,7 +410,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         // them (IR passes move pure arithmetic across sched_barrier) and leave their interleaving to the scheduler.
         auto gap = [&](int q) __attribute__((always_inline)) {
             const int ea = q - G0, eb = ea - 1;
-            if (fuse && !(dbg & 2)) {
+            if (fuse) {
                 const bool va = valid(ea), vb = valid(eb);
                 float told = 0.f, vold = 0.f, x = 0.f, o = 0.f, v = 0.f, t = 0.f;
                 if (vb) { told = tq[eb & 1]; vold = vp[eb & 1]; asm volatile("" : "+v"(told)); }
@@ -481,7 +450,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     // ---- wave-local epilogue of one finished tile --------------------------------------------------------------
     const int cc = lane & 7, rsub = lane >> 3;              // this lane's 16-byte chunk column / row inside an 8-row pass
     auto epilogue = [&](int tseq, int next_n0) __attribute__((always_inline)) {
-        if (dbg & 512) return;
         int b0, m0, n0;
         geom(tseq, b0, m0, n0);
         float* sc = (float*)(ldsScr + wave * 2048);          // [8][64] fp32
@@ -522,7 +490,7 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
                 }
-                if (!(dbg & 1)) *(u32x4_t*)(out + off) = pack16_stored<T>(v);
+                *(u32x4_t*)(out + off) = pack16_stored<T>(v);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2_t v2 = {v[e], v[e + 1]};
@@ -562,17 +530,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
         if (++nbk == nb) { nbk = 0; ++nt; }
         return desc(nt < ntiles ? nt : ntiles - 1, nbk);     // past the end: a valid but unused descriptor
     };
-#ifdef ADF_PP_STAMP
-    auto pstamp = [&](int id) __attribute__((always_inline)) {
-        if (bidx == 0 && a.nseg == 1 && a.n_pad <= 128) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (lane == 0) ((unsigned long long*)(smem + kPpOffBias + 512))[wave * 24 + id] = t;
-        }
-    };
-#else
-    auto pstamp = [&](int) __attribute__((always_inline)) {};
-#endif
-    pstamp(17);
     // bias vector and the first tile's affine table: their global loads go out first (one HBM round trip, ~3 us on a cold
     // line, that gates the block's first barrier), then the descriptors and the first DMAs, then the LDS stores
     float bias_v[(kPpMaxN + 511) / 512];
@@ -597,7 +554,6 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     PpBlk d1 = next_desc();
     if (GB > 1) (void)issue_a(d1, 1, -1);
     PpBlk d2 = next_desc();
-    pstamp(18);
 #pragma unroll
     for (int q = 0; q < (kPpMaxN + 511) / 512; ++q)
         if (tid + q * 512 < a.n_pad) ldsBias[tid + q * 512] = bias_v[q];
@@ -609,11 +565,8 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
             *(f32x4_t*)(ldsTab + tid * 16) = f32x4_t{A0, B0, A1, B1};
         }
     } else if (use_tab && tid * 2 < ctot0) *(f32x4_t*)(ldsTab + tid * 16) = tab_v;
-    pstamp(19);
     wait_dma(0);
-    pstamp(20);
     __syncthreads();
-    pstamp(21);
     {
         int b0, m0, n0;
         geom(0, b0, m0, n0);
@@ -628,33 +581,14 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_r[j];
     }
     transform(dc, 0, part_all);
-    pstamp(22);
     lds_barrier();
-    pstamp(23);
 
     int stA = 0, stW = 0;
     // the two waves of a SIMD run their own copy of the loop (EARLY decides where the prologue elements sit among the
     // MFMA gaps); both copies reach the same barriers
     auto main_loop = [&](auto earlyc) __attribute__((always_inline)) {
-#ifndef ADF_PP_SPLIT
     const bool EARLY = earlyc;
-#else
-    constexpr bool EARLY = decltype(earlyc)::value;
-#endif
     for (int g = 0; g < GB; ++g) {
-#ifdef ADF_PP_STAMP
-        // stamps go to the unused tail of the bias area (LDS) and are copied out when the kernel ends
-        const bool stamp_on = bidx == 0 && g == nb + 1 && a.nseg == 1 && a.n_pad <= 128;
-        auto stamp = [&](int id) __attribute__((always_inline)) {
-            if (stamp_on) {
-                const unsigned long long t = __builtin_amdgcn_s_memtime();
-                if (lane == 0) ((unsigned long long*)(smem + kPpOffBias + 512))[wave * 24 + id] = t;
-            }
-        };
-#else
-        auto stamp = [&](int) __attribute__((always_inline)) {};
-#endif
-        stamp(0);
         const bool has1 = g + 1 < GB, has2 = g + 2 < GB;
         const int stA1 = stA == kPpAStages - 1 ? 0 : stA + 1;
         const int stA2 = stA1 == kPpAStages - 1 ? 0 : stA1 + 1;
@@ -674,38 +608,24 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
                 if (slow && EARLY) transform(d1, stA1, partc);
                 __builtin_amdgcn_sched_barrier(0);
                 auto call = [&](auto ec) __attribute__((always_inline)) {
-#ifndef ADF_PP_GAPBRANCH
                     if (fuse) mfma_fused(tapc, partc, ec, stA, stW, d1, stA1, std::true_type{}, between);
                     else mfma_fused(tapc, partc, ec, stA, stW, d1, stA1, std::false_type{}, between);
-#else
-                    mfma_fused(tapc, partc, ec, stA, stW, d1, stA1, fuse, between);
-#endif
                 };
-#ifndef ADF_PP_SPLIT
                 if (EARLY) call(std::true_type{});
                 else call(std::false_type{});
-#else
-                call(earlyc);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (slow && !EARLY) transform(d1, stA1, partc);
             };
-            stamp(1);
             sub(tap0, part0, [&](int ks) __attribute__((always_inline)) {
                 if (ks == 0) issue_w(dc.w + slab, stW ^ 1);
                 else if (has2) nA += issue_a(d2, stA2, ks - 1);
             });
-            stamp(3);
             wait_dma(nA);
-            stamp(4);
             stW ^= 1;
             lds_barrier();
-            stamp(5);
             // ---- tap 1
             sub(tap1, part1, [&](int ks) __attribute__((always_inline)) { if (ks == 0) issue_w(dc.w + slab + slab, stW ^ 1); });
-            stamp(8);
             wait_dma(0);
-            stamp(9);
             if (gn_in && (g % nb) == 0 && dc.tseq + 1 < ntiles) {            // first block of a tile: the next tile's sample
                 int bc, bn, m0_, n0_;
                 geom(dc.tseq, bc, m0_, n0_);
@@ -714,16 +634,12 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
             }
             stW ^= 1;
             lds_barrier();
-            stamp(10);
             // ---- tap 2: next slab = tap 0 of block g+1; zero padding of block g+1 once its last part is in place
             sub(tap2, part2, [&](int ks) __attribute__((always_inline)) { if (ks == 0 && has1) issue_w(d1.w, stW ^ 1); });
             if (has1 && !slow) transform(d1, stA1, part_tail);
-            stamp(13);
             wait_dma(0);
-            stamp(14);
             stW ^= 1;
             lds_barrier();
-            stamp(15);
         } else {
             // ---- single-tap block: everything of the next block is needed after this one sub-step
             int nA = 0;
@@ -737,23 +653,13 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
             lds_barrier();
         }
         dc = d1; d1 = d2;
-        if (!(dbg & 1024)) d2 = next_desc();
+        d2 = next_desc();
         stA = stA1;
-        stamp(16);
     }
     wait_dma(0);
     epilogue(ntiles - 1, 0);
     };
-#ifndef ADF_PP_SPLIT
     main_loop(early);
-#else
-    if (early) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-#endif
-#ifdef ADF_PP_STAMP
-    if (bidx == 0 && a.nseg == 1 && a.n_pad <= 128 && lane < 24)
-        adf_pp_stamps[wave * 32 + lane] = ((const unsigned long long*)(smem + kPpOffBias + 512))[wave * 24 + lane];
-#endif
 }
 
 }  // namespace adf

@@ -207,18 +207,54 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         rb_dma2(wsrc, wlane, wlane + 64u * (unsigned)kRowBytes, l, l + 8192u);
     };
 
-    // ---- GroupNorm table of one sample: two channels per thread (the arithmetic of gn_finalize_kernel) -------------
+    // ---- GroupNorm table of one sample: ONE channel per thread, every load issued before the first use -------------------
+    // (the arithmetic of gn_finalize_kernel / gn_affine<true>.  Per-wave stamps showed the two-channels-per-thread form on waves
+    //  0-1 -- four dependent memory round trips -- holding the block's first barrier until 12.6 K cycles after entry, three times
+    //  the landing time of the first DMAs.)
+    struct GnLoaded { double s0, q0, s1, q1; float gamma, beta, fs, fh; };
+    auto gn_load = [&](int b, int c) __attribute__((always_inline)) -> GnLoaded {
+        const GnFinalizeArgs& g = a.gn;
+        const int ctot = g.c0 + g.c1;
+        const int gs = ctot / g.G;                         // channels per (coarse) group
+        const int cstart = (c / gs) * gs;
+        const bool from1 = cstart >= g.c0;
+        const double* st = from1 ? g.stats1 : g.stats0;
+        const int csrc = from1 ? g.c1 : g.c0;
+        const int lc = from1 ? cstart - g.c0 : cstart;
+        const int fg = csrc / g.G;                         // channels per stored (fine) group: gs = fg (one source) or 2 fg (two equal sources)
+        const int g0 = lc / fg;
+        const bool two = gs > fg;
+        const double* p0 = st + ((size_t)b * g.G + g0) * 2;
+        const double* p1 = two ? p0 + 2 : p0;
+        GnLoaded r;
+        r.s0 = p0[0]; r.q0 = p0[1]; r.s1 = p1[0]; r.q1 = p1[1];
+        if (!two) { r.s1 = 0.0; r.q1 = 0.0; }
+        r.gamma = g.gamma[c]; r.beta = g.beta[c];
+        r.fs = 1.0f; r.fh = 0.0f;
+        if (g.film) {
+            r.fs = g.film[(size_t)b * g.film_bstride + c] + 1.0f;
+            r.fh = g.film[(size_t)b * g.film_bstride + ctot + c];
+            if (g.film2) {
+                r.fs += g.film2[(size_t)b * g.film2_bstride + c];
+                r.fh += g.film2[(size_t)b * g.film2_bstride + ctot + c];
+            }
+        }
+        return r;
+    };
+    auto gn_store = [&](int c, const GnLoaded& v, int slot) __attribute__((always_inline)) {
+        GnRaw r;
+        r.sum = v.s0 + v.s1; r.sq = v.q0 + v.q1;
+        r.gamma = v.gamma; r.beta = v.beta; r.fs = v.fs; r.fh = v.fh;
+        float A, Bc;
+        gn_affine_finish<true>(a.gn, c, r, A, Bc);
+        *(f32x2_t*)(ldsTab + slot * kPpTab + c * 8) = f32x2_t{A, Bc};
+    };
     auto fill_table = [&](int b, int slot) __attribute__((always_inline)) {
         // (the thread index goes through an empty asm: otherwise the per-lane 64-bit addresses of gamma / beta / FiLM / statistics
         //  are computed at kernel entry and kept -- spilled -- across the whole tile loop)
-        int t2 = tid * 2;
-        asm volatile("" : "+v"(t2));
-        if (t2 < ctot0) {
-            float A0, B0, A1, B1;
-            gn_affine<true>(a.gn, b, t2, A0, B0);
-            gn_affine<true>(a.gn, b, t2 + 1, A1, B1);
-            *(f32x4_t*)(ldsTab + slot * kPpTab + t2 * 8) = f32x4_t{A0, B0, A1, B1};
-        }
+        int t1 = tid;
+        asm volatile("" : "+v"(t1));
+        if (t1 < ctot0) gn_store(t1, gn_load(b, t1), slot);
     };
 
     // ---- prologue arithmetic on one 8-byte half (4 elements) of a chunk this lane fetched ----------------------------
@@ -520,14 +556,25 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         }
     };
 
+#ifdef ADF_RB_STAMP
+    auto kstamp = [&](int id) __attribute__((always_inline)) {
+        if (bidx == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) ((unsigned long long*)(smem + kPpOffBias + 1024))[wave * 16 + id] = t;
+        }
+    };
+#else
+    auto kstamp = [&](int) __attribute__((always_inline)) {};
+#endif
+    kstamp(11);
     // ---- start-up: bias vector, the first sample's table, first DMAs -------------------------------------------------
     float bias_v = 0.f;
     if (tid < a.n) {
         if (a.bias0) bias_v += a.bias0[tid];
         if (a.bias1) bias_v += a.bias1[tid];
     }
-    GnRaw gr0 = {}, gr1 = {};
-    if (!RAW && tid * 2 < ctot0) { gr0 = gn_affine_load(a.gn, b_first, tid * 2); gr1 = gn_affine_load(a.gn, b_first, tid * 2 + 1); }
+    GnLoaded gl = {};
+    if (!RAW && tid < ctot0) gl = gn_load(b_first, tid);
     Blk dc = make_desc();
     advance();
     issue_a01(dc, 0u); issue_a23(dc, 0u); issue_halo(dc, 0u);
@@ -538,14 +585,11 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     Blk d2 = make_desc();
     advance();
     if (tid < a.n) ldsBias[tid] = bias_v;
-    if (!RAW && tid * 2 < ctot0) {
-        float A0, B0, A1, B1;
-        gn_affine_finish<true>(a.gn, tid * 2, gr0, A0, B0);
-        gn_affine_finish<true>(a.gn, tid * 2 + 1, gr1, A1, B1);
-        *(f32x4_t*)(ldsTab + tid * 16) = f32x4_t{A0, B0, A1, B1};
-    }
+    if (!RAW && tid < ctot0) gn_store(tid, gl, 0);
+    kstamp(12);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    kstamp(13);
     Tile cur_tile = tile_of(0);
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
@@ -561,6 +605,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     }
     if (RAW) zero_fill(dc, 0u); else transform_all(dc, 0u);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    kstamp(14);
 
     // ---- pipeline -----------------------------------------------------------------------------------------------------
     // K blocks are numbered over the whole thread block; block g lives in A stage g % 3 (fetched while block g-2 computes,
@@ -675,7 +720,12 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     for (; tseq < ntiles; ++tseq) {
         cur_tile = tile_of(tseq);
         // the previous tile's accumulators leave, this tile's start from its bias
-        if (tseq > 0) epilogue(tile_of(tseq - 1), cur_tile.n0);
+        if (tseq > 0) {
+#ifdef ADF_RB_STAMP
+            if (tseq == 1) kstamp(15);
+#endif
+            epilogue(tile_of(tseq - 1), cur_tile.n0);
+        }
         // blocks come in pairs (nb3 and nb1 are even): the weight stage parity is a compile-time constant
         for (kb = 0; kb < nb3; kb += 2) {
             block3(c0); rotate(); --remaining; prev_one = false;

@@ -27,7 +27,6 @@ struct RbFusedArgs {
     float skip_scale, eps;
     double* stats;                             // [B][8][2] statistics of the output, or nullptr
     int B;
-    unsigned long long* stamps;                // diagnostics (ADF_TR_STAMPS=1): s_memtime of workgroup 0 after every stage, or nullptr
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 rb_bf16x8_t;
@@ -75,10 +74,6 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         return;
     }
 
-    auto stamp = [&](int id) __attribute__((always_inline)) {
-        if (a.stamps && b == 0 && tid == 0) a.stamps[id] = __builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
     // ---- GEMM stage: acc[i] += sum over taps t and K steps: A[row i*32 + r + t + row0][channels] * W[tap t][columns n0 + r]^T.
     // A from LDS (pitch, halo-shifted rows), W fragments from the fragment-major global copy in packed K order [chunk][tap] --------
     // The ring of weight fragments lives across the stages: `prefetch(W)` issues the first 16 K steps of a GEMM (16 KB per wave)
@@ -176,7 +171,6 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         }
     }
     __syncthreads();
-    stamp(1);
 
     // ---- R1: the residual into the output accumulators: 1x1 conv of the raw concat, or the input itself -------------------
     rb_f32x16_t accy[MT];
@@ -197,8 +191,6 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
                 accy[i][e] = row < NTOK ? bf16_to_f32(xb[(size_t)row * 256 + col].v) : 0.f;
             }
     }
-
-    stamp(2);
     // ---- R2: silu(GroupNorm1(input)) -> bufX rows 1 .. NTOK, zero halo rows ---------------------------------------------
     for (int idx = tid; idx < NTOK * CPR; idx += 512) {
         const int row = idx / CPR, cc = idx % CPR;
@@ -217,7 +209,6 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         *(u32x4_t*)(bufH + row * PH + cc * 16) = u32x4_t{0u, 0u, 0u, 0u};
     }
     __syncthreads();
-    stamp(3);
 
     // ---- R3: h1 = conv1 + bias; GroupNorm 2 over the sample (this wave's 32 columns are one group); silu(FiLM(GN2(h1))) -> bufH
     {
@@ -228,7 +219,6 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
             for (int e = 0; e < 16; ++e) acch[i][e] = 0.f;
         gemm(three, chin, bufX, PX, 0, a.w1, wave * 32, acch);
         prefetch(a.w2, wave * 32);
-        stamp(4);
         const float bias = prm[col];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -263,11 +253,9 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
             }
     }
     __syncthreads();
-    stamp(5);
 
     // ---- R4: y = conv2 + residual + biases -> statistics, bf16 rows -> bufX -> global ------------------------------------
     gemm(three, chco, bufH, PH, 0, a.w2, wave * 32, accy);
-    stamp(6);
     {
         const float bias = prm[256 + col];
         float s1 = 0.f, s2 = 0.f;
@@ -299,7 +287,6 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
             *(u32x4_t*)(ob + (size_t)row * CO + cc * 8) = *(const u32x4_t*)(bufX + (row + 1) * PX + cc * 16);
         }
     }
-    stamp(7);
 }
 
 inline size_t resblock_small_lds(int ntok, int cin) {

@@ -36,7 +36,6 @@ struct TrFusedArgs {
     bf16_t* qkv_out;      // MODE 1: q|k|v [rows][768]
     int tiles_per_sample; // MODE 1 / 2: workgroups (64-row tiles) per sample
     int B;                // samples (MODE 0) or row tiles = worker workgroups; the grid may carry helper workgroups beyond (see the kernel)
-    unsigned long long* stamps;   // diagnostics (ADF_TR_STAMPS=1): s_memtime of workgroup 0 after every stage, or nullptr
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 tr_bf16x8_t;
@@ -64,9 +63,6 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x;
     const bf16_t* const xb = a.x + (size_t)(b < a.B ? b : 0) * NTOK * C;
-    auto stamp = [&](int id) __attribute__((always_inline)) {
-        if (a.stamps && b == 0 && tid == 0) a.stamps[id] = __builtin_amdgcn_s_memtime();
-    };
     // ---- L2 warm-up by helper workgroups.  The block's 1 MB of weights is cold in L2 when it starts and a CU draws only ~11
     // B/clk of L2 misses however much it keeps in flight.  The grid therefore carries 3 helper workgroups per sample
     // (b >= a.B; they occupy the CUs this launch would leave idle): workgroups b, b + 8, b + 16 ... usually share an XCD
@@ -98,7 +94,6 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
-    stamp(0);
 
     // ---- row LayerNorm (the arithmetic of ln_rows_kernel: two-pass variance on registers), TPR threads per row ----
     constexpr int TPR = 512 / NTOK;                     // 8 (64 tokens) or 32 (16 tokens)
@@ -220,8 +215,6 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     // ---- S0: LayerNorm of the input rows -> bufA ------------------------------------------------------------------
     layer_norm(std::integral_constant<int, C>{}, (const char*)xb, C * 2, true, bufA, PA, prm, prm + 256, true);
     __syncthreads();
-
-    stamp(1);
     // ---- S1: q | k | v = xn W^T (768 columns, 96 per wave) -> bufQ -------------------------------------------------
     {
         tr_f32x16_t acc[MT][3];
@@ -254,8 +247,6 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
         }
         __syncthreads();
     }
-
-    stamp(2);
     if constexpr (MODE == 0) {
     // ---- S2: attention, wave = head; output rows -> bufA ---------------------------------------------------------
     {
@@ -337,8 +328,6 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     }
     __syncthreads();
     }
-
-    stamp(3);
     // ---- S3: x1 = att Wp^T + x (32 columns per wave); kept (rounded to bf16, as the unfused path stores it) for S7 -----
     float x1r[MT][16];
     {
@@ -356,19 +345,14 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
             }
     }
     __syncthreads();                                    // every wave is done reading att
-    stamp(4);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) *(unsigned short*)(bufA + row_of(i, e) * PA + (wave * 32 + r) * 2) = f32_to_bf16_hw(x1r[i][e]);
     __syncthreads();
-
-    stamp(5);
     // ---- S4: n1 = LayerNorm1d(x1), in place ----------------------------------------------------------------------
     layer_norm(std::integral_constant<int, C>{}, bufA, PA, false, bufA, PA, prm + 512, nullptr, false);
     __syncthreads();
-
-    stamp(6);
     // ---- S5: f1 = gelu(n1 W1^T) (512 columns, 64 per wave) -> bufQ as [MR][512] -----------------------------------
     {
         tr_f32x16_t acc[MT][2];
@@ -384,13 +368,9 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
                     *(unsigned short*)(bufQ + row_of(i, e) * PF + (wave * 64 + j * 32 + r) * 2) = f32_to_bf16_hw(gelu_fast(acc[i][j][e]));
     }
     __syncthreads();
-
-    stamp(7);
     // ---- S6: n2 = LayerNorm1d(f1), in place ----------------------------------------------------------------------
     layer_norm(std::integral_constant<int, MID>{}, bufQ, PF, false, bufQ, PF, prm + 768, nullptr, false);
     __syncthreads();
-
-    stamp(8);
     // ---- S7: x2 = n2 W2^T + x1 -> bufA -> global; GroupNorm statistics of x2 -------------------------------------
     {
         tr_f32x16_t acc[MT][1];
@@ -422,7 +402,6 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
         }
     }
     __syncthreads();
-    stamp(9);
     {
         bf16_t* const ob = a.out + (size_t)b * NTOK * C;
         for (int idx = tid; idx < NTOK * (C / 8); idx += 512) {
@@ -430,7 +409,6 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
             *(u32x4_t*)(ob + (size_t)row * C + cc * 8) = *(const u32x4_t*)(bufA + row * PA + cc * 16);
         }
     }
-    stamp(10);
 }
 
 inline const char* launch_transformer_small(const TrFusedArgs& a, int B, int ntok, hipStream_t s) {

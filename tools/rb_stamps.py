@@ -30,9 +30,13 @@ buf = (C.c_ulonglong * 128)()
 fn = lib.adf_debug_rb_stamps
 fn.restype = C.c_int
 print("copy rc", fn(buf))
-names = ["T0 start", "T0 mfma done", "T0 dma wait", "T0 barrier", "T1 mfma done", "T1 dma wait", "T1 barrier(+tab)", "T2 mfma done", "T2 halo/zero",
-         "T2 dma wait", "T2 barrier"]
+names = ["block start", "u0 mfma done", "u0 dma wait", "u0 barrier", "u1 mfma done", "u1 dma wait", "u1 barrier", "u2 mfma done", "u2 dma wait",
+         "u2 barrier"]
 t0 = min(buf[w * 16] for w in range(8))
 print("%-18s" % "point" + "".join("%8s" % ("w%d" % w) for w in range(8)))
 for i, nm in enumerate(names):
     print("%-18s" % nm + "".join("%8d" % (buf[w * 16 + i] - t0) for w in range(8)))
+e0 = min(buf[w * 16 + 11] for w in range(8))
+print("kernel timeline (cycles from the first wave's entry)")
+for i, nm in ((11, "entry"), (12, "first DMAs issued"), (13, "landed + sync"), (14, "first block ready"), (15, "tile 0 done (epilogue)"), (0, "stamped K block")):
+    print("%-24s" % nm + "".join("%8d" % (buf[w * 16 + i] - e0) for w in range(8)))
