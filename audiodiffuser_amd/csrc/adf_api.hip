@@ -69,6 +69,11 @@ struct Plan {
     std::vector<TapRec> taps;
     std::vector<RbRec> rbs;
     float *temb = nullptr, *film = nullptr, *coef = nullptr;
+    // per sampler run: (c_in, c_noise, c_skip, c_out), sigma embedding and the FiLM projections of EVERY denoiser evaluation of
+    // the run, computed by three launches at the head of the loop (sigma is uniform over the batch and the whole schedule is
+    // known on the host) instead of three launches per evaluation
+    float *coef_all = nullptr, *temb_all = nullptr, *film_all = nullptr;
+    int pre_cap = 0;
     // sampler state (fp32 [B][C][L] each)
     float* sb[10] = {nullptr};
     float* noise_stage = nullptr; float* out_stage = nullptr; float* inj_stage = nullptr; size_t inj_cap = 0;
@@ -359,6 +364,7 @@ struct Walker {
     bool bad = false;
     const float* film2 = nullptr;       // class part of the FiLM projections for this pass (FwdIO::film2)
     int film2_bstride = 0;
+    const float* film = nullptr;        // time part: Plan::film, or the evaluation's row of Plan::film_all
 
     void check(const char* e) { if (e && !bad) { bad = true; h->err = e; } }
     void* alloc(size_t bytes) {
@@ -468,7 +474,7 @@ struct Walker {
             fa.x = (const bf16_t*)x.p; fa.skip = skip ? (const bf16_t*)skip->p : nullptr; fa.out = (bf16_t*)y.p;
             fa.gn1 = f1;
             fa.gamma2 = r.g2w; fa.beta2 = r.g2b;
-            fa.film = p->film + r.film_off; fa.film_bstride = nb == 1 ? 0 : h->film_total;
+            fa.film = film + r.film_off; fa.film_bstride = nb == 1 ? 0 : h->film_total;
             if (film2) { fa.film2 = film2 + r.film_off; fa.film2_bstride = film2_bstride; }
             fa.w1 = r.c1.wfrag; fa.w2 = r.c2.wfrag; fa.wr = r.has_res ? r.cr.wfrag : nullptr;
             fa.b1 = r.c1.bias; fa.b2 = r.c2.bias; fa.br = r.has_res ? r.cr.bias : nullptr;
@@ -500,7 +506,7 @@ struct Walker {
         memset(&f2, 0, sizeof(f2));
         f2.stats0 = sh; f2.c0 = r.cout; f2.L = x.L; f2.G = G; f2.B = B; f2.scale1 = 1.f; f2.eps = 1e-5f;
         f2.gamma = r.g2w; f2.beta = r.g2b;
-        f2.film = p->film + r.film_off; f2.film_bstride = nb == 1 ? 0 : h->film_total; f2.ab = ab2;
+        f2.film = film + r.film_off; f2.film_bstride = nb == 1 ? 0 : h->film_total; f2.ab = ab2;
         if (film2) { f2.film2 = film2 + r.film_off; f2.film2_bstride = film2_bstride; }
         Act y = new_act(r.cout, x.L);
         GemmArgs g2 = gemm_base(y, x.L, x.L, r.c2);
@@ -600,12 +606,14 @@ struct FwdIO {
     const float* t = nullptr; int t_stride = 0; int nb = 0;
     const float* coef = nullptr; int coef_bstride = 0; int mode = 0; const float* x_noisy = nullptr;
     const float* film2 = nullptr; int film2_bstride = 0;   // class part of the FiLM projections (rows of adf_handle::cond_film)
+    const float* film_pre = nullptr;                       // this evaluation's row of Plan::film_all: sigma embedding + FiLM already computed
 };
 
 int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     const adf_net_config& c = h->cfg;
     Walker W{h, p, s};
     W.film2 = io.film2; W.film2_bstride = io.film2_bstride;
+    W.film = io.film_pre ? io.film_pre : p->film;
     p->arena_off = 0; p->stats_off = 0;
     p->taps.clear(); p->rbs.clear();
     const int B = p->B, L = p->L, n = c.num_layers;
@@ -614,8 +622,8 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     if (!p->dry && p->stats_bytes) {
         if (hipMemsetAsync(p->stats, 0, p->stats_bytes, s) != hipSuccess) return fail(h, "hipMemsetAsync(stats) failed");
     }
-    // sigma embedding + every resblock's FiLM projection
-    if (W.live()) {
+    // sigma embedding + every resblock's FiLM projection (unless the sampler computed them for the whole run already)
+    if (W.live() && !io.film_pre) {
         TimeEmbedArgs te;
         te.t = io.t; te.t_stride = io.t_stride; te.nb = io.nb; te.ch = c.channels;
         te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb;
@@ -789,9 +797,18 @@ struct SamplerCtx {
     adf_handle* h; Plan* p; const adf_sampler_desc* d; const float* sig; int nsig; hipStream_t s; long long n;
     int nfe = 0;
     bool count_only = false;
+    std::vector<float>* collect = nullptr;     // count_only pass: the sigma of every evaluation, in order
+    bool precomputed = false;                  // real pass: evaluation k reads row k of Plan::coef_all / film_all
     int den(const float* x, float sigma, float* out) {
-        ++nfe;
-        if (count_only) return 0;
+        const int k = nfe++;
+        if (count_only) { if (collect) collect->push_back(sigma); return 0; }
+        if (precomputed) {
+            FwdIO io;
+            io.x = x; io.t = p->coef_all + (size_t)k * 4 + 1; io.t_stride = 4; io.nb = 1;
+            io.coef = p->coef_all + (size_t)k * 4; io.coef_bstride = 0; io.x_noisy = x;
+            io.film_pre = p->film_all + (size_t)k * h->film_total;
+            return denoise_io(h, p, io, out, s);
+        }
         return denoise_scalar(h, p, x, sigma, d->sigma_data, out, s);
     }
     int ck(const char* e) { if (e) { h->err = e; return 1; } return 0; }
@@ -1416,9 +1433,52 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     } else if (desc->kind == ADF_SAMPLER_ADPM2) {
         return fail(h, "ADPM2Sampler needs injected_noise (one pre-drawn randn_like tensor per step)");
     }
+    // the sigma of every denoiser evaluation of this run (host logic only), then the buffers of the per-run table -- sized
+    // before any capture starts
+    std::vector<float> eval_sigmas;
+    {
+        SamplerCtx cc{nullptr, nullptr, desc, sigmas_host, n_sigmas, nullptr, 0};
+        cc.count_only = true;
+        cc.collect = &eval_sigmas;
+        float* r0 = nullptr;
+        if (run_sampler(cc, &r0)) eval_sigmas.clear();     // a schedule the sampler rejects: the real pass below reports why
+    }
+    const int n_eval = (int)eval_sigmas.size();
+    if (n_eval > p->pre_cap) {
+        if (p->pre_cap) {
+            (void)hipDeviceSynchronize();
+            drop_graphs(p);
+            dfree(h, p->coef_all, (size_t)p->pre_cap * 4 * 4, p);
+            dfree(h, p->temb_all, (size_t)p->pre_cap * 4 * h->cfg.channels * 4, p);
+            dfree(h, p->film_all, (size_t)p->pre_cap * h->film_total * 4, p);
+            p->pre_cap = 0;
+        }
+        p->coef_all = (float*)dalloc(h, (size_t)n_eval * 4 * 4, p);
+        p->temb_all = (float*)dalloc(h, (size_t)n_eval * 4 * h->cfg.channels * 4, p);
+        p->film_all = (float*)dalloc(h, (size_t)n_eval * h->film_total * 4, p);
+        if (!p->coef_all || !p->temb_all || !p->film_all) return fail(h, "device allocation failed for the per-run sigma table");
+        p->pre_cap = n_eval;
+    }
+    // head of the loop (inside the captured graph when there is one): coefficients, sigma embeddings and FiLM projections of all
+    // evaluations in three launches
+    auto sigma_table = [&](hipStream_t st) -> int {
+        if (n_eval == 0) return 0;
+        const adf_net_config& cfg = h->cfg;
+        if (const char* e = launch_edm_coef_list(eval_sigmas.data(), n_eval, desc->sigma_data, p->coef_all, st)) return fail(h, e);
+        TimeEmbedArgs te;
+        te.t = p->coef_all + 1; te.t_stride = 4; te.nb = n_eval; te.ch = cfg.channels;
+        te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb_all;
+        if (const char* e = launch_time_embed(te, st)) return fail(h, e);
+        if (const char* e = launch_film(p->temb_all, 4 * cfg.channels, h->film_w, 4 * cfg.channels + h->cdim, 0, h->film_b, p->film_all, n_eval,
+                                        h->film_total, st))
+            return fail(h, e);
+        return 0;
+    };
     SamplerCtx c{h, p, desc, sigmas_host, n_sigmas, s, n};
+    c.precomputed = n_eval > 0;
     float* result = nullptr;
     if (!desc->use_graph) {
+        if (sigma_table(s)) return 1;
         if (run_sampler(c, &result)) return 1;
         if (hipMemcpyAsync(out, result, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
         return 0;
@@ -1447,7 +1507,8 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     if (it == p->graphs.end()) {
         const hipError_t be = hipStreamBeginCapture(gs, hipStreamCaptureModeRelaxed);
         if (be != hipSuccess) return fail(h, std::string("hipStreamBeginCapture failed: ") + hipGetErrorString(be));
-        int rc = run_sampler(c, &result);
+        int rc = sigma_table(gs);
+        if (!rc) rc = run_sampler(c, &result);
         if (!rc && hipMemcpyAsync(p->out_stage, result, (size_t)n * 4, hipMemcpyDeviceToDevice, gs) != hipSuccess) { rc = 1; h->err = "result copy failed (capture)"; }
         hipGraph_t graph = nullptr;
         const hipError_t ee = hipStreamEndCapture(gs, &graph);

@@ -42,6 +42,8 @@ const char* launch_to_out(const void* h, const float* w, float* out, int bf16, i
 // coef[b][4] = (c_in, c_noise, c_skip, c_out) from sigma (EluDiffusion.get_scale_weights).
 const char* launch_edm_coef(const float* sigmas_dev, float sigma_scalar, int nb, float sigma_data, float* coef,
                             hipStream_t s);
+// coef[i] for a host-side list of sigmas (values passed in the kernel arguments: usable inside a stream capture)
+const char* launch_edm_coef_list(const float* sigmas_host, int n, float sigma_data, float* coef, hipStream_t s);
 
 // Time embedding MLP: t[b] -> temb[b][4*ch];  t read as t[b*t_stride].
 struct TimeEmbedArgs {

@@ -842,6 +842,30 @@ __global__ void edm_coef_kernel(const float* __restrict__ sigmas, float sigma_sc
     coef[b * 4 + 3] = s * sd * (1.0f / sqrtf(d2 + s2));
 }
 
+// The same for a list of sigmas known on the host (the sigma of every denoiser evaluation of a sampler run): the values ride in
+// the kernel arguments (no host -> device copy inside a captured graph), 256 per launch.
+struct SigmaPack { float s[256]; };
+__global__ void edm_coef_pack_kernel(const SigmaPack pk, int n, float sd, float* __restrict__ coef) {
+    const int b = threadIdx.x;
+    if (b >= n) return;
+    const float s = pk.s[b];
+    const float s2 = s * s, d2 = sd * sd;
+    coef[b * 4 + 0] = 1.0f / sqrtf(s2 + d2);
+    coef[b * 4 + 1] = logf(s) * 0.25f;
+    coef[b * 4 + 2] = d2 / (s2 + d2);
+    coef[b * 4 + 3] = s * sd * (1.0f / sqrtf(d2 + s2));
+}
+const char* launch_edm_coef_list(const float* sigmas_host, int n, float sigma_data, float* coef, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        SigmaPack pk;
+        const int m = n - i0 < 256 ? n - i0 : 256;
+        for (int i = 0; i < 256; ++i) pk.s[i] = i < m ? sigmas_host[i0 + i] : 1.0f;
+        hipLaunchKernelGGL(edm_coef_pack_kernel, dim3(1), dim3(256), 0, s, pk, m, sigma_data, coef + (size_t)i0 * 4);
+        if (hipGetLastError() != hipSuccess) return "edm_coef_list: launch failed";
+    }
+    return nullptr;
+}
+
 const char* launch_edm_coef(const float* sigmas_dev, float sigma_scalar, int nb, float sigma_data, float* coef, hipStream_t s) {
     hipLaunchKernelGGL(edm_coef_kernel, dim3(ceil_div(nb, 64)), dim3(64), 0, s, sigmas_dev, sigma_scalar, nb, sigma_data, coef);
     return ADF_LAUNCH_CHECK("edm_coef");
