@@ -47,9 +47,16 @@ class AdfSamplerDesc(C.Structure):
     ]
 
 
+class AdfWaveNetConfig(C.Structure):
+    """``adf_wavenet_config`` of include/audiodiffuser_amd.h."""
+    _fields_ = [("residual_channels", C.c_int32), ("residual_layers", C.c_int32), ("dilation_cycle", C.c_int32),
+                ("dim_in", C.c_int32), ("dim_mid", C.c_int32), ("dim_out", C.c_int32), ("dtype", C.c_int32)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "adf_create": (C.c_int, [C.POINTER(AdfNetConfig), C.POINTER(C.c_void_p)]),
+    "adf_wavenet_create": (C.c_int, [C.POINTER(AdfWaveNetConfig), C.POINTER(C.c_void_p)]),
     "adf_destroy": (None, [C.c_void_p]),
     "adf_last_error": (C.c_char_p, [C.c_void_p]),
     "adf_num_weights": (C.c_int, [C.c_void_p]),
@@ -117,6 +124,14 @@ def make_config(cfg: UNet1dConfig, dtype: int, flags: int = 0) -> AdfNetConfig:
     c.use_attention_bottleneck = 1 if cfg.use_attention_bottleneck else 0
     c.dtype, c.flags = dtype, flags
     c.num_classes = int(cfg.num_classes) if cfg.class_cond else 0
+    return c
+
+
+def make_wavenet_config(cfg, dtype: int) -> AdfWaveNetConfig:
+    c = AdfWaveNetConfig()
+    c.residual_channels, c.residual_layers, c.dilation_cycle = cfg.residual_channels, cfg.residual_layers, cfg.dilation_cycle
+    c.dim_in, c.dim_mid, c.dim_out = cfg.dim_in, cfg.dim_mid, cfg.dim_out
+    c.dtype = dtype
     return c
 
 

@@ -111,3 +111,37 @@ def config_tiny_cc() -> UNet1dConfig:
 
 
 PRESETS = {"c1": config_c1, "c2": config_c2, "c3": config_c3, "tiny": config_tiny, "tiny_cc": config_tiny_cc}
+
+
+@dataclass
+class WaveNetConfig:
+    """Constructor arguments of the reference ``WaveNetNoise`` (src/models/backbones/wavenet.py:154-157), same names and
+    defaults.  The embedding widths (128 -> 512 -> 512) are the defaults of ``ResidualGroup`` (:120) and the literal 512 of
+    ``ResidualBlock`` (:103)."""
+    residual_channels: int = 256
+    residual_layers: int = 36
+    dilation_cycle: int = 12
+    dim_in: int = 128
+    dim_mid: int = 512
+    dim_out: int = 512
+    # what the shared sampler / denoise host code reads from a network config
+    in_channels: int = 1
+    out_channels: int = 1
+    class_cond: bool = False
+
+    def to_kwargs(self) -> dict:
+        return dict(residual_channels=self.residual_channels, residual_layers=self.residual_layers,
+                    dilation_cycle=self.dilation_cycle)
+
+    def dilation(self, n: int) -> int:
+        """wavenet.py:131-134"""
+        return 2 ** (n % self.dilation_cycle)
+
+
+def config_c5() -> WaveNetConfig:
+    """BASELINE configs[4]: the reference's default WaveNetNoise (36 layers, 256 channels, dilation cycle 12)."""
+    return WaveNetConfig()
+
+
+def config_c5_small() -> WaveNetConfig:
+    return WaveNetConfig(residual_channels=32, residual_layers=6, dilation_cycle=3)

@@ -10,6 +10,7 @@
 #include "../../include/audiodiffuser_amd.h"
 #include "adf_gemm.h"
 #include "adf_kernels.h"
+#include "adf_wavenet.h"
 #include "adf_transformer.h"
 #include "adf_resblock_small.h"
 
@@ -58,7 +59,23 @@ struct Slot {
 };
 
 struct Act { void* p = nullptr; int C = 0, L = 0; double* stats = nullptr; };
-struct TapRec { std::string name; void* p; int C, L; };
+struct TapRec { std::string name; void* p; int C, L; int f32 = 0; float scale = 1.0f; };   // f32: an fp32 buffer whatever the storage mode
+
+// WaveNetNoise (wavenet.py:153-180): a weight-normed conv keeps the state-dict tensors (bias, 0-dim g, v) in fp32 and a packed
+// GEMM operand of the effective weight v * g / ||v||, rebuilt when a tensor was (re)loaded
+struct WnConv {
+    float *bias = nullptr, *g = nullptr, *v = nullptr;
+    void* packed = nullptr;
+    int cout = 0, cin = 0, K = 0;
+};
+struct WnW {
+    adf_wavenet_config cfg;
+    WnConv in, sp;
+    std::vector<WnConv> dil, outp;
+    float *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr, *out_w = nullptr, *out_b = nullptr;
+    double* sumsq = nullptr;             // scratch of the norm reduction
+    bool packed = false;
+};
 struct RbRec { std::string name; GemmArgs g1, g2; int cin, cout, L; };
 
 struct Plan {
@@ -122,6 +139,7 @@ struct adf_handle {
     std::vector<UpW> ups;
     std::map<std::pair<int, int>, Plan*> plans;
     Plan* last_plan = nullptr;
+    WnW* wn = nullptr;                  // non-null: the handle is a WaveNetNoise (adf_wavenet_create), not a UNet1dBase
     // graphs are captured and replayed on a library-owned stream (the caller's stream may be the legacy
     // default stream, which cannot be captured); it is fenced against the caller's stream with events
     hipStream_t gstream = nullptr;
@@ -609,7 +627,10 @@ struct FwdIO {
     const float* film_pre = nullptr;                       // this evaluation's row of Plan::film_all: sigma embedding + FiLM already computed
 };
 
+int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
+
 int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
+    if (h->wn) return wn_forward(h, p, io, s);
     const adf_net_config& c = h->cfg;
     Walker W{h, p, s};
     W.film2 = io.film2; W.film2_bstride = io.film2_bstride;
@@ -690,12 +711,15 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     return W.bad ? 1 : 0;
 }
 
+int wn_pack_weights(adf_handle* h, hipStream_t s);
+
 int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
     const adf_net_config& c = h->cfg;
     int total = c.stride;
     for (int i = 0; i < c.num_layers; ++i) total *= c.factors[i];
     if (B < 1 || L < 1 || L % total) return fail(h, "length must be a positive multiple of the total down-sampling factor");
     if (adf_weights_missing(h)) return fail(h, "weights are not fully loaded");
+    if (h->wn && !h->wn->packed && wn_pack_weights(h, s)) return 1;
     auto it = h->plans.find({B, L});
     if (it != h->plans.end()) { *out = it->second; h->last_plan = it->second; it->second->last_use = ++h->use_clock; return 0; }
     Plan* p = new Plan();
@@ -740,6 +764,113 @@ int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
     p->last_use = ++h->use_clock;
     *out = p;
     return 0;
+}
+
+// ---- WaveNetNoise ----------------------------------------------------------------------------------------------------
+// Registration order = the reference module's state_dict order (wavenet.py:158-167; the custom WeightNorm re-registers
+// g and v after the bias, :37-42).
+int wn_build_weights(adf_handle* h) {
+    WnW& w = *h->wn;
+    const adf_wavenet_config& c = w.cfg;
+    Registrar R{h};
+    const int C = c.residual_channels;
+    auto conv = [&](const std::string& pre, WnConv& cv, int cout, int cin, int K, int layout) {
+        cv.cout = cout; cv.cin = cin; cv.K = K;
+        cv.bias = R.reg_f32(pre + ".conv.module.bias", cout);
+        cv.g = R.reg_f32(pre + ".conv.module.weight_g", 1);
+        cv.v = R.reg_f32(pre + ".conv.module.weight_v", (int64_t)cout * cin * K);
+        cv.packed = dalloc(h, (size_t)cout * cin * K * (layout == 1 ? 2 : 4));
+        if (!cv.packed) R.ok = false;
+    };
+    const int lay = h->bf16 ? 1 : 0;
+    conv("input_projection", w.in, C, 1, 1, 2);
+    w.fc1w = R.reg_f32("residual_layer.fc_t1.weight", (int64_t)c.dim_mid * c.dim_in);
+    w.fc1b = R.reg_f32("residual_layer.fc_t1.bias", c.dim_mid);
+    w.fc2w = R.reg_f32("residual_layer.fc_t2.weight", (int64_t)c.dim_out * c.dim_mid);
+    w.fc2b = R.reg_f32("residual_layer.fc_t2.bias", c.dim_out);
+    // the per-layer diffusion projections, concatenated: one launch_film call computes every layer's addend
+    h->film_total = c.residual_layers * C;
+    h->film_w = (float*)dalloc(h, (size_t)h->film_total * c.dim_out * 4);
+    h->film_b = (float*)dalloc(h, (size_t)h->film_total * 4);
+    if (!h->film_w || !h->film_b) R.ok = false;
+    w.dil.resize(c.residual_layers);
+    w.outp.resize(c.residual_layers);
+    for (int n = 0; n < c.residual_layers && R.ok; ++n) {
+        const std::string pre = "residual_layer.residual_blocks." + std::to_string(n);
+        conv(pre + ".dilated_conv", w.dil[n], 2 * C, C, 3, lay);
+        R.reg_f32(pre + ".diffusion_projection.weight", (int64_t)C * c.dim_out, h->film_w + (size_t)n * C * c.dim_out);
+        R.reg_f32(pre + ".diffusion_projection.bias", C, h->film_b + (size_t)n * C);
+        conv(pre + ".output_projection", w.outp[n], 2 * C, C, 1, lay);
+    }
+    conv("skip_projection", w.sp, C, C, 1, lay);
+    w.out_w = R.reg_f32("output_projection.conv.weight", C);
+    w.out_b = R.reg_f32("output_projection.conv.bias", 1);
+    w.sumsq = (double*)dalloc(h, 256);
+    if (!w.sumsq) R.ok = false;
+    return R.ok ? 0 : fail(h, "device allocation failed while building the weight registry");
+}
+
+// effective weights of every weight-normed conv, as GEMM operands (stream-ordered; the one sumsq scratch is reused in order)
+int wn_pack_weights(adf_handle* h, hipStream_t s) {
+    WnW& w = *h->wn;
+    const int lay = h->bf16 ? 1 : 0;
+    auto one = [&](const WnConv& cv, int layout) -> int {
+        if (const char* e = launch_wn_sumsq(cv.v, (long long)cv.cout * cv.cin * cv.K, w.sumsq, s)) return fail(h, e);
+        if (const char* e = launch_wn_pack(cv.v, cv.g, w.sumsq, cv.packed, layout, cv.cout, cv.cin, cv.K, s)) return fail(h, e);
+        return 0;
+    };
+    if (one(w.in, 2) || one(w.sp, lay)) return 1;
+    for (size_t n = 0; n < w.dil.size(); ++n)
+        if (one(w.dil[n], lay) || one(w.outp[n], lay)) return 1;
+    w.packed = true;
+    return 0;
+}
+
+// WaveNetNoise.forward (wavenet.py:169-180) for x [B][1][T]; io as for the U-Net (EDM scalars fused into the first and last kernel)
+int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
+    WnW& w = *h->wn;
+    const adf_wavenet_config& c = w.cfg;
+    Walker W{h, p, s};
+    p->arena_off = 0; p->stats_off = 0;
+    p->taps.clear(); p->rbs.clear();
+    const int B = p->B, T = p->L, C = c.residual_channels, NL = c.residual_layers;
+    const size_t act = (size_t)B * T * C * h->esz;
+    // every layer input stays resident when that is small (the parity taps y<n>); otherwise two buffers alternate
+    const bool keep = act * (size_t)NL <= ((size_t)256 << 20);
+    std::vector<void*> ys(keep ? NL : 2);
+    for (auto& q : ys) q = W.alloc(act);
+    float* const skip = (float*)W.alloc((size_t)B * T * C * 4);
+    if (p->dry) return 0;
+    const float* film = io.film_pre ? io.film_pre : p->film;
+    if (!io.film_pre) {
+        W.check(launch_wn_step_embed(io.t, io.t_stride, io.nb, w.fc1w, w.fc1b, w.fc2w, w.fc2b, c.dim_in, c.dim_mid, c.dim_out, p->temb, s));
+        W.check(launch_film(p->temb, c.dim_out, h->film_w, c.dim_out, 0, h->film_b, p->film, io.nb, h->film_total, s));
+    }
+    WnIO wio;
+    wio.B = B; wio.T = T; wio.C = C; wio.bf16 = h->bf16 ? 1 : 0;
+    wio.e = film; wio.e_bstride = io.nb > 1 ? h->film_total : 0;
+    W.check(launch_wn_input(wio, io.x, io.coef, io.coef_bstride, (const float*)w.in.packed, w.in.bias, ys[0], s));
+    for (int n = 0; n < NL && !W.bad; ++n) {
+        WnLayerArgs a;
+        a.y = ys[keep ? n : (n & 1)];
+        a.y_next = n + 1 < NL ? ys[keep ? n + 1 : ((n + 1) & 1)] : nullptr;
+        a.skip = skip;
+        a.w1 = w.dil[n].packed; a.b1 = w.dil[n].bias;
+        a.w2 = w.outp[n].packed; a.b2 = w.outp[n].bias;
+        a.n = n; a.first = n == 0 ? 1 : 0;
+        a.dilation = 1 << (n % c.dilation_cycle);
+        if (keep) p->taps.push_back({"y" + std::to_string(n), (void*)a.y, C, T});
+        W.check(launch_wn_layer(wio, a, s));
+    }
+    WnFinalArgs f;
+    f.skip = skip; f.skip_scale = (float)std::sqrt(1.0 / (double)NL);
+    f.w_sp = w.sp.packed; f.b_sp = w.sp.bias; f.w_out = w.out_w; f.b_out = w.out_b;
+    f.out = io.out; f.mode = io.mode; f.x_noisy = io.x_noisy; f.coef = io.coef; f.coef_bstride = io.coef_bstride;
+    TapRec sk{"skip", (void*)skip, C, T};
+    sk.f32 = 1; sk.scale = f.skip_scale;
+    p->taps.push_back(sk);
+    W.check(launch_wn_final(wio, f, s));
+    return W.bad ? 1 : 0;
 }
 
 // class part of the FiLM projections for one network pass: the per-sample rows, or the null row for every sample
@@ -1278,6 +1409,34 @@ int adf_create(const adf_net_config* cfg, adf_handle** out) {
     return 0;
 }
 
+int adf_wavenet_create(const adf_wavenet_config* cfg, adf_handle** out) {
+    if (!cfg || !out) { g_create_error = "adf_wavenet_create: null argument"; return 1; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "adf_wavenet_create: no HIP device available"; return 1; }
+    const adf_wavenet_config& c = *cfg;
+    if (c.residual_channels < 32 || c.residual_channels % 32 || c.residual_channels > 512) { g_create_error = "adf_wavenet_create: residual_channels must be a multiple of 32 in [32, 512]"; return 1; }
+    if (c.residual_layers < 1 || c.residual_layers > 1024 || c.dilation_cycle < 1 || c.dilation_cycle > 24) { g_create_error = "adf_wavenet_create: bad residual_layers / dilation_cycle"; return 1; }
+    if (c.dim_in < 4 || c.dim_in % 2 || c.dim_in > 1024 || c.dim_mid < 1 || c.dim_mid > 1024 || c.dim_out < 4 || c.dim_out % 4 || c.dim_out > 1024) { g_create_error = "adf_wavenet_create: bad embedding widths"; return 1; }
+    if (c.dtype != ADF_DTYPE_F32 && c.dtype != ADF_DTYPE_BF16) { g_create_error = "adf_wavenet_create: bad dtype"; return 1; }
+    if (c.dtype == ADF_DTYPE_BF16 && c.residual_channels != 256) { g_create_error = "adf_wavenet_create: the bf16 (MFMA) kernels are built for residual_channels = 256; use ADF_DTYPE_F32 for other widths"; return 1; }
+    adf_handle* h = new adf_handle();
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    // the fields of the U-Net config the shared plan / sampler code reads: one waveform channel in and out, no length
+    // constraint, embedding width 4 * channels = dim_out
+    h->cfg.in_channels = 1; h->cfg.out_channels = 1; h->cfg.stride = 1; h->cfg.num_layers = 0; h->cfg.channels = c.dim_out / 4;
+    h->cfg.dtype = c.dtype; h->cfg.resnet_groups = 1;
+    if (hipGetDevice(&h->device) != hipSuccess) { g_create_error = "adf_wavenet_create: hipGetDevice failed"; delete h; return 1; }
+    h->bf16 = c.dtype == ADF_DTYPE_BF16;
+    h->esz = h->bf16 ? 2 : 4;
+    h->kc = kRowBytes / h->esz;
+    h->wn = new WnW();
+    h->wn->cfg = c;
+    if (wn_build_weights(h)) { g_create_error = h->err; adf_destroy(h); return 1; }
+    *out = h;
+    return 0;
+}
+
 void adf_destroy(adf_handle* h) {
     if (!h) return;
     DeviceScope scope(h);
@@ -1287,6 +1446,7 @@ void adf_destroy(adf_handle* h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    delete h->wn;
     delete h;
 }
 
@@ -1319,6 +1479,7 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
         }
     }
     sl.loaded = true;
+    if (h->wn) h->wn->packed = false;      // the effective weights (v * g / ||v||) are rebuilt before the next pass
     return 0;
 }
 
@@ -1465,10 +1626,17 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
         if (n_eval == 0) return 0;
         const adf_net_config& cfg = h->cfg;
         if (const char* e = launch_edm_coef_list(eval_sigmas.data(), n_eval, desc->sigma_data, p->coef_all, st)) return fail(h, e);
-        TimeEmbedArgs te;
-        te.t = p->coef_all + 1; te.t_stride = 4; te.nb = n_eval; te.ch = cfg.channels;
-        te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb_all;
-        if (const char* e = launch_time_embed(te, st)) return fail(h, e);
+        if (h->wn) {
+            const adf_wavenet_config& wc = h->wn->cfg;
+            if (const char* e = launch_wn_step_embed(p->coef_all + 1, 4, n_eval, h->wn->fc1w, h->wn->fc1b, h->wn->fc2w, h->wn->fc2b, wc.dim_in,
+                                                     wc.dim_mid, wc.dim_out, p->temb_all, st))
+                return fail(h, e);
+        } else {
+            TimeEmbedArgs te;
+            te.t = p->coef_all + 1; te.t_stride = 4; te.nb = n_eval; te.ch = cfg.channels;
+            te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb_all;
+            if (const char* e = launch_time_embed(te, st)) return fail(h, e);
+        }
         if (const char* e = launch_film(p->temb_all, 4 * cfg.channels, h->film_w, 4 * cfg.channels + h->cdim, 0, h->film_b, p->film_all, n_eval,
                                         h->film_total, st))
             return fail(h, e);
@@ -1549,7 +1717,8 @@ int adf_debug_tap_copy(adf_handle* h, const char* name, float* out, void* stream
     if (!h->last_plan) return fail(h, "no forward has run yet");
     for (const auto& t : h->last_plan->taps)
         if (t.name == name) {
-            const char* e = launch_nlc_to_ncl_f32(t.p, out, h->bf16, h->last_plan->B, t.L, t.C, (hipStream_t)stream);
+            const char* e = launch_nlc_to_ncl_f32(t.p, out, t.f32 ? 0 : h->bf16, h->last_plan->B, t.L, t.C, (hipStream_t)stream);
+            if (!e && t.scale != 1.0f) e = launch_scale(out, out, t.scale, (long long)h->last_plan->B * t.L * t.C, (hipStream_t)stream);
             return e ? fail(h, e) : 0;
         }
     return fail(h, std::string("unknown tap ") + name);

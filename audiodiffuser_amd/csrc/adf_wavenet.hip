@@ -1,0 +1,538 @@
+// WaveNetNoise (DiffWave-style, unconditional) on gfx950 -- BASELINE config 5, SURVEY.md 8f row 4.
+// Reference: src/models/backbones/wavenet.py (WeightNorm :15-55, Conv :68-82, diffusion_embedding :88-92, ResidualBlock
+// :94-116, ResidualGroup :117-152, WaveNetNoise :153-180).
+//
+// One launch per residual layer.  The layer is two GEMMs per position (dilated k = 3 conv C -> 2C, K = 3C; 1x1 conv C -> 2C)
+// with a gate between them and a residual / skip epilogue: 1.05 MFLOP against ~2.5 KB of HBM traffic per position at C = 256,
+// i.e. far on the matrix side of the ridge, so the throughput kernel is an MFMA kernel and the weights (1 MB per layer in
+// bf16, re-read by every tile from L2) are its second stream:
+//   wn_layer_bf16_kernel: 64 positions per 512-thread workgroup.  The three dilated windows of y (rows t0 + (tap - 1) d, zero
+//     outside the sample) are staged once into LDS; each wave owns 32 gate columns AND the 32 matching filter columns of GEMM 1
+//     (so sigmoid * tanh is register-local) and reads its weight fragments straight from a fragment-major copy in global
+//     memory, 8 K steps ahead (each weight byte once per workgroup); the gated tile goes to LDS as bf16 and is the A operand of
+//     GEMM 2, whose residual columns update the centre window in place (LDS) and whose skip columns are accumulated into the
+//     fp32 skip sum in HBM; the centre window then leaves as 16-byte stores.
+//   wn_layer_f32_kernel: the parity path -- the same fusion on the vector ALUs in exact fp32 (one thread per channel, 16
+//     positions per workgroup, operands transposed in LDS so that a ds_read_b128 is a 4-position broadcast).
+#include "adf_wavenet.h"
+#include <type_traits>
+
+namespace adf {
+
+typedef float f32x4_vec __attribute__((ext_vector_type(4)));
+
+#define WN_LAUNCH_CHECK(name) (hipGetLastError() == hipSuccess ? nullptr : "launch failed: " name)
+
+// ------------------------------------------------------------------------------------------------ weight preparation
+__global__ void __launch_bounds__(1024) wn_sumsq_kernel(const float* __restrict__ v, long long numel, double* __restrict__ out) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < numel; i += 1024) { const double x = (double)v[i]; acc += x * x; }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        out[0] = t;
+    }
+}
+const char* launch_wn_sumsq(const float* v, long long numel, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(wn_sumsq_kernel, dim3(1), dim3(1024), 0, s, v, numel, out);
+    return WN_LAUNCH_CHECK("wn_sumsq");
+}
+
+__global__ void __launch_bounds__(256) wn_pack_kernel(const float* __restrict__ v, const float* __restrict__ g, const double* __restrict__ sumsq,
+                                                      void* __restrict__ dst, int layout, int cout, int cin, int K) {
+    const long long total = (long long)cout * cin * K;
+    const float scale = g[0] / (float)sqrt(sumsq[0]);                 // wavenet.py:50
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        if (layout == 2) {
+            ((float*)dst)[idx] = v[idx] * scale;
+        } else if (layout == 0) {                                     // [K][cin][cout]
+            const int co = (int)(idx % cout);
+            const long long r = idx / cout;
+            const int ci = (int)(r % cin), k = (int)(r / cin);
+            ((float*)dst)[idx] = v[((long long)co * cin + ci) * K + k] * scale;
+        } else {                                                      // [(tap, 16-channel step)][half][cout][8]
+            const int e = (int)(idx & 7);
+            long long r = idx >> 3;
+            const int co = (int)(r % cout); r /= cout;
+            const int hh = (int)(r & 1); r >>= 1;
+            const int steps = cin / 16;
+            const int j = (int)(r % steps), k = (int)(r / steps);
+            const int ci = j * 16 + hh * 8 + e;
+            ((uint16_t*)dst)[idx] = f32_to_bf16(v[((long long)co * cin + ci) * K + k] * scale);
+        }
+    }
+}
+const char* launch_wn_pack(const float* v, const float* g, const double* sumsq, void* dst, int layout, int cout, int cin, int K,
+                           hipStream_t s) {
+    if (layout == 1 && cin % 16) return "wn_pack: the fragment-major layout needs a multiple of 16 input channels";
+    const long long total = (long long)cout * cin * K;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(wn_pack_kernel, dim3(blocks), dim3(256), 0, s, v, g, sumsq, dst, layout, cout, cin, K);
+    return WN_LAUNCH_CHECK("wn_pack");
+}
+
+// ------------------------------------------------------------------------------------------------ diffusion-step embedding
+__global__ void __launch_bounds__(256) wn_step_embed_kernel(const float* __restrict__ t, int t_stride, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, int dim_in, int dim_mid, int dim_out,
+                                                            float* __restrict__ pre) {
+    __shared__ float f[1024];
+    __shared__ float hdn[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float tv = t[(size_t)b * t_stride];
+    const int half = dim_in / 2;
+    for (int i = tid; i < half; i += 256) {                           // wavenet.py:89-91, sines first
+        const float ang = tv * expf((-(float)i * 4.0f) / (float)(half - 1));
+        f[i] = sinf(ang);
+        f[half + i] = cosf(ang);
+    }
+    __syncthreads();
+    for (int j = tid; j < dim_mid; j += 256) {
+        float acc = b1[j];
+        for (int i = 0; i < dim_in; ++i) acc = fmaf(w1[(size_t)j * dim_in + i], f[i], acc);
+        hdn[j] = acc / (1.0f + expf(-acc));                            // swish, :84-86
+    }
+    __syncthreads();
+    for (int j = tid; j < dim_out; j += 256) {
+        float acc = b2[j];
+        for (int i = 0; i < dim_mid; ++i) acc = fmaf(w2[(size_t)j * dim_mid + i], hdn[i], acc);
+        pre[(size_t)b * dim_out + j] = acc;                            // the second swish is applied by film_kernel
+    }
+}
+const char* launch_wn_step_embed(const float* t, int t_stride, int nb, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, int dim_in, int dim_mid, int dim_out, float* pre, hipStream_t s) {
+    if (dim_in > 1024 || dim_mid > 1024 || dim_in % 2 || dim_in < 4) return "wn_step_embed: unsupported embedding widths";
+    hipLaunchKernelGGL(wn_step_embed_kernel, dim3(nb), dim3(256), 0, s, t, t_stride, w1, b1, w2, b2, dim_in, dim_mid, dim_out, pre);
+    return WN_LAUNCH_CHECK("wn_step_embed");
+}
+
+// ------------------------------------------------------------------------------------------------ input projection
+template <typename T>
+__global__ void __launch_bounds__(256) wn_input_kernel(const float* __restrict__ x, const float* __restrict__ coef, int coef_bstride,
+                                                       const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                       const float* __restrict__ e, int e_bstride, T* __restrict__ y0, int B, int Tn, int C) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    const int cpr = C / EPC;
+    const long long total = (long long)B * Tn * cpr;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int cc = (int)(idx % cpr);
+        const long long row = idx / cpr;
+        const int b = (int)(row / Tn);
+        const float cin = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
+        const float xv = x[row] * cin;
+        float f[EPC];
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) {
+            const int c = cc * EPC + k;
+            f[k] = fmaxf(fmaf(w_in[c], xv, b_in[c]), 0.0f) + e[(size_t)b * e_bstride + c];
+        }
+        *(u32x4_t*)(y0 + row * C + cc * EPC) = pack16<T>(f);
+    }
+}
+const char* launch_wn_input(const WnIO& io, const float* x, const float* coef, int coef_bstride, const float* w_in, const float* b_in,
+                            void* y0, hipStream_t s) {
+    const long long total = (long long)io.B * io.T * (io.C / (io.bf16 ? 8 : 4));
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    if (io.bf16) hipLaunchKernelGGL(wn_input_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, coef, coef_bstride, w_in, b_in, io.e, io.e_bstride, (bf16_t*)y0, io.B, io.T, io.C);
+    else hipLaunchKernelGGL(wn_input_kernel<float>, dim3(blocks), dim3(256), 0, s, x, coef, coef_bstride, w_in, b_in, io.e, io.e_bstride, (float*)y0, io.B, io.T, io.C);
+    return WN_LAUNCH_CHECK("wn_input");
+}
+
+// ------------------------------------------------------------------------------------------------ residual layer, fp32 (parity)
+constexpr int kWnTP = 16;           // positions per workgroup of the fp32 kernels
+constexpr float kInvSqrt2Div = 1.41421356237309504880f;
+
+__global__ void __launch_bounds__(512) wn_layer_f32_kernel(const float* __restrict__ y, float* __restrict__ y_next, float* __restrict__ skip,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            const float* __restrict__ e, int e_bstride, int n, int dil, int first,
+                                                            int Tn, int C) {
+    constexpr int TP = kWnTP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const At = (float*)smem;                    // [3][C][TP]: the three dilated windows, transposed
+    float* const Gt = At + 3 * C * TP;                 // [C][TP]: gated activation, transposed
+    const int c = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * TP;
+    const float* const yb = y + (size_t)b * Tn * C;
+    for (int idx = c; idx < 3 * TP * C; idx += C) {
+        const int tap = idx / (TP * C), rem = idx - tap * TP * C;
+        const int i = rem / C, ch = rem - i * C;
+        const int t = t0 + i + (tap - 1) * dil;
+        At[(tap * C + ch) * TP + i] = (t >= 0 && t < Tn) ? yb[(size_t)t * C + ch] : 0.0f;     // zero padding of y (wavenet.py:71)
+    }
+    __syncthreads();
+    float ag[TP], af[TP];
+#pragma unroll
+    for (int i = 0; i < TP; ++i) { ag[i] = b1[c]; af[i] = b1[C + c]; }
+    for (int tap = 0; tap < 3; ++tap) {
+        const float* wt = w1 + (size_t)tap * C * 2 * C;
+        const float* at = At + (size_t)tap * C * TP;
+        for (int k = 0; k < C; ++k) {
+            const float wg = wt[(size_t)k * 2 * C + c], wf = wt[(size_t)k * 2 * C + C + c];
+            const f32x4_vec* a4 = (const f32x4_vec*)(at + k * TP);
+#pragma unroll
+            for (int q = 0; q < TP / 4; ++q) {
+                const f32x4_vec a = a4[q];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ag[q * 4 + u] = fmaf(wg, a[u], ag[q * 4 + u]); af[q * 4 + u] = fmaf(wf, a[u], af[q * 4 + u]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TP; ++i) Gt[c * TP + i] = (1.0f / (1.0f + expf(-ag[i]))) * tanhf(af[i]);       // :112-113 (first chunk = gate)
+    __syncthreads();
+    float ar[TP], as[TP];
+#pragma unroll
+    for (int i = 0; i < TP; ++i) { ar[i] = b2[c]; as[i] = b2[C + c]; }
+    for (int k = 0; k < C; ++k) {
+        const float wr = w2[(size_t)k * 2 * C + c], ws = w2[(size_t)k * 2 * C + C + c];
+        const f32x4_vec* a4 = (const f32x4_vec*)(Gt + k * TP);
+#pragma unroll
+        for (int q = 0; q < TP / 4; ++q) {
+            const f32x4_vec a = a4[q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ar[q * 4 + u] = fmaf(wr, a[u], ar[q * 4 + u]); as[q * 4 + u] = fmaf(ws, a[u], as[q * 4 + u]); }
+        }
+    }
+    const float en = e[(size_t)b * e_bstride + (size_t)n * C + c];
+    const float en1 = y_next ? e[(size_t)b * e_bstride + (size_t)(n + 1) * C + c] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TP; ++i) {
+        const int t = t0 + i;
+        if (t < Tn) {
+            const size_t o = ((size_t)b * Tn + t) * C + c;
+            if (y_next) y_next[o] = ((At[(C + c) * TP + i] - en) + ar[i]) / kInvSqrt2Div + en1;         // :116, then the next layer's :110
+            skip[o] = first ? as[i] : skip[o] + as[i];                                                   // :149
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ residual layer, bf16 (MFMA)
+typedef __attribute__((ext_vector_type(8))) __bf16 wn_bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float wn_f32x16_t;
+
+__device__ __forceinline__ float wn_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+__device__ __forceinline__ float wn_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f)); }
+
+// The MFMA stage shared by the layer kernel and the final kernel: a wave accumulates NN column tiles of 32 (columns nbase[j] + r)
+// over KS K steps of 16 channels; A fragments from LDS (window `tap` of `TMR` rows at pitch PA), W fragments from the
+// fragment-major global copy [K step][half][NCOLS][8], DEPTH steps ahead in a register ring.
+template <int C, int TM>
+struct WnTile {
+    static constexpr int PA = C * 2 + 16;              // LDS row pitch: conflict-free 16-byte fragment reads (see adf_gemm.h)
+    static constexpr int MT = TM / 32;
+    static constexpr int SPT = C / 16;                 // K steps per tap
+    static constexpr int DEPTH = 7, RING = 8;
+};
+
+template <int C, int TM, int NCOLS, int NN, int TAPS>
+__device__ __forceinline__ void wn_gemm(const char* __restrict__ A, const void* __restrict__ W, const int (&nbase)[NN],
+                                        wn_f32x16_t (&acc)[NN][TM / 32], int r, int hh) {
+    using Tl = WnTile<C, TM>;
+    constexpr int PA = Tl::PA, MT = Tl::MT, SPT = Tl::SPT, DEPTH = Tl::DEPTH, RING = Tl::RING;
+    constexpr int KS = TAPS * SPT;
+    static_assert(KS % RING == 0 && KS > DEPTH, "K steps must fill whole ring trips");
+    const char* wl[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) wl[j] = (const char*)W + ((size_t)hh * NCOLS + nbase[j] + r) * 16;
+    auto wfrag = [&](int j, int ks) __attribute__((always_inline)) -> wn_bf16x8_t {
+        return __builtin_bit_cast(wn_bf16x8_t, *(const u32x4_t*)(wl[j] + (size_t)ks * 2 * NCOLS * 16));
+    };
+    auto afrag = [&](int ks, wn_bf16x8_t (&af)[MT]) __attribute__((always_inline)) {
+        const int tap = ks / SPT, q = ks - tap * SPT;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const wn_bf16x8_t*)(A + ((size_t)tap * TM + i * 32 + r) * PA + q * 32 + hh * 16);
+    };
+    wn_bf16x8_t wf[NN][RING];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) wf[j][d] = wfrag(j, d);
+    wn_bf16x8_t af[2][MT];
+    afrag(0, af[0]);
+#pragma unroll 1
+    for (int kb = 0; kb < KS; kb += RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            const int ks = kb + u;
+            if (ks + DEPTH < KS) {
+#pragma unroll
+                for (int j = 0; j < NN; ++j) wf[j][(u + DEPTH) % RING] = wfrag(j, ks + DEPTH);
+            }
+            if (ks + 1 < KS) afrag(ks + 1, af[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NN; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][i], wf[j][u], acc[j][i], 0, 0, 0);
+        }
+    }
+}
+
+template <int C, int TM>
+__global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ y_next, float* __restrict__ skip,
+                                                            const void* __restrict__ w1, const float* __restrict__ b1,
+                                                            const void* __restrict__ w2, const float* __restrict__ b2,
+                                                            const float* __restrict__ e, int e_bstride, int n, int dil, int first, int Tn) {
+    using Tl = WnTile<C, TM>;
+    constexpr int PA = Tl::PA, MT = Tl::MT;
+    static_assert(C == 256, "a wave owns 32 of the C gate columns: 8 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const bufA = smem;                               // [3][TM][PA]: the dilated windows of y
+    char* const bufG = smem + 3 * TM * PA;                 // [TM][PA]: gated activation
+    float* const prm = (float*)(bufG + TM * PA);           // b1 (2C) | b2 (2C) | e_n (C) | e_{n+1} (C)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TM;
+    const bf16_t* const yb = y + (size_t)b * Tn * C;
+
+    // ---- stage the three windows (zero outside the sample: the conv's padding of y) and the parameters --------------------
+    constexpr int CPR = C / 8;
+    for (int idx = tid; idx < 3 * TM * CPR; idx += 512) {
+        const int tap = idx / (TM * CPR), rem = idx - tap * TM * CPR;
+        const int i = rem / CPR, cc = rem - i * CPR;
+        const int t = t0 + i + (tap - 1) * dil;
+        const bool in = t >= 0 && t < Tn;
+        u32x4_t v = *(const u32x4_t*)(yb + (size_t)(in ? t : 0) * C + cc * 8);
+        if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
+        *(u32x4_t*)(bufA + ((size_t)tap * TM + i) * PA + cc * 16) = v;
+    }
+    for (int i = tid; i < 6 * C; i += 512) {
+        float v;
+        if (i < 2 * C) v = b1[i];
+        else if (i < 4 * C) v = b2[i - 2 * C];
+        else if (i < 5 * C) v = e[(size_t)b * e_bstride + (size_t)n * C + (i - 4 * C)];
+        else v = y_next ? e[(size_t)b * e_bstride + (size_t)(n + 1) * C + (i - 5 * C)] : 0.0f;
+        prm[i] = v;
+    }
+    __syncthreads();
+
+    auto row_of = [&](int i, int q) __attribute__((always_inline)) -> int { return i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh; };
+    const int col = wave * 32 + r;
+    const int nb2[2] = {wave * 32, C + wave * 32};
+
+    // ---- GEMM 1: gate columns and the matching filter columns; sigmoid * tanh -> bufG -------------------------------------
+    {
+        wn_f32x16_t acc[2][MT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
+        wn_gemm<C, TM, 2 * C, 2, 3>(bufA, w1, nb2, acc, r, hh);
+        const float bg = prm[col], bf = prm[C + col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float v = wn_sigmoid(acc[0][i][q] + bg) * wn_tanh(acc[1][i][q] + bf);
+                *(unsigned short*)(bufG + (size_t)row_of(i, q) * PA + col * 2) = f32_to_bf16_hw(v);
+            }
+    }
+    __syncthreads();
+
+    // ---- GEMM 2: residual columns -> centre window in place; skip columns -> fp32 sum in HBM ------------------------------
+    {
+        wn_f32x16_t acc[2][MT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
+        wn_gemm<C, TM, 2 * C, 2, 1>(bufG, w2, nb2, acc, r, hh);
+        const float br = prm[2 * C + col], bs = prm[3 * C + col], en = prm[4 * C + col], en1 = prm[5 * C + col];
+        float* const sb = skip + ((size_t)b * Tn + t0) * C + col;
+        char* const ctr = bufA + (size_t)TM * PA;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = row_of(i, q);
+                if (y_next) {
+                    unsigned short* const p = (unsigned short*)(ctr + (size_t)row * PA + col * 2);
+                    const float yo = bf16_to_f32(*p);
+                    *p = f32_to_bf16_hw(((yo - en) + (acc[0][i][q] + br)) * 0.70710678118654752440f + en1);
+                }
+                if (t0 + row < Tn) {
+                    const float sv = acc[1][i][q] + bs;
+                    float* const sp = sb + (size_t)row * C;
+                    *sp = first ? sv : *sp + sv;
+                }
+            }
+    }
+    if (!y_next) return;
+    __syncthreads();
+    bf16_t* const ob = y_next + ((size_t)b * Tn + t0) * C;
+    for (int idx = tid; idx < TM * CPR; idx += 512) {
+        const int i = idx / CPR, cc = idx - i * CPR;
+        if (t0 + i < Tn) *(u32x4_t*)(ob + (size_t)i * C + cc * 8) = *(const u32x4_t*)(bufA + ((size_t)TM + i) * PA + cc * 16);
+    }
+}
+
+const char* launch_wn_layer(const WnIO& io, const WnLayerArgs& a, hipStream_t s) {
+    if (io.bf16) {
+        constexpr int C = 256, TM = 64;
+        if (io.C != C) return "WaveNet bf16 mode: the MFMA layer kernel is built for residual_channels = 256 (use fp32 for other widths)";
+        const size_t lds = (size_t)4 * TM * WnTile<C, TM>::PA + 6 * C * 4;
+        static bool attr_done[kMaxDevices] = {};
+        bool& attr = attr_done[current_device()];
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)wn_layer_bf16_kernel<C, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return "wn_layer: hipFuncSetAttribute failed";
+            attr = true;
+        }
+        hipLaunchKernelGGL((wn_layer_bf16_kernel<C, TM>), dim3(ceil_div(io.T, TM), io.B), dim3(512), lds, s, (const bf16_t*)a.y, (bf16_t*)a.y_next,
+                           a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+        return WN_LAUNCH_CHECK("wn_layer_bf16");
+    }
+    if (io.C % 32 || io.C > 512) return "WaveNet fp32 mode: residual_channels must be a multiple of 32, at most 512";
+    const size_t lds = (size_t)4 * io.C * kWnTP * 4;
+    static bool attr_done32[kMaxDevices] = {};
+    bool& attr = attr_done32[current_device()];
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)wn_layer_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return "wn_layer: hipFuncSetAttribute failed";
+        attr = true;
+    }
+    hipLaunchKernelGGL(wn_layer_f32_kernel, dim3(ceil_div(io.T, kWnTP), io.B), dim3(io.C), lds, s, (const float*)a.y, (float*)a.y_next, a.skip,
+                       (const float*)a.w1, a.b1, (const float*)a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T, io.C);
+    return WN_LAUNCH_CHECK("wn_layer_f32");
+}
+
+// ------------------------------------------------------------------------------------------------ skip projection + output conv
+__device__ __forceinline__ float wn_edm_out(float F, int mode, const float* x_noisy, const float* coef, int coef_bstride, int b, size_t o) {
+    if (mode == 0) return F;
+    const float c_skip = coef[(size_t)b * coef_bstride + 2], c_out = coef[(size_t)b * coef_bstride + 3];
+    return fminf(fmaxf(fmaf(c_out, F, c_skip * x_noisy[o]), -1.0f), 1.0f);
+}
+
+__global__ void __launch_bounds__(512) wn_final_f32_kernel(const float* __restrict__ skip, float scale, const float* __restrict__ w_sp,
+                                                            const float* __restrict__ b_sp, const float* __restrict__ w_out,
+                                                            const float* __restrict__ b_out, float* __restrict__ out, int mode,
+                                                            const float* __restrict__ x_noisy, const float* __restrict__ coef,
+                                                            int coef_bstride, int Tn, int C) {
+    constexpr int TP = kWnTP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const St = (float*)smem;                    // [C][TP]: skip * scale, transposed
+    float* const Pt = St + C * TP;                     // [C][TP]: w_out[c] * relu(sp[c])
+    const int c = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * TP;
+    for (int idx = c; idx < TP * C; idx += C) {
+        const int i = idx / C, ch = idx - i * C;
+        const int t = t0 + i;
+        St[ch * TP + i] = t < Tn ? skip[((size_t)b * Tn + t) * C + ch] * scale : 0.0f;      // wavenet.py:152
+    }
+    __syncthreads();
+    float acc[TP];
+#pragma unroll
+    for (int i = 0; i < TP; ++i) acc[i] = b_sp[c];
+    for (int k = 0; k < C; ++k) {
+        const float w = w_sp[(size_t)k * C + c];
+        const f32x4_vec* a4 = (const f32x4_vec*)(St + k * TP);
+#pragma unroll
+        for (int q = 0; q < TP / 4; ++q) {
+            const f32x4_vec a = a4[q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[q * 4 + u] = fmaf(w, a[u], acc[q * 4 + u]);
+        }
+    }
+    const float wo = w_out[c];
+#pragma unroll
+    for (int i = 0; i < TP; ++i) Pt[c * TP + i] = wo * fmaxf(acc[i], 0.0f);                  // :177-179
+    __syncthreads();
+    if (c < TP && t0 + c < Tn) {
+        float F = b_out[0];
+        for (int k = 0; k < C; ++k) F += Pt[k * TP + c];
+        const size_t o = (size_t)b * Tn + t0 + c;
+        out[o] = wn_edm_out(F, mode, x_noisy, coef, coef_bstride, b, o);
+    }
+}
+
+template <int C, int TM>
+__global__ void __launch_bounds__(512) wn_final_bf16_kernel(const float* __restrict__ skip, float scale, const void* __restrict__ w_sp,
+                                                            const float* __restrict__ b_sp, const float* __restrict__ w_out,
+                                                            const float* __restrict__ b_out, float* __restrict__ out, int mode,
+                                                            const float* __restrict__ x_noisy, const float* __restrict__ coef,
+                                                            int coef_bstride, int Tn) {
+    using Tl = WnTile<C, TM>;
+    constexpr int PA = Tl::PA, MT = Tl::MT;
+    static_assert(C == 256, "8 waves x 32 columns");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const bufA = smem;                               // [TM][PA]: bf16(skip * scale)
+    float* const prm = (float*)(bufA + TM * PA);           // b_sp (C) | w_out (C)
+    float* const red = prm + 2 * C;                        // [8][TM] per-wave partial dot products
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TM;
+    constexpr int CPR = C / 8;
+    for (int idx = tid; idx < TM * CPR; idx += 512) {
+        const int i = idx / CPR, cc = idx - i * CPR;
+        const bool in = t0 + i < Tn;
+        const float* src = skip + ((size_t)b * Tn + (in ? t0 + i : 0)) * C + cc * 8;
+        float f[8];
+        const u32x4_t lo = *(const u32x4_t*)src, hi = *(const u32x4_t*)(src + 4);
+        unpack16<float>(lo, f); unpack16<float>(hi, f + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = in ? f[k] * scale : 0.0f;
+        *(u32x4_t*)(bufA + (size_t)i * PA + cc * 16) = pack16<bf16_t>(f);
+    }
+    for (int i = tid; i < 2 * C; i += 512) prm[i] = i < C ? b_sp[i] : w_out[i - C];
+    __syncthreads();
+    const int col = wave * 32 + r;
+    const int nb1[1] = {wave * 32};
+    wn_f32x16_t acc[1][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][i][q] = 0.f;
+    wn_gemm<C, TM, C, 1, 1>(bufA, w_sp, nb1, acc, r, hh);
+    const float bs = prm[col], wo = prm[C + col];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float v = wo * bf16_stored(fmaxf(acc[0][i][q] + bs, 0.0f));
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);       // over the 32 columns of this half-wave
+            if (r == 0) red[wave * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh] = v;
+        }
+    __syncthreads();
+    if (tid < TM && t0 + tid < Tn) {
+        float F = b_out[0];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) F += red[w * TM + tid];
+        const size_t o = (size_t)b * Tn + t0 + tid;
+        out[o] = wn_edm_out(F, mode, x_noisy, coef, coef_bstride, b, o);
+    }
+}
+
+const char* launch_wn_final(const WnIO& io, const WnFinalArgs& a, hipStream_t s) {
+    if (io.bf16) {
+        constexpr int C = 256, TM = 64;
+        if (io.C != C) return "WaveNet bf16 mode: built for residual_channels = 256";
+        const size_t lds = (size_t)TM * WnTile<C, TM>::PA + (2 * C + 8 * TM) * 4;
+        static bool attr_done[kMaxDevices] = {};
+        bool& attr = attr_done[current_device()];
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)wn_final_bf16_kernel<C, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return "wn_final: hipFuncSetAttribute failed";
+            attr = true;
+        }
+        hipLaunchKernelGGL((wn_final_bf16_kernel<C, TM>), dim3(ceil_div(io.T, TM), io.B), dim3(512), lds, s, a.skip, a.skip_scale, a.w_sp, a.b_sp,
+                           a.w_out, a.b_out, a.out, a.mode, a.x_noisy, a.coef, a.coef_bstride, io.T);
+        return WN_LAUNCH_CHECK("wn_final_bf16");
+    }
+    if (io.C % 32 || io.C > 512) return "WaveNet fp32 mode: residual_channels must be a multiple of 32, at most 512";
+    const size_t lds = (size_t)2 * io.C * kWnTP * 4;
+    hipLaunchKernelGGL(wn_final_f32_kernel, dim3(ceil_div(io.T, kWnTP), io.B), dim3(io.C), lds, s, a.skip, a.skip_scale, (const float*)a.w_sp, a.b_sp,
+                       a.w_out, a.b_out, a.out, a.mode, a.x_noisy, a.coef, a.coef_bstride, io.T, io.C);
+    return WN_LAUNCH_CHECK("wn_final_f32");
+}
+
+}  // namespace adf

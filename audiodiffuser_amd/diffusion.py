@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from .net import UNet1dBase
+from .net import HipNet, UNet1dBase
 
 
 def _extend(x: Tensor, ndim: int) -> Tensor:
@@ -49,7 +49,7 @@ class EluDiffusion(nn.Module):
     def _native_ok(self, net, inference: bool, cond_scale: float, kwargs: dict) -> bool:
         """The HIP fast path covers inference with clamp clipping; the only conditioning kwarg it understands is
         ``classes`` (labels) on a class-conditional net, where ``cond_scale != 1`` is classifier-free guidance."""
-        if not (isinstance(net, UNet1dBase) and inference and self.dynamic_threshold == 0.0):
+        if not (isinstance(net, HipNet) and inference and self.dynamic_threshold == 0.0):
             return False
         extra = {k: v for k, v in kwargs.items() if v is not None}
         if net.cfg.class_cond:
@@ -93,7 +93,7 @@ class EluDiffusion(nn.Module):
     # diffusion.py:65-98 (training loss; stock tensor ops, outside the accelerated path)
     def forward(self, x: Tensor, net: nn.Module, sigmas: Tensor, inference: bool = False, cond_scale: float = 1.0,
                 **kwargs) -> Tensor:
-        if isinstance(net, UNet1dBase) and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+        if isinstance(net, HipNet) and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
             raise NotImplementedError("EluDiffusion.forward is the training loss; the HIP UNet1dBase is an inference path without "
                                       "backward -- train the reference module and load its state_dict here, or call under torch.no_grad()")
         noise = torch.randn_like(x)

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .config import UNet1dConfig
+from .config import UNet1dConfig, WaveNetConfig
 from .weights import param_specs
 
 _DTYPES = {"fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16}
@@ -34,15 +34,19 @@ def _stream_ptr(device: torch.device) -> int:
 class NativeHandle:
     """Owns one ``adf_handle`` (one device, one compute dtype)."""
 
-    def __init__(self, cfg: UNet1dConfig, dtype: str, flags: int = 0):
+    def __init__(self, cfg, dtype: str, flags: int = 0):
         self.lib = _lib.load_library()
         self.cfg = cfg
         self.dtype = dtype
-        c = _lib.make_config(cfg, _DTYPES[dtype], flags)
         h = C.c_void_p()
-        rc = self.lib.adf_create(C.byref(c), C.byref(h))
+        if isinstance(cfg, WaveNetConfig):
+            c = _lib.make_wavenet_config(cfg, _DTYPES[dtype])
+            rc, what = self.lib.adf_wavenet_create(C.byref(c), C.byref(h)), "adf_wavenet_create"
+        else:
+            c = _lib.make_config(cfg, _DTYPES[dtype], flags)
+            rc, what = self.lib.adf_create(C.byref(c), C.byref(h)), "adf_create"
         if rc != 0:
-            raise _lib.AdfError("adf_create: " + self.lib.adf_last_error(None).decode())
+            raise _lib.AdfError(what + ": " + self.lib.adf_last_error(None).decode())
         self.h = h
         self._loaded: Dict[str, tuple] = {}
 
@@ -165,7 +169,56 @@ def _init_like_reference(name: str, shape, kind: str) -> torch.Tensor:
     raise ValueError(kind)
 
 
-class UNet1dBase(nn.Module):
+class HipNet(nn.Module):
+    """What the HIP-backed ``model.net`` plugins share: a parameter tree under the reference's state_dict key names, one
+    ``NativeHandle`` per (device, compute dtype) whose packed weights follow the parameters, and the ``cfg`` the denoise /
+    sampler fast paths read (``class_cond``, ``out_channels``).  Subclasses set ``cfg``, ``compute_dtype``, ``native_flags``."""
+
+    compute_dtype = "fp32"
+    native_flags = 0
+
+    # -- parameter tree with reference key names ------------------------------------
+    def _register(self, dotted: str, p: nn.Parameter) -> None:
+        mod = self
+        parts = dotted.split(".")
+        for part in parts[:-1]:
+            if part not in mod._modules:
+                mod.add_module(part, nn.Module())
+            mod = mod._modules[part]
+        mod.register_parameter(parts[-1], p)
+
+    # -- native handle ---------------------------------------------------------------
+    def native(self, device: torch.device) -> NativeHandle:
+        if device.type != "cuda":
+            raise RuntimeError(f"the HIP {type(self).__name__} only runs on a ROCm device ('cuda'); there is no CPU fallback")
+        handles = self.__dict__.setdefault("_handles", {})
+        key = (device.index if device.index is not None else torch.cuda.current_device(), self.compute_dtype)
+        hd = handles.get(key)
+        if hd is None:
+            with torch.cuda.device(device):
+                hd = NativeHandle(self.cfg, self.compute_dtype, self.native_flags)
+            handles[key] = hd
+        hd.sync_weights(dict(self.named_parameters()), device)
+        return hd
+
+    def invalidate_native(self) -> None:
+        """Force a re-upload of all weights on the next call.  The staleness check keys on ``(data_ptr, _version, device)``;
+        ``load_state_dict`` and in-place tensor ops bump ``_version``, but writes through ``p.data`` (some EMA / weight-swap
+        code) or raw pointers do not -- call this after them."""
+        for hd in self.__dict__.get("_handles", {}).values():
+            hd.invalidate()
+
+    def _load_from_state_dict(self, *args, **kwargs):       # (only parameters registered on this module itself, if any)
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_native()
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_native()
+        return out
+
+
+class UNet1dBase(HipNet):
     """HIP-backed ``UNet1dBase``.  Extra kwarg: ``compute_dtype`` in {"fp32", "bf16"}."""
 
     def __init__(self, channels: int, cond_drop_prob: float = 0.0, num_classes: Optional[int] = None,
@@ -193,49 +246,10 @@ class UNet1dBase(nn.Module):
             self._register(name, nn.Parameter(_init_like_reference(name, shape, kind)))
         self._handles: Dict[tuple, NativeHandle] = {}
 
-    # -- parameter tree with reference key names ------------------------------------
-    def _register(self, dotted: str, p: nn.Parameter) -> None:
-        mod = self
-        parts = dotted.split(".")
-        for part in parts[:-1]:
-            if part not in mod._modules:
-                mod.add_module(part, nn.Module())
-            mod = mod._modules[part]
-        mod.register_parameter(parts[-1], p)
-
     @classmethod
     def from_config(cls, cfg: UNet1dConfig, compute_dtype: str = "fp32", native_flags: int = 0) -> "UNet1dBase":
         kw = cfg.to_kwargs()
         return cls(compute_dtype=compute_dtype, native_flags=native_flags, **kw)
-
-    # -- native handle ---------------------------------------------------------------
-    def native(self, device: torch.device) -> NativeHandle:
-        if device.type != "cuda":
-            raise RuntimeError("the HIP UNet1dBase only runs on a ROCm device ('cuda'); there is no CPU fallback")
-        key = (device.index if device.index is not None else torch.cuda.current_device(), self.compute_dtype)
-        hd = self._handles.get(key)
-        if hd is None:
-            with torch.cuda.device(device):
-                hd = NativeHandle(self.cfg, self.compute_dtype, self.native_flags)
-            self._handles[key] = hd
-        hd.sync_weights(dict(self.named_parameters()), device)
-        return hd
-
-    def invalidate_native(self) -> None:
-        """Force a re-upload of all weights on the next call.  The staleness check keys on ``(data_ptr, _version, device)``;
-        ``load_state_dict`` and in-place tensor ops bump ``_version``, but writes through ``p.data`` (some EMA / weight-swap
-        code) or raw pointers do not -- call this after them."""
-        for hd in self._handles.values():
-            hd.invalidate()
-
-    def _load_from_state_dict(self, *args, **kwargs):       # (only parameters registered on this module itself, if any)
-        super()._load_from_state_dict(*args, **kwargs)
-        self.invalidate_native()
-
-    def load_state_dict(self, *args, **kwargs):
-        out = super().load_state_dict(*args, **kwargs)
-        self.invalidate_native()
-        return out
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, classes=None, text_embeds=None, text_mask=None,
                 inj_embeddings=None, inj_channels=None, cond_drop_prob=None, **kwargs) -> torch.Tensor:

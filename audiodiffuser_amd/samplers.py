@@ -20,7 +20,7 @@ from torch import Tensor
 
 from . import _lib
 from .diffusion import EluDiffusion
-from .net import UNet1dBase
+from .net import HipNet, UNet1dBase
 
 
 def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict) -> Optional[EluDiffusion]:
@@ -29,7 +29,7 @@ def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict) -> Optional
     ``cond_scale != 1`` is classifier-free guidance (two network passes per evaluation)."""
     owner = getattr(fn, "__self__", None)
     if not (isinstance(owner, EluDiffusion) and getattr(fn, "__func__", None) is EluDiffusion.denoise_fn
-            and isinstance(net, UNet1dBase) and owner.dynamic_threshold == 0.0):
+            and isinstance(net, HipNet) and owner.dynamic_threshold == 0.0):
         return None
     extra = {k: v for k, v in kwargs.items() if v is not None}
     if net.cfg.class_cond:

@@ -20,7 +20,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .config import UNet1dConfig
+from .config import UNet1dConfig, WaveNetConfig
 
 Spec = Tuple[Tuple[int, ...], str]  # (shape, kind)
 
@@ -165,3 +165,49 @@ def count_parameters(cfg: UNet1dConfig) -> int:
             k *= d
         n += k
     return n
+
+
+# ---------------------------------------------------------------------------------------------- WaveNetNoise (BASELINE configs[4])
+def wavenet_param_specs(cfg: WaveNetConfig) -> "OrderedDict[str, Spec]":
+    """Every ``WaveNetNoise.state_dict()`` key in registration order (reference: src/models/backbones/wavenet.py:153-167).  The
+    custom ``WeightNorm`` (:15-55) deletes ``weight`` and registers a 0-dim ``weight_g`` (the norm of the WHOLE tensor, :29)
+    and ``weight_v`` after ``bias``."""
+    out: "OrderedDict[str, Spec]" = OrderedDict()
+    c = cfg.residual_channels
+
+    def wn_conv(pre, cin, cout, k):
+        out[f"{pre}.conv.module.bias"] = ((cout,), "bias")
+        out[f"{pre}.conv.module.weight_g"] = ((), "wn_g")
+        out[f"{pre}.conv.module.weight_v"] = ((cout, cin, k), "conv_w")
+
+    wn_conv("input_projection", 1, c, 1)
+    out["residual_layer.fc_t1.weight"] = ((cfg.dim_mid, cfg.dim_in), "linear_w")
+    out["residual_layer.fc_t1.bias"] = ((cfg.dim_mid,), "bias")
+    out["residual_layer.fc_t2.weight"] = ((cfg.dim_out, cfg.dim_mid), "linear_w")
+    out["residual_layer.fc_t2.bias"] = ((cfg.dim_out,), "bias")
+    for n in range(cfg.residual_layers):
+        pre = f"residual_layer.residual_blocks.{n}"
+        wn_conv(f"{pre}.dilated_conv", c, 2 * c, 3)
+        out[f"{pre}.diffusion_projection.weight"] = ((c, cfg.dim_out), "linear_w")
+        out[f"{pre}.diffusion_projection.bias"] = ((c,), "bias")
+        wn_conv(f"{pre}.output_projection", c, 2 * c, 1)
+    wn_conv("skip_projection", c, c, 1)
+    out["output_projection.conv.weight"] = ((1, c, 1), "conv_w")
+    out["output_projection.conv.bias"] = ((1,), "bias")
+    return out
+
+
+def generate_wavenet_weights(cfg: WaveNetConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Name-keyed deterministic weights.  ``weight_g`` is drawn so that the effective weight ``v * g / ||v||`` has the usual
+    1/sqrt(fan_in) scale per element (g = sqrt(Cout) times a name-keyed factor in [0.8, 1.2]); the zero-initialised output
+    conv (``ZeroConv1d`` wavenet.py:57-66) is random here, otherwise every output is 0 and a parity check vacuous."""
+    specs = wavenet_param_specs(cfg)
+    out = OrderedDict()
+    for k, (shape, kind) in specs.items():
+        if kind == "wn_g":
+            vshape = specs[k[:-1] + "v"][0]
+            u = generate_tensor(k, (1,), "embed", seed).clamp(-2, 2)[0]
+            out[k] = (vshape[0] ** 0.5) * (1.0 + 0.1 * u)
+        else:
+            out[k] = generate_tensor(k, shape, kind, seed)
+    return out

@@ -10,6 +10,10 @@
  *                                     DPM2Sampler.forward (src/models/components/sampler_edm.py:371-397, :284-300,
  *                                     :710-768, :470-493) and ADPM2Sampler.forward (stochastic_sampler_edm.py:85-100)
  *   the call site all of them sit behind: src/models/diffunet_complex_module.py:86-89
+ *   adf_wavenet_create             <- WaveNetNoise.__init__ (src/models/backbones/wavenet.py:153-167); the handle it returns goes
+ *                                     through the same entry points: adf_load_weight (the module's state_dict keys, incl. the
+ *                                     custom WeightNorm's weight_g / weight_v, wavenet.py:15-55), adf_net_forward
+ *                                     <- WaveNetNoise.forward (wavenet.py:169-180), adf_denoise / adf_sampler_run as above
  *
  * Conventions
  *   - every function returns 0 on success, non-zero on failure; adf_last_error() gives the message.
@@ -80,9 +84,21 @@ typedef struct adf_sampler_desc {
     int32_t eps_pred;          /* DPM (both kinds): 1 = the reference's x0_pred=False (noise prediction, :700-706) */
 } adf_sampler_desc;
 
+/* Hyper-parameters of WaveNetNoise (wavenet.py:154-157) and of the ResidualGroup it builds (:120: dim_in 128, dim_mid 512,
+ * dim_out 512; ResidualBlock's Linear(512, C) fixes dim_out = 512 in the reference). */
+typedef struct adf_wavenet_config {
+    int32_t residual_channels, residual_layers, dilation_cycle;
+    int32_t dim_in, dim_mid, dim_out;
+    int32_t dtype;                          /* ADF_DTYPE_*; BF16 (MFMA kernels) needs residual_channels = 256 */
+} adf_wavenet_config;
+
 typedef struct adf_handle adf_handle;
 
 int adf_create(const adf_net_config* cfg, adf_handle** out);
+/* A WaveNetNoise handle.  x / out of adf_net_forward, adf_denoise, adf_sampler_run are [B][1][T] (the reference's forward takes
+ * audio [B][T] and returns [B][1][T]: same memory); any T >= 1.  Debug taps: "y<n>" = input of residual layer n including its
+ * diffusion-step addend (kept while all of them fit 256 MiB), "skip" = the normalised skip sum. */
+int adf_wavenet_create(const adf_wavenet_config* cfg, adf_handle** out);
 void adf_destroy(adf_handle* h);
 const char* adf_last_error(const adf_handle* h);   /* h may be NULL: error of the last failed adf_create */
 

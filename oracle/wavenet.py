@@ -18,89 +18,22 @@ embedding and all accumulations stay fp32.
 from __future__ import annotations
 
 import math
-from collections import OrderedDict
-from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
 
-from audiodiffuser_amd.weights import generate_tensor
+from audiodiffuser_amd.config import WaveNetConfig, config_c5, config_c5_small
+from audiodiffuser_amd.weights import wavenet_param_specs, generate_wavenet_weights
 from .unet1d import Storage, FP32, rel_l2
 
 P = Dict[str, torch.Tensor]
 Spec = Tuple[Tuple[int, ...], str]
 
 
-@dataclass
-class WaveNetConfig:
-    """Constructor arguments of ``WaveNetNoise`` (:154-157), same names and defaults.  The embedding widths
-    (128 -> 512 -> 512) are the defaults of ``ResidualGroup`` (:120) and the literal 512 of ``ResidualBlock`` (:103)."""
-    residual_channels: int = 256
-    residual_layers: int = 36
-    dilation_cycle: int = 12
-    dim_in: int = 128
-    dim_mid: int = 512
-    dim_out: int = 512
-
-    def to_kwargs(self) -> dict:
-        return dict(residual_channels=self.residual_channels, residual_layers=self.residual_layers,
-                    dilation_cycle=self.dilation_cycle)
-
-    def dilation(self, n: int) -> int:
-        """:131-134"""
-        return 2 ** (n % self.dilation_cycle)
-
-
-def config_c5() -> WaveNetConfig:
-    return WaveNetConfig()
-
-
-def config_c5_small() -> WaveNetConfig:
-    return WaveNetConfig(residual_channels=32, residual_layers=6, dilation_cycle=3)
-
-
-def param_specs(cfg: WaveNetConfig) -> "OrderedDict[str, Spec]":
-    """Every ``WaveNetNoise.state_dict()`` key in registration order.  The custom ``WeightNorm`` (:15-55) deletes
-    ``weight`` and registers a 0-dim ``weight_g`` (the norm of the WHOLE tensor, :29) and ``weight_v`` after ``bias``."""
-    out: "OrderedDict[str, Spec]" = OrderedDict()
-    c = cfg.residual_channels
-
-    def wn_conv(pre, cin, cout, k):
-        out[f"{pre}.conv.module.bias"] = ((cout,), "bias")
-        out[f"{pre}.conv.module.weight_g"] = ((), "wn_g")
-        out[f"{pre}.conv.module.weight_v"] = ((cout, cin, k), "conv_w")
-
-    wn_conv("input_projection", 1, c, 1)
-    out["residual_layer.fc_t1.weight"] = ((cfg.dim_mid, cfg.dim_in), "linear_w")
-    out["residual_layer.fc_t1.bias"] = ((cfg.dim_mid,), "bias")
-    out["residual_layer.fc_t2.weight"] = ((cfg.dim_out, cfg.dim_mid), "linear_w")
-    out["residual_layer.fc_t2.bias"] = ((cfg.dim_out,), "bias")
-    for n in range(cfg.residual_layers):
-        pre = f"residual_layer.residual_blocks.{n}"
-        wn_conv(f"{pre}.dilated_conv", c, 2 * c, 3)
-        out[f"{pre}.diffusion_projection.weight"] = ((c, 512), "linear_w")
-        out[f"{pre}.diffusion_projection.bias"] = ((c,), "bias")
-        wn_conv(f"{pre}.output_projection", c, 2 * c, 1)
-    wn_conv("skip_projection", c, c, 1)
-    out["output_projection.conv.weight"] = ((1, c, 1), "conv_w")
-    out["output_projection.conv.bias"] = ((1,), "bias")
-    return out
-
-
-def generate_weights(cfg: WaveNetConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
-    """Name-keyed deterministic weights.  ``weight_g`` is drawn so that the effective weight has the usual
-    1/sqrt(fan_in) scale per element (g = sqrt(Cout), times a name-keyed factor in [0.8, 1.2]); the zero-initialised output
-    conv (``ZeroConv1d`` :57-66) is random here, otherwise every output is 0 and parity vacuous."""
-    out = OrderedDict()
-    for k, (shape, kind) in param_specs(cfg).items():
-        if kind == "wn_g":
-            vshape = param_specs(cfg)[k[:-1] + "v"][0]
-            u = generate_tensor(k, (1,), "embed", seed).clamp(-2, 2)[0]
-            out[k] = (vshape[0] ** 0.5) * (1.0 + 0.1 * u)
-        else:
-            out[k] = generate_tensor(k, shape, kind, seed)
-    return out
+# configuration, state-dict layout and the name-keyed weight generator live in the package (the plugin needs them too)
+param_specs = wavenet_param_specs
+generate_weights = generate_wavenet_weights
 
 
 # ------------------------------------------------------------------ pieces

@@ -2,24 +2,50 @@
 # Runs ON the GPU box (gpurun): produces the small summaries that get committed under profiles/ (named per round).
 # usage: tools/collect_profiles.sh r01      -> gpurun_out/profiles_r01/*
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-echo "[1/5] bench.py"; timeout -k 10 400 python bench.py --steps 2 --warmup 1 2>/dev/null | tail -1 > $out/${tag}_bench.json || exit 1
-echo "[2/5] kernel trace of bench.py"; rm -rf /tmp/p1
+echo "[1/9] bench.py"; timeout -k 10 400 python bench.py --steps 2 --warmup 1 2>/dev/null | tail -1 > $out/${tag}_bench.json || exit 1
+echo "[2/9] kernel trace of bench.py"; rm -rf /tmp/p1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/p1.log 2>&1 || { tail -5 /tmp/p1.log; exit 1; }
 cp $(ls /tmp/p1/*/*kernel_stats.csv | head -1) $out/${tag}_bench_kernel_stats.csv
 python3 tools/trace_summary.py $(ls /tmp/p1/*/*kernel_trace.csv | head -1) 198 --grid | sed "s#/tmp/p1/[^ ]*#rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline#" > $out/${tag}_bench_per_nfe_summary.txt
-echo "[3/5] kernel trace of the resblock replay"; rm -rf /tmp/p2
+echo "[3/9] kernel trace of the resblock replay"; rm -rf /tmp/p2
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python3 bench.py --roofline-only --roofline-iters 50 > /tmp/p2.log 2>&1 || { tail -5 /tmp/p2.log; exit 1; }
 cp $(ls /tmp/p2/*/*kernel_stats.csv | head -1) $out/${tag}_roofline_replay_kernel_stats.csv
 ADF_BENCH_VERBOSE=1 timeout -k 10 300 python bench.py --roofline-only --roofline-iters 50 2>/dev/null | tail -1 > $out/${tag}_roofline_replay.json
-echo "[4/5] PMC FETCH_SIZE (resblock replay, conv_gemm kernels)"; rm -rf /tmp/p3 /tmp/p4
+echo "[4/9] PMC FETCH_SIZE (resblock replay, conv_gemm kernels)"; rm -rf /tmp/p3 /tmp/p4
 timeout -k 10 400 rocprofv3 --kernel-trace --kernel-include-regex "conv_gemm" --pmc FETCH_SIZE --output-format csv -d /tmp/p3 -- python3 bench.py --roofline-only --roofline-iters 2 > /tmp/p3.log 2>&1 || { tail -5 /tmp/p3.log; exit 1; }
-echo "[5/5] PMC WRITE_SIZE"
+echo "[5/9] PMC WRITE_SIZE"
 timeout -k 10 400 rocprofv3 --kernel-trace --kernel-include-regex "conv_gemm" --pmc WRITE_SIZE --output-format csv -d /tmp/p4 -- python3 bench.py --roofline-only --roofline-iters 2 > /tmp/p4.log 2>&1 || { tail -5 /tmp/p4.log; exit 1; }
 { echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --roofline-only --roofline-iters 2"
   echo "# per kernel variant and grid: mean of the last 3 dispatches, KB as reported (gfx950: double FETCH_SIZE for 16 B/lane streaming reads)"
   PMC_MIN_GRID=1 PMC_PAIRS=1 python3 tools/pmc_summary.py /tmp/p3 /tmp/p4; } > $out/${tag}_pmc_fetch_write_summary.txt
+echo "[6/9] per-launch layer table (route lines matched with the kernel trace)"; rm -rf /tmp/lt
+ADF_GEMM_TRACE=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -- python3 bench.py --steps 1 --warmup 0 --num-steps 2 --no-graph --no-cpu-baseline --no-pmc --no-precision-check > /tmp/lt.log 2> /tmp/lt.err || { tail -5 /tmp/lt.err; exit 1; }
+{ echo "# ADF_GEMM_TRACE=1 rocprofv3 --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --num-steps 2 --no-graph (C2, B = 64, L = 16384, bf16)"
+  python3 tools/layer_table.py /tmp/lt /tmp/lt.err; } > $out/${tag}_layer_table.txt || exit 1
+echo "[7/9] SQ counters of the rb kernel (resblock replay)"
+rm -rf gpurun_out/pmc_sq; bash tools/pmc_sq.sh gpurun_out/pmc_sq rb_kernel > /tmp/sq.log 2>&1; cp gpurun_out/pmc_sq/sq_counters.txt $out/${tag}_rb_kernel_sq_counters.txt
+echo "[8/9] attention PMC (C3, DPM)"; rm -rf /tmp/pa
+timeout -k 10 400 rocprofv3 --kernel-trace --kernel-include-regex attention_mfma32 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pa -- python3 bench.py --config c3 --sampler dpm --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-pmc --no-precision-check > /tmp/pa.log 2>&1 || { tail -5 /tmp/pa.log; exit 1; }
+python3 - > $out/${tag}_attention_pmc_raw.txt <<'PY'
+import csv, glob, collections
+f = glob.glob('/tmp/pa/*/*counter_collection.csv')[0]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    agg[r['Grid_Size']][r['Counter_Name']].append(float(r['Counter_Value']))
+for g, c in sorted(agg.items(), key=lambda kv: -int(kv[0])):
+    print('grid', g, ' '.join(f"{k} {sum(v)/len(v):,.0f}" for k, v in c.items()), ' n=%d' % max(len(v) for v in c.values()))
+t = glob.glob('/tmp/pa/*/*kernel_trace.csv')
+if t:
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(t[0])):
+        d[r['Grid_Size_X'] if 'Grid_Size_X' in r else r['Grid_Size']].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    for g, v in sorted(d.items(), key=lambda kv: -int(kv[0])):
+        print(f"grid_x {g}: {len(v)} launches, mean {sum(v)/len(v):.1f} us (under counter collection)")
+PY
+echo "[9/9] C3 bench line"
+timeout -k 10 400 python bench.py --config c3 --sampler dpm --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_c3_dpm.json
 ls -la $out

@@ -1,14 +1,15 @@
 #!/bin/bash
 # Runs ON the GPU box: SQ / SQC counters of the DMA kernel launches of the resblock replay, one rocprofv3 pass per
-# counter group (a pass with an unknown counter name fails alone).  usage: tools/pmc_sq.sh outdir
+# counter group (a pass with an unknown counter name fails alone).  usage: tools/pmc_sq.sh outdir [kernel regex]
 out=${1:-gpurun_out/pmc_sq}; mkdir -p $out
+kre=${2:-rb_kernel}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1)); rm -rf /tmp/pq$i
   echo "[pass $i] $grp"
-  timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "pp_kernel" --pmc $grp --output-format csv -d /tmp/pq$i -- python3 bench.py --roofline-only --roofline-iters 2 > /tmp/pq$i.log 2>&1 || { echo "pass $i failed"; tail -3 /tmp/pq$i.log; continue; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "$kre" --pmc $grp --output-format csv -d /tmp/pq$i -- python3 bench.py --roofline-only --roofline-iters 2 > /tmp/pq$i.log 2>&1 || { echo "pass $i failed"; tail -3 /tmp/pq$i.log; continue; }
   PMC_MIN_GRID=1 python3 tools/pmc_summary.py /tmp/pq$i | grep "131072" >> $out/sq_counters.txt
 done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA

@@ -26,11 +26,12 @@ for key, o in out.items():
 # distinct (FETCH_SIZE, WRITE_SIZE) pairs of the persistent DMA kernel, one per layer shape (PMC_PAIRS=1)
 import os
 if os.environ.get("PMC_PAIRS") and len(sys.argv) >= 3:
-    f = {k: e for k, e in load(sys.argv[1]).items() if 'pp_kernel' in e['name']}
-    w = {k: e for k, e in load(sys.argv[2]).items() if 'pp_kernel' in e['name']}
+    dma = lambda e: 'pp_kernel' in e['name'] or 'rb_kernel' in e['name']
+    f = {k: e for k, e in load(sys.argv[1]).items() if dma(e)}
+    w = {k: e for k, e in load(sys.argv[2]).items() if dma(e)}
     pairs = collections.Counter()
     for (kf, ef), (kw, ew) in zip(f.items(), w.items()):      # same launch order in both passes
         pairs[(round(ef.get('FETCH_SIZE', 0) / 256) * 256, round(ew.get('WRITE_SIZE', 0) / 256) * 256)] += 1
-    print("# conv_gemm_pp_kernel dispatches by (FETCH_SIZE KB, WRITE_SIZE KB), rounded to 256 KB: count")
+    print("# conv_gemm_pp_kernel / conv_gemm_rb_kernel dispatches by (FETCH_SIZE KB, WRITE_SIZE KB), rounded to 256 KB: count")
     for k, v in sorted(pairs.items()):
         print(k, v, " HBM bytes/launch = 2*FETCH + WRITE = %.1f MB" % ((2 * k[0] + k[1]) * 1024 / 1e6))
