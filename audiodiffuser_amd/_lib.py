@@ -80,6 +80,8 @@ EXPORTS = {
                                      C.c_void_p]),
     "adf_bench_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]),
+    "adf_bench_wavenet_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

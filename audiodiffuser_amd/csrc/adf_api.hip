@@ -102,6 +102,8 @@ struct Plan {
     unsigned long long last_use = 0;
     // timing replay buffers of adf_bench_resblock (rotating copies of one layer's operands), sized on first use
     char* bench_buf = nullptr; size_t bench_cap = 0;
+    // WaveNetNoise: the layer launches of the last pass, for adf_bench_wavenet_layer
+    WnIO wn_io; std::vector<WnLayerArgs> wn_layers;
 };
 constexpr size_t kMaxGraphsPerPlan = 8;
 constexpr size_t kMaxPlans = 4;      // (B, L) workspaces kept per handle; the least recently used one is released beyond that
@@ -832,7 +834,7 @@ int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     const adf_wavenet_config& c = w.cfg;
     Walker W{h, p, s};
     p->arena_off = 0; p->stats_off = 0;
-    p->taps.clear(); p->rbs.clear();
+    p->taps.clear(); p->rbs.clear(); p->wn_layers.clear();
     const int B = p->B, T = p->L, C = c.residual_channels, NL = c.residual_layers;
     const size_t act = (size_t)B * T * C * h->esz;
     // every layer input stays resident when that is small (the parity taps y<n>); otherwise two buffers alternate
@@ -860,8 +862,10 @@ int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         a.n = n; a.first = n == 0 ? 1 : 0;
         a.dilation = 1 << (n % c.dilation_cycle);
         if (keep) p->taps.push_back({"y" + std::to_string(n), (void*)a.y, C, T});
+        p->wn_layers.push_back(a);
         W.check(launch_wn_layer(wio, a, s));
     }
+    p->wn_io = wio;
     WnFinalArgs f;
     f.skip = skip; f.skip_scale = (float)std::sqrt(1.0 / (double)NL);
     f.w_sp = w.sp.packed; f.b_sp = w.sp.bias; f.w_out = w.out_w; f.b_out = w.out_b;
@@ -1829,6 +1833,35 @@ int adf_bench_layer(adf_handle* h, int B, int L, int level, int conv, int iters,
     double b1 = 0, b2 = 0, f1 = 0, f2 = 0;
     if (bench_resblock_impl(h, B, L, level, conv, iters, &m1, &m2, &b1, &b2, &f1, &f2, copies, stream)) return 1;
     *ms = conv == 1 ? m1 : m2; *algo_bytes = conv == 1 ? b1 : b2; *flops = conv == 1 ? f1 : f2;
+    return 0;
+}
+
+int adf_bench_wavenet_layer(adf_handle* h, int B, int T, int layer, int iters, float* ms, double* algo_bytes, double* flops, void* stream) {
+    ADF_ON_DEVICE(h);
+    if (!h->wn) return fail(h, "adf_bench_wavenet_layer: not a WaveNetNoise handle");
+    hipStream_t s = (hipStream_t)stream;
+    Plan* p;
+    if (get_plan(h, B, T, s, &p)) return 1;
+    if (layer < 0 || layer >= (int)p->wn_layers.size()) return fail(h, "adf_bench_wavenet_layer: layer out of range (run a forward first)");
+    if (iters < 1) return fail(h, "adf_bench_wavenet_layer: iters must be positive");
+    const WnLayerArgs& a = p->wn_layers[layer];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(h, "hipEventCreate failed");
+    const char* err = nullptr;
+    for (int i = 0; i < 2 && !err; ++i) err = launch_wn_layer(p->wn_io, a, s);
+    if (!err && hipEventRecord(e0, s) != hipSuccess) err = "hipEventRecord failed";
+    for (int i = 0; i < iters && !err; ++i) err = launch_wn_layer(p->wn_io, a, s);
+    if (!err && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) err = "event sync failed";
+    float t = 0.f;
+    if (!err && hipEventElapsedTime(&t, e0, e1) != hipSuccess) err = "hipEventElapsedTime failed";
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err) return fail(h, err);
+    const double C = h->wn->cfg.residual_channels, pos = (double)B * T, esz = h->esz;
+    *ms = t / (float)iters;
+    // per position: read y, write y_next (not for the last layer), skip read-modify-write in fp32 (first layer: write only);
+    // per launch: both weight matrices once.  Flops: the K = 3C and K = C GEMMs onto 2C columns each.
+    *algo_bytes = pos * C * (esz + (a.y_next ? esz : 0.0) + (a.first ? 4.0 : 8.0)) + 8.0 * C * C * esz;
+    *flops = pos * 2.0 * 8.0 * C * C;
     return 0;
 }
 

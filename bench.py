@@ -39,7 +39,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WORKLOADS = {"c1": "BASELINE configs[0] network", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2]", "tiny": "unit-test network"}
+WORKLOADS = {"c1": "BASELINE configs[0] network", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2]", "tiny": "unit-test network",
+             "c5": "BASELINE configs[4]"}
+# per-config defaults of --batch (per GPU), --length, --num-steps: c5 = 1024 waveforms over 8 GPUs, 22050 samples, 6-step sampler
+DEFAULTS = {"c5": (128, 22050, 6)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 SURVEY_REFERENCE_CONFIG1_S = 3.81    # the reference itself, config 1, in the build container (8 threads)
@@ -50,11 +53,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "tiny"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "tiny", "c5"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=64, help="waveforms per GPU")
-    ap.add_argument("--length", type=int, default=16384)
-    ap.add_argument("--num-steps", type=int, default=50, help="sigma schedule length N (Heun => 2N-1 NFE)")
+    ap.add_argument("--batch", type=int, default=None, help="waveforms per GPU (default 64; c5: 128)")
+    ap.add_argument("--length", type=int, default=None, help="samples per waveform (default 16384; c5: 22050)")
+    ap.add_argument("--num-steps", type=int, default=None, help="sigma schedule length N (Heun => 2N-1 NFE; default 50; c5: 6)")
     ap.add_argument("--sampler", default=None, choices=["heun", "dpm"], help="default: heun, dpm for --config c3")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -65,6 +68,10 @@ def parse(argv=None):
     ap.add_argument("--roofline-level", type=int, default=-1, help="with --roofline-only: replay this resblock only")
     ap.add_argument("--roofline-conv", type=int, default=0, choices=[0, 1, 2], help="with --roofline-level: only conv1 / conv2 of the block")
     a = ap.parse_args(argv)
+    db, dl, dn = DEFAULTS.get(a.config, (64, 16384, 50))
+    a.batch = db if a.batch is None else a.batch
+    a.length = dl if a.length is None else a.length
+    a.num_steps = dn if a.num_steps is None else a.num_steps
     if a.sampler is None:
         a.sampler = "dpm" if a.config == "c3" else "heun"
     return a
@@ -154,6 +161,44 @@ def roofline(hd, batch, length, dtype, iters, device):
     return out
 
 
+def wavenet_rows(hd, batch, length, iters, device, layers):
+    """HIP-event replay of residual-layer launches of the last WaveNetNoise pass (adf_bench_wavenet_layer)."""
+    import torch
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rows = []
+    for n in layers:
+        ms, by, fl = C.c_float(), C.c_double(), C.c_double()
+        rc = hd.lib.adf_bench_wavenet_layer(hd.h, batch, length, n, iters, C.byref(ms), C.byref(by), C.byref(fl), C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("adf_bench_wavenet_layer: " + hd.lib.adf_last_error(hd.h).decode())
+        rows.append({"layer": n, "ms": ms.value, "bytes": by.value, "flops": fl.value})
+    return rows
+
+
+def wavenet_roofline(hd, cfg, batch, length, dtype, iters, device):
+    """The residual-layer kernel (36 of the 40 launches of a pass, > 99 % of its flops): dilations 1 / 32 / 2048 and the last
+    layer replayed with HIP events; the slowest is reported against the roofline that bounds it."""
+    layers = sorted({0, min(5, cfg.residual_layers - 1), min(cfg.dilation_cycle - 1, cfg.residual_layers - 1), cfg.residual_layers - 1})
+    rows = wavenet_rows(hd, batch, length, iters, device, layers)
+    mid = [r for r in rows if 0 < r["layer"] < cfg.residual_layers - 1] or rows
+    dom = max(mid, key=lambda r: r["ms"])
+    ai = dom["flops"] / dom["bytes"]
+    ridge = MFMA_PEAK_TFLOPS[dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+    gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    tfs = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    out = {"bound": "hbm" if ai < ridge else "mfma", "kernel": f"fused WaveNet residual layer (layer {dom['layer']}, dilation {cfg.dilation(dom['layer'])})",
+           "definition": "slowest of the replayed residual-layer launches: algorithmic bytes (y read + y_next write in the storage type, fp32 skip "
+                         "read-modify-write, both weight matrices once) and flops (K = 3C and K = C GEMMs onto 2C columns) / mean duration, HIP events",
+           "level": dom["layer"], "conv": 0, "ms_per_launch": dom["ms"], "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"],
+           "flop_per_byte": ai, "ridge_flop_per_byte": ridge, "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_TFLOPs": tfs,
+           "mfma_frac": tfs / MFMA_PEAK_TFLOPS[dtype], "rows": rows, "traffic": None}
+    if out["bound"] == "hbm":
+        out.update({"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    else:
+        out.update({"achieved": tfs, "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS[dtype]})
+    return out
+
+
 def pmc_traffic(a, level: int, conv: int):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured now: two child runs of
     `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --roofline-only --roofline-level K` (FETCH_SIZE and WRITE_SIZE
@@ -179,14 +224,14 @@ def pmc_traffic(a, level: int, conv: int):
             return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
         per = {}
         for row in csv.DictReader(open(files[0])):
-            if row.get("Counter_Name") != counter or "conv_gemm" not in row.get("Kernel_Name", ""):
+            if row.get("Counter_Name") != counter or ("wn_layer" if a.config == "c5" else "conv_gemm") not in row.get("Kernel_Name", ""):
                 continue
             per.setdefault(row["Dispatch_Id"], [row["Kernel_Name"], 0.0])[1] += float(row["Counter_Value"])
         shutil.rmtree(tmp, ignore_errors=True)
         # the child's last launches are the 4 timed replays of (level, conv): the last 4 conv_gemm dispatches of the trace
         seq = [v for _, v in sorted(per.items(), key=lambda kv: int(kv[0]))]
         if len(seq) < 4:
-            return None, f"no conv_gemm dispatch in the {counter} pass"
+            return None, f"no matching dispatch in the {counter} pass"
         tail = seq[-4:]
         if len({nm for nm, _ in tail}) != 1:
             return None, f"the {counter} pass ended on mixed kernels"
@@ -240,16 +285,24 @@ def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
     prev = torch.get_num_threads()
     out = {"unit": "audio-samples/s", "kind": "port", "cpu_model": cpu_model(), "physical_cores": cores}
     try:
-        w = generate_weights(cfg, seed=0)
-        fn = E.make_denoiser(w, cfg, 0.2)
-        b = 2
+        if isinstance(cfg, A.WaveNetConfig):
+            from audiodiffuser_amd.weights import generate_wavenet_weights
+            from oracle import wavenet as OW
+            w = generate_wavenet_weights(cfg, seed=0)
+            wnet = OW.wavenet_net(w, cfg)
+            fn = lambda xx, sigma=None, sigmas=None: E.denoise(wnet, xx, 0.2, sigma=sigma, sigmas=sigmas)
+        else:
+            w = generate_weights(cfg, seed=0)
+            fn = E.make_denoiser(w, cfg, 0.2)
+        heavy = isinstance(cfg, A.WaveNetConfig)       # 0.83 TFLOP per waveform and evaluation: a smaller sample keeps the leg bounded
+        b = 1 if heavy else 2
         x = generate_noise(0, b, length) * 3.0
         reps = []
         with torch.no_grad():
             # torch's CPU convolutions do not scale to every core of a large host (oversubscription): give the CPU its best
             # thread count -- one evaluation at each candidate after a warm-up, keep the fastest
             scan = {}
-            for k in sorted({min(c, cores) for c in (8, 16, 32, 64, cores)}):
+            for k in sorted({min(c, cores) for c in ((16, 64) if heavy else (8, 16, 32, 64, cores))}):
                 torch.set_num_threads(k)
                 fn(x, sigma=torch.tensor(3.0))
                 t0 = time.perf_counter()
@@ -259,17 +312,21 @@ def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
             torch.set_num_threads(best_k)
             out["thread_scan_s_per_evaluation"] = scan
             fn(x, sigma=torch.tensor(3.0))           # warm-up
+            per = 1 if heavy else 3
             for rep in range(3):
                 t0 = time.perf_counter()
-                for i in range(3):
+                for i in range(per):
                     fn(x, sigma=torch.tensor(3.0 / (3 * rep + i + 1)))
-                reps.append((time.perf_counter() - t0) / 3)
+                reps.append((time.perf_counter() - t0) / per)
         dt = statistics.median(reps)
         wps = b / (dt * nfe_per_waveform)
         out.update({"value": wps * length, "waveforms_per_s": wps, "cores": best_k,
-                    "sample": f"same network and sampler as the GPU line: oracle denoiser at batch {b}, 1 warm-up + 3 x 3 evaluations, median "
+                    "sample": f"same network and sampler as the GPU line: oracle denoiser at batch {b}, 1 warm-up + 3 x {per} evaluations, median "
                               f"{dt:.3f} s per evaluation (repeats {', '.join('%.3f' % r for r in reps)}), scaled to {nfe_per_waveform} evaluations per waveform"})
         del w, fn
+        if isinstance(cfg, A.WaveNetConfig):
+            out["gpu_over_cpu_same_workload"] = gpu_value / out["value"] if out.get("value") else None
+            return out
         # ---- SURVEY.md 8(d) protocol on configs[0] ------------------------------------------------------------------
         c1 = A.config_c1()
         w1 = generate_weights(c1, seed=0)
@@ -362,9 +419,18 @@ def main():
     from audiodiffuser_amd.weights import generate_weights
     from audiodiffuser_amd.distributed import rank_noise, gather_samples
 
-    cfg = A.PRESETS[a.config]()
-    net = A.UNet1dBase.from_config(cfg, compute_dtype=a.dtype)
-    net.load_state_dict(generate_weights(cfg, seed=0))     # every rank regenerates the same weights
+    wavenet = a.config == "c5"
+    if wavenet:
+        from audiodiffuser_amd.weights import generate_wavenet_weights
+        cfg = A.config_c5()
+        make_net = lambda dt: A.WaveNetNoise.from_config(cfg, compute_dtype=dt)
+        make_weights = lambda: generate_wavenet_weights(cfg, seed=0)
+    else:
+        cfg = A.PRESETS[a.config]()
+        make_net = lambda dt: A.UNet1dBase.from_config(cfg, compute_dtype=dt)
+        make_weights = lambda: generate_weights(cfg, seed=0)
+    net = make_net(a.dtype)
+    net.load_state_dict(make_weights())     # every rank regenerates the same weights
     net = net.to(device)
     diff = A.EluDiffusion(sigma_data=0.2)
     sigmas = A.KarrasSchedule(0.002, 80.0, 7.0, a.num_steps)()
@@ -385,7 +451,10 @@ def main():
     if a.roofline_only:
         net(noise[:a.batch], torch.zeros(a.batch, device=device))
         torch.cuda.synchronize()
-        rows = replay_rows(hd, a.batch, a.length, a.roofline_iters, device, a.roofline_level, a.roofline_conv)
+        if wavenet:
+            rows = wavenet_rows(hd, a.batch, a.length, a.roofline_iters, device, [max(a.roofline_level, 0)])
+        else:
+            rows = replay_rows(hd, a.batch, a.length, a.roofline_iters, device, a.roofline_level, a.roofline_conv)
         print(json.dumps({"rows": rows}))
         return
 
@@ -412,7 +481,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "waveforms_per_s": waveforms / dt, "nfe_per_waveform": nfe, "finite": finite, "clamped": clamped,
         "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-        "config": {"workload": f"{WORKLOADS.get(a.config, a.config)}: UNet1d {cfg.channels} ch ({a.config}), {a.length}-sample waveforms, "
+        "config": {"workload": f"{WORKLOADS.get(a.config, a.config)}: " + (f"WaveNetNoise {cfg.residual_layers} x {cfg.residual_channels} ch (unconditional, as the reference class is)"
+                                                                            if wavenet else f"UNet1d {cfg.channels} ch") + f" ({a.config}), {a.length}-sample waveforms, "
                                f"KarrasSchedule N={a.num_steps} {a.sampler}, batch {a.batch}/GPU, random-init weights",
                    "global_batch": global_batch, "sampler": a.sampler, "num_steps": a.num_steps, "nfe": nfe,
                    "hipgraph": not a.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
@@ -420,7 +490,8 @@ def main():
     if rank == 0:
         net(noise[:a.batch], torch.zeros(a.batch, device=device))       # one eager pass: the replay reads its operands
         torch.cuda.synchronize()
-        rf = roofline(hd, a.batch, a.length, a.dtype, a.roofline_iters, device)
+        rf = (wavenet_roofline(hd, cfg, a.batch, a.length, a.dtype, min(a.roofline_iters, 10), device) if wavenet
+              else roofline(hd, a.batch, a.length, a.dtype, a.roofline_iters, device))
         res["roofline"] = rf
         if rf and world == 1 and not a.no_pmc:
             traffic, detail = pmc_traffic(a, rf["level"], rf["conv"])
@@ -429,8 +500,8 @@ def main():
         if a.dtype == "bf16" and not a.no_precision_check:
             # the parity-grade (fp32) mode on the first waveforms of the same noise: what the storage precision costs the audio
             nb = min(2, a.batch)
-            net32 = A.UNet1dBase.from_config(cfg, compute_dtype="fp32")
-            net32.load_state_dict(generate_weights(cfg, seed=0))
+            net32 = make_net("fp32")
+            net32.load_state_dict(make_weights())
             net32 = net32.to(device)
             t1 = time.perf_counter()
             y32 = sampler(noise[:nb].contiguous(), fn=diff.denoise_fn, net=net32, sigmas=sigmas)
@@ -447,10 +518,11 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, a.length, nfe, value)
             res["gpu_over_cpu"] = res["cpu_baseline"]["gpu_over_cpu_same_workload"]
-            g1 = gpu_config1(device)
-            res["cpu_baseline"]["config1"]["gpu_hip_fp32"] = g1
-            best = max(v["waveforms_per_s"] for key, v in res["cpu_baseline"]["config1"].items() if key.startswith("threads_"))
-            res["cpu_baseline"]["config1"]["gpu_over_cpu"] = g1["waveforms_per_s"] / best      # against the FASTER of the two thread counts
+            if "config1" in res["cpu_baseline"]:
+                g1 = gpu_config1(device)
+                res["cpu_baseline"]["config1"]["gpu_hip_fp32"] = g1
+                best = max(v["waveforms_per_s"] for key, v in res["cpu_baseline"]["config1"].items() if key.startswith("threads_"))
+                res["cpu_baseline"]["config1"]["gpu_over_cpu"] = g1["waveforms_per_s"] / best      # against the FASTER of the two thread counts
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

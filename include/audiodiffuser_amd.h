@@ -155,6 +155,11 @@ int adf_bench_resblock(adf_handle* h, int B, int L, int level, int iters, float*
 int adf_bench_layer(adf_handle* h, int B, int L, int level, int conv, int iters, float* ms, double* algo_bytes, double* flops,
                     int* copies, void* stream);
 
+/* WaveNetNoise handles: residual layer `layer` of the last pass replayed `iters` times (after 2 untimed launches) with HIP events
+ * on `stream`.  The working set of one launch at bench sizes (y, y_next, fp32 skip sum: > 5 GB at B = 128, T = 22050) is far beyond
+ * the 256 MiB Infinity Cache, so no operand rotation is needed. */
+int adf_bench_wavenet_layer(adf_handle* h, int B, int T, int layer, int iters, float* ms, double* algo_bytes, double* flops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
