@@ -17,6 +17,18 @@
 #include "adf_wavenet.h"
 #include <type_traits>
 
+#ifdef ADF_WN_STAMP
+// diagnostic build (tools/build_variant.sh wnstamp -DADF_WN_STAMP; tools/wn_stamps.py): s_memtime at the phase boundaries of the
+// bf16 layer kernel, all 8 waves of one workgroup in the middle of the grid
+namespace adf { __device__ unsigned long long adf_wn_stamps[8 * 16]; }
+extern "C" int adf_debug_wn_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adf::adf_wn_stamps), sizeof(unsigned long long) * 8 * 16);
+}
+#define WN_STAMP(i) do { if (stamped && lane == 0) adf_wn_stamps[wave * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WN_STAMP(i) do { } while (0)
+#endif
+
 namespace adf {
 
 typedef float f32x4_vec __attribute__((ext_vector_type(4)));
@@ -218,21 +230,20 @@ __device__ __forceinline__ float wn_sigmoid(float v) { return __builtin_amdgcn_r
 __device__ __forceinline__ float wn_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f)); }
 
 // The MFMA stage shared by the layer kernel and the final kernel: a wave accumulates NN column tiles of 32 (columns nbase[j] + r)
-// over KS K steps of 16 channels; A fragments from LDS (window `tap` of `TMR` rows at pitch PA), W fragments from the
+// over KS K steps of 16 channels; A fragments from LDS (tap k starts `tap_rows` rows after tap k - 1, pitch PA), W fragments from the
 // fragment-major global copy [K step][half][NCOLS][8], DEPTH steps ahead in a register ring.
 template <int C, int TM>
 struct WnTile {
     static constexpr int PA = C * 2 + 16;              // LDS row pitch: conflict-free 16-byte fragment reads (see adf_gemm.h)
     static constexpr int MT = TM / 32;
     static constexpr int SPT = C / 16;                 // K steps per tap
-    static constexpr int DEPTH = 7, RING = 8;
 };
 
-template <int C, int TM, int NCOLS, int NN, int TAPS>
+template <int C, int TM, int NCOLS, int NN, int TAPS, int RING = 8>
 __device__ __forceinline__ void wn_gemm(const char* __restrict__ A, const void* __restrict__ W, const int (&nbase)[NN],
-                                        wn_f32x16_t (&acc)[NN][TM / 32], int r, int hh) {
+                                        wn_f32x16_t (&acc)[NN][TM / 32], int r, int hh, int tap_rows = TM) {
     using Tl = WnTile<C, TM>;
-    constexpr int PA = Tl::PA, MT = Tl::MT, SPT = Tl::SPT, DEPTH = Tl::DEPTH, RING = Tl::RING;
+    constexpr int PA = Tl::PA, MT = Tl::MT, SPT = Tl::SPT, DEPTH = RING - 1;
     constexpr int KS = TAPS * SPT;
     static_assert(KS % RING == 0 && KS > DEPTH, "K steps must fill whole ring trips");
     const char* wl[NN];
@@ -244,7 +255,7 @@ __device__ __forceinline__ void wn_gemm(const char* __restrict__ A, const void* 
     auto afrag = [&](int ks, wn_bf16x8_t (&af)[MT]) __attribute__((always_inline)) {
         const int tap = ks / SPT, q = ks - tap * SPT;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const wn_bf16x8_t*)(A + ((size_t)tap * TM + i * 32 + r) * PA + q * 32 + hh * 16);
+        for (int i = 0; i < MT; ++i) af[i] = *(const wn_bf16x8_t*)(A + ((size_t)tap * tap_rows + i * 32 + r) * PA + q * 32 + hh * 16);
     };
     wn_bf16x8_t wf[NN][RING];
 #pragma unroll
@@ -289,17 +300,35 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * TM;
     const bf16_t* const yb = y + (size_t)b * Tn * C;
+#ifdef ADF_WN_STAMP
+    const bool stamped = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2;
+#endif
+    WN_STAMP(0);
 
     // ---- stage the three windows (zero outside the sample: the conv's padding of y) and the parameters --------------------
+    // All loads of a thread are issued before its first LDS store (a load -> store loop pays the memory latency per trip:
+    // 6 us of a 38 us tile in the first version of this kernel).
     constexpr int CPR = C / 8;
-    for (int idx = tid; idx < 3 * TM * CPR; idx += 512) {
-        const int tap = idx / (TM * CPR), rem = idx - tap * TM * CPR;
-        const int i = rem / CPR, cc = rem - i * CPR;
-        const int t = t0 + i + (tap - 1) * dil;
-        const bool in = t >= 0 && t < Tn;
-        u32x4_t v = *(const u32x4_t*)(yb + (size_t)(in ? t : 0) * C + cc * 8);
-        if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
-        *(u32x4_t*)(bufA + ((size_t)tap * TM + i) * PA + cc * 16) = v;
+    constexpr int NST = 3 * TM * CPR / 512;
+    {
+        u32x4_t sv[NST];
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + k * 512;
+            const int tap = idx / (TM * CPR), rem = idx - tap * TM * CPR;
+            const int i = rem / CPR, cc = rem - i * CPR;
+            const int t = t0 + i + (tap - 1) * dil;
+            const bool in = t >= 0 && t < Tn;
+            sv[k] = *(const u32x4_t*)(yb + (size_t)(in ? t : 0) * C + cc * 8);
+            if (!in) sv[k] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + k * 512;
+            const int tap = idx / (TM * CPR), rem = idx - tap * TM * CPR;
+            const int i = rem / CPR, cc = rem - i * CPR;
+            *(u32x4_t*)(bufA + ((size_t)tap * TM + i) * PA + cc * 16) = sv[k];
+        }
     }
     for (int i = tid; i < 6 * C; i += 512) {
         float v;
@@ -309,7 +338,9 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
         else v = y_next ? e[(size_t)b * e_bstride + (size_t)(n + 1) * C + (i - 5 * C)] : 0.0f;
         prm[i] = v;
     }
+    WN_STAMP(1);
     __syncthreads();
+    WN_STAMP(2);
 
     auto row_of = [&](int i, int q) __attribute__((always_inline)) -> int { return i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh; };
     const int col = wave * 32 + r;
@@ -325,6 +356,7 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
         wn_gemm<C, TM, 2 * C, 2, 3>(bufA, w1, nb2, acc, r, hh);
+        WN_STAMP(3);
         const float bg = prm[col], bf = prm[C + col];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -334,9 +366,32 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
                 *(unsigned short*)(bufG + (size_t)row_of(i, q) * PA + col * 2) = f32_to_bf16_hw(v);
             }
     }
+    WN_STAMP(4);
     __syncthreads();
+    WN_STAMP(5);
 
     // ---- GEMM 2: residual columns -> centre window in place; skip columns -> fp32 sum in HBM ------------------------------
+    // The skip tile is a read-modify-write of 64 KB per workgroup.  Its loads are issued BEFORE GEMM 2 (16-byte pieces, the
+    // latency hidden behind the MFMAs) and the accumulators reach those pieces through LDS -- the two outer windows are dead
+    // once every wave has left GEMM 1 -- so the stores are 16-byte and coalesced too.  (Element-wise `skip[..] += acc` from the
+    // accumulator layout was a chain of 32 dependent HBM round trips per lane: 17 us of a 38 us tile.)
+    constexpr int PS = C * 4 + 16;                         // fp32 row pitch of the skip tile in LDS
+    static_assert((TM / 2) * PS <= TM * PA, "half the skip tile fits one dead window");
+    constexpr int SCH = C / 4;                             // 16-byte chunks per fp32 row
+    constexpr int NSK = TM * SCH / 512;
+    auto srow = [&](int row) __attribute__((always_inline)) -> char* {
+        return bufA + (row < TM / 2 ? (size_t)row * PS : (size_t)2 * TM * PA + (size_t)(row - TM / 2) * PS);
+    };
+    float* const sg = skip + ((size_t)b * Tn + t0) * C;
+    u32x4_t sk[NSK];
+#pragma unroll
+    for (int k = 0; k < NSK; ++k) {
+        const int idx = tid + k * 512;
+        const int row = idx / SCH, cc = idx - row * SCH;
+        const bool in = !first && t0 + row < Tn;
+        sk[k] = *(const u32x4_t*)(sg + (size_t)(in ? row : 0) * C + cc * 4);
+        if (!in) sk[k] = u32x4_t{0u, 0u, 0u, 0u};
+    }
     {
         wn_f32x16_t acc[2][MT];
 #pragma unroll
@@ -346,8 +401,8 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
         wn_gemm<C, TM, 2 * C, 2, 1>(bufG, w2, nb2, acc, r, hh);
+        WN_STAMP(6);
         const float br = prm[2 * C + col], bs = prm[3 * C + col], en = prm[4 * C + col], en1 = prm[5 * C + col];
-        float* const sb = skip + ((size_t)b * Tn + t0) * C + col;
         char* const ctr = bufA + (size_t)TM * PA;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -359,33 +414,292 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
                     const float yo = bf16_to_f32(*p);
                     *p = f32_to_bf16_hw(((yo - en) + (acc[0][i][q] + br)) * 0.70710678118654752440f + en1);
                 }
-                if (t0 + row < Tn) {
-                    const float sv = acc[1][i][q] + bs;
-                    float* const sp = sb + (size_t)row * C;
-                    *sp = first ? sv : *sp + sv;
-                }
+                *(float*)(srow(row) + col * 4) = acc[1][i][q] + bs;
             }
     }
-    if (!y_next) return;
+    WN_STAMP(7);
     __syncthreads();
-    bf16_t* const ob = y_next + ((size_t)b * Tn + t0) * C;
-    for (int idx = tid; idx < TM * CPR; idx += 512) {
-        const int i = idx / CPR, cc = idx - i * CPR;
-        if (t0 + i < Tn) *(u32x4_t*)(ob + (size_t)i * C + cc * 8) = *(const u32x4_t*)(bufA + ((size_t)TM + i) * PA + cc * 16);
+    WN_STAMP(8);
+#pragma unroll
+    for (int k = 0; k < NSK; ++k) {
+        const int idx = tid + k * 512;
+        const int row = idx / SCH, cc = idx - row * SCH;
+        if (t0 + row < Tn) {
+            const f32x4_vec a = *(const f32x4_vec*)(srow(row) + cc * 16);
+            const f32x4_vec o = __builtin_bit_cast(f32x4_vec, sk[k]);
+            *(f32x4_vec*)(sg + (size_t)row * C + cc * 4) = a + o;
+        }
     }
+    if (y_next) {
+        bf16_t* const ob = y_next + ((size_t)b * Tn + t0) * C;
+#pragma unroll
+        for (int k = 0; k < TM * CPR / 512; ++k) {
+            const int idx = tid + k * 512;
+            const int i = idx / CPR, cc = idx - i * CPR;
+            if (t0 + i < Tn) *(u32x4_t*)(ob + (size_t)i * C + cc * 8) = *(const u32x4_t*)(bufA + ((size_t)TM + i) * PA + cc * 16);
+        }
+    }
+    WN_STAMP(9);
 }
+
+// The wide variant: 128 positions per workgroup (still eight waves; a wave's 32 gate + 32 filter columns x 128 rows are 2 x 4
+// accumulator tiles = 128 registers).  A weight fragment now feeds four row tiles instead of two, which halves the L2 -> CU
+// weight stream per position: the 64-position kernel spends its GEMM phases AT that stream's limit (768 KB per tile at
+// ~34 B/clk, tools/wn_stamps.py).  (A four-wave version with 4 x 4 tiles per wave in the accumulation registers was tried
+// first: hipcc spilled accumulators inside the K loop.)
+// LDS holds two 128-row buffers: taps 0 and 1 of the dilated conv are staged into X and G, tap 2 waits in registers and
+// replaces tap 0 once every wave has left the first two taps; the gated tile then replaces tap 1; after GEMM 2 both buffers
+// together are the fp32 exchange tile through which the residual and the skip accumulators reach 16-byte global pieces.
+template <int C, int TM>
+__global__ void __launch_bounds__(512) wn_layer_bf16_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ y_next, float* __restrict__ skip,
+                                                                 const void* __restrict__ w1, const float* __restrict__ b1,
+                                                                 const void* __restrict__ w2, const float* __restrict__ b2,
+                                                                 const float* __restrict__ e, int e_bstride, int n, int dil, int first, int Tn) {
+    using Tl = WnTile<C, TM>;
+    constexpr int PA = Tl::PA, MT = Tl::MT, SPT = Tl::SPT;
+    constexpr int NT = 512;                                // threads
+    static_assert(C == 256 && TM == 128, "8 waves x 32 gate columns; two 128-row buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const bufX = smem;                               // [TM][PA]: tap 0, then tap 2
+    char* const bufG = smem + TM * PA;                     // [TM][PA]: tap 1, then the gated activation
+    float* const prm = (float*)(smem + 2 * TM * PA);       // b1 (2C) | b2 (2C) | e_n (C) | e_{n+1} (C)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TM;
+    // Global pieces are addressed as a wave-uniform base + a 32-bit per-lane byte offset derived from a freshly pinned thread id
+    // in every phase: 64-bit per-lane pointers, which the compiler otherwise computes once for all phases and keeps (or
+    // spills), would take ~200 of the 256 vector registers of this kernel.
+    const char* const yb = (const char*)(y + (size_t)b * Tn * C);
+    auto pin = [&]() __attribute__((always_inline)) -> int { int t = tid; asm volatile("" : "+v"(t)); return t; };
+
+#ifdef ADF_WN_STAMP
+    const bool stamped = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2;
+#endif
+    WN_STAMP(0);
+    constexpr int CPR = C / 8;
+    constexpr int NST = TM * CPR / NT;                     // 16-byte pieces of one window per thread
+    auto row_of = [&](int i, int q) __attribute__((always_inline)) -> int { return i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh; };
+    const int nb2[2] = {wave * 32, C + wave * 32};
+    const int col = wave * 32 + r;
+    wn_f32x16_t acc[2][MT];
+    auto zero = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
+    };
+    auto ldprm = [&]() __attribute__((always_inline)) {
+        for (int i = tid; i < 6 * C; i += NT) {
+            float v;
+            if (i < 2 * C) v = b1[i];
+            else if (i < 4 * C) v = b2[i - 2 * C];
+            else if (i < 5 * C) v = e[(size_t)b * e_bstride + (size_t)n * C + (i - 4 * C)];
+            else v = y_next ? e[(size_t)b * e_bstride + (size_t)(n + 1) * C + (i - 5 * C)] : 0.0f;
+            prm[i] = v;
+        }
+    };
+    zero();
+    if (2 * dil <= TM) {
+        // ---- small dilation: the three windows overlap -- rows t0 - d .. t0 + TM + d are staged ONCE into X|G (<= 2 TM rows) and
+        // tap k reads them from row k d on; one GEMM over all three taps -------------------------------------------------------
+        u32x4_t wv[2 * NST];
+        const int rows = TM + 2 * dil;
+        {
+            const int tq = pin();
+#pragma unroll
+            for (int k = 0; k < 2 * NST; ++k) {
+                const int idx = tq + k * NT;
+                const int i = idx / CPR, cc = idx - i * CPR;
+                const int t = t0 - dil + i;
+                const bool in = i < rows && t >= 0 && t < Tn;
+                wv[k] = *(const u32x4_t*)(yb + (unsigned)(in ? t * (C * 2) + cc * 16 : 0));
+                if (!in) wv[k] = u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+        ldprm();
+#pragma unroll
+        for (int k = 0; k < 2 * NST; ++k) {
+            const int idx = tid + k * NT;
+            const int i = idx / CPR, cc = idx - i * CPR;
+            *(u32x4_t*)(bufX + (size_t)i * PA + cc * 16) = wv[k];
+        }
+        WN_STAMP(1);
+        __syncthreads();
+        WN_STAMP(2);
+        wn_gemm<C, TM, 2 * C, 2, 3, 4>(bufX, w1, nb2, acc, r, hh, dil);
+        __syncthreads();                                   // every wave has left the windows: G may be overwritten
+    } else {
+        // ---- large dilation: three disjoint windows.  Taps 0 and 1 go to X and G, tap 2 waits in registers and replaces tap 0
+        // once every wave has left the first two taps ----------------------------------------------------------------------------
+        u32x4_t w2v[NST];
+        {
+            u32x4_t w0v[NST], w1v[NST];
+            auto ldwin = [&](int tap, u32x4_t (&v)[NST]) __attribute__((always_inline)) {
+                const int tq = pin();
+#pragma unroll
+                for (int k = 0; k < NST; ++k) {
+                    const int idx = tq + k * NT;
+                    const int i = idx / CPR, cc = idx - i * CPR;
+                    const int t = t0 + i + (tap - 1) * dil;
+                    const bool in = t >= 0 && t < Tn;
+                    v[k] = *(const u32x4_t*)(yb + (unsigned)(in ? t * (C * 2) + cc * 16 : 0));
+                    if (!in) v[k] = u32x4_t{0u, 0u, 0u, 0u};
+                }
+            };
+            ldwin(0, w0v); ldwin(1, w1v); ldwin(2, w2v);
+            ldprm();
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int idx = tid + k * NT;
+                const int i = idx / CPR, cc = idx - i * CPR;
+                *(u32x4_t*)(bufX + (size_t)i * PA + cc * 16) = w0v[k];
+                *(u32x4_t*)(bufG + (size_t)i * PA + cc * 16) = w1v[k];
+            }
+        }
+        WN_STAMP(1);
+        __syncthreads();
+        WN_STAMP(2);
+        wn_gemm<C, TM, 2 * C, 2, 2, 4>(bufX, w1, nb2, acc, r, hh);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + k * NT;
+            const int i = idx / CPR, cc = idx - i * CPR;
+            *(u32x4_t*)(bufX + (size_t)i * PA + cc * 16) = w2v[k];
+        }
+        __syncthreads();
+        wn_gemm<C, TM, 2 * C, 2, 1, 4>(bufX, (const char*)w1 + (size_t)2 * SPT * 2 * (2 * C) * 16, nb2, acc, r, hh);
+        // (every wave has left tap 1 at the barrier above: G may be overwritten)
+    }
+    WN_STAMP(3);
+    // gate: sigmoid(a) tanh(b) = (E - 1) / ((1 + exp(-a)) (1 + E)), E = exp(2 b) clamped so that (1 + E) stays finite: one
+    // reciprocal per element instead of two
+    {
+        const float bg = prm[col], bf = prm[C + col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float ea = __builtin_amdgcn_exp2f((acc[0][i][q] + bg) * -1.4426950408889634f);
+                const float eb = __builtin_amdgcn_exp2f(fminf((acc[1][i][q] + bf) * 2.8853900817779268f, 60.0f));
+                const float v = (eb - 1.0f) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
+                *(unsigned short*)(bufG + (size_t)row_of(i, q) * PA + col * 2) = f32_to_bf16_hw(v);
+            }
+    }
+    WN_STAMP(4);
+    __syncthreads();
+    WN_STAMP(5);
+
+    // ---- GEMM 2 ----------------------------------------------------------------------------------------------------------
+    zero();
+    wn_gemm<C, TM, 2 * C, 2, 1, 4>(bufG, w2, nb2, acc, r, hh);
+    asm volatile("" ::: "memory");                         // keep the epilogue's global loads below the GEMM (register pressure)
+    WN_STAMP(6);
+
+    // ---- epilogue: global pieces are issued first, the accumulators reach them through the fp32 exchange tile ---------------
+    constexpr int PS = C * 4 + 16;
+    static_assert(TM * PS <= 2 * TM * PA, "the exchange tile fits the two buffers");
+    constexpr int SCH = C / 4;                             // 16-byte pieces per fp32 row
+    constexpr int NSK = TM * SCH / NT;
+    char* const sg = (char*)(skip + ((size_t)b * Tn + t0) * C);
+    u32x4_t yo[NST];
+    {
+        const int tq = pin();
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tq + k * NT;
+            const int i = idx / CPR, cc = idx - i * CPR;
+            const bool in = y_next && t0 + i < Tn;
+            yo[k] = *(const u32x4_t*)(yb + (unsigned)(in ? (t0 + i) * (C * 2) + cc * 16 : 0));
+        }
+    }
+    u32x4_t sk[NSK];
+    {
+        const int tq = pin();
+#pragma unroll
+        for (int k = 0; k < NSK; ++k) {
+            const int idx = tq + k * NT;
+            const int row = idx / SCH, cc = idx - row * SCH;
+            const bool in = !first && t0 + row < Tn;
+            sk[k] = *(const u32x4_t*)(sg + (unsigned)(in ? row * (C * 4) + cc * 16 : 0));
+            if (!in) sk[k] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();                                       // every wave has left GEMM 2: X and G become the exchange tile
+    auto put = [&](int j, int boff) __attribute__((always_inline)) {
+        const float bias = prm[boff + col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *(float*)(smem + (size_t)row_of(i, q) * PS + col * 4) = acc[j][i][q] + bias;
+    };
+    put(0, 2 * C);
+    __syncthreads();
+    if (y_next) {
+        char* const ob = (char*)(y_next + ((size_t)b * Tn + t0) * C);
+        const int tq = pin();
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tq + k * NT;
+            const int i = idx / CPR, cc = idx - i * CPR;
+            if (t0 + i < Tn) {
+                float f[8];
+                unpack16<bf16_t>(yo[k], f);
+                const float* const rs = (const float*)(smem + (size_t)i * PS + cc * 32);
+                const float* const en = prm + 4 * C + cc * 8;
+                const float* const en1 = prm + 5 * C + cc * 8;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = ((f[u] - en[u]) + rs[u]) * 0.70710678118654752440f + en1[u];
+                *(u32x4_t*)(ob + (unsigned)(i * (C * 2) + cc * 16)) = pack16<bf16_t>(f);
+            }
+
+        }
+    }
+    __syncthreads();
+    WN_STAMP(7);
+    put(1, 3 * C);
+    __syncthreads();
+    WN_STAMP(8);
+    {
+        const int tq = pin();
+#pragma unroll
+        for (int k = 0; k < NSK; ++k) {
+            const int idx = tq + k * NT;
+            const int row = idx / SCH, cc = idx - row * SCH;
+            if (t0 + row < Tn) {
+                const f32x4_vec a = *(const f32x4_vec*)(smem + (size_t)row * PS + cc * 16);
+                *(f32x4_vec*)(sg + (unsigned)(row * (C * 4) + cc * 16)) = a + __builtin_bit_cast(f32x4_vec, sk[k]);
+            }
+
+        }
+    }
+    WN_STAMP(9);
+}
+
 
 const char* launch_wn_layer(const WnIO& io, const WnLayerArgs& a, hipStream_t s) {
     if (io.bf16) {
-        constexpr int C = 256, TM = 64;
+        constexpr int C = 256, TM = 64, TMW = 128;
         if (io.C != C) return "WaveNet bf16 mode: the MFMA layer kernel is built for residual_channels = 256 (use fp32 for other widths)";
         const size_t lds = (size_t)4 * TM * WnTile<C, TM>::PA + 6 * C * 4;
         static bool attr_done[kMaxDevices] = {};
         bool& attr = attr_done[current_device()];
         if (!attr) {
-            if (hipFuncSetAttribute((const void*)wn_layer_bf16_kernel<C, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)wn_layer_bf16_kernel<C, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)wn_layer_bf16_wide_kernel<C, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return "wn_layer: hipFuncSetAttribute failed";
             attr = true;
+        }
+        // route switch (the parity tests run both): 1 = 128-position tiles, 0 = 64-position tiles
+        static const int wide = adf_route_switch("ADF_WN_WIDE", 1);
+        if (wide) {
+            const size_t ldsw = (size_t)2 * TMW * WnTile<C, TMW>::PA + 6 * C * 4;
+            hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<C, TMW>), dim3(ceil_div(io.T, TMW), io.B), dim3(512), ldsw, s, (const bf16_t*)a.y,
+                               (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+            return WN_LAUNCH_CHECK("wn_layer_bf16_wide");
         }
         hipLaunchKernelGGL((wn_layer_bf16_kernel<C, TM>), dim3(ceil_div(io.T, TM), io.B), dim3(512), lds, s, (const bf16_t*)a.y, (bf16_t*)a.y_next,
                            a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
