@@ -128,6 +128,24 @@ def test_bf16_every_layer_vs_bf16_storage_oracle(tlen):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_bf16_both_layer_kernel_routes_in_a_child_process(wide):
+    """The layer kernel has two routes (128-position tiles, default; 64-position tiles, ADF_WN_WIDE=0); the switch is read once
+    per process, so each runs in its own child: per-layer teacher-forced deviation, the fp32 path, the free-running bf16 net."""
+    import json, subprocess, sys
+    env = dict(os.environ, ADF_WN_WIDE=wide)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "gpu_wn_report.py"), "1500", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["route_wide"] == wide and rep["forced_taps"] == 37
+    assert rep["forced_max_rel_l2"] < BF16_LAYER_TOL, rep
+    assert rep["out_vs_forced_oracle_rel_l2"] < BF16_LAYER_TOL, rep
+    assert rep["bf16_vs_fp32_oracle_rel_l2"] < BF16_NET_TOL, rep
+    assert rep["fp32_device_vs_oracle_max_rel"] < FP32_TIGHT, rep
+
+
+@pytest.mark.gpu
 def test_denoise_and_heun_sampler_fp32_vs_oracle():
     """The EDM wrapper and a 6-step Heun run (config 5's sampler length: 11 evaluations) around the adapter, eager and
     graph-replayed, against the oracle's wrapper + loop around the pinned network restatement."""

@@ -48,4 +48,16 @@ if t:
 PY
 echo "[9/9] C3 bench line"
 timeout -k 10 400 python bench.py --config c3 --sampler dpm --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_c3_dpm.json
+echo "[10] WaveNet (config 5): bench line, kernel trace, parity report, phase stamps"
+timeout -k 10 600 python bench.py --config c5 --steps 1 --warmup 1 2>/dev/null | tail -1 > $out/${tag}_bench_c5_wavenet.json
+rm -rf /tmp/p5
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -- python3 bench.py --config c5 --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-precision-check > /tmp/p5.log 2>&1 || { tail -5 /tmp/p5.log; exit 1; }
+cp $(ls /tmp/p5/*/*kernel_stats.csv | head -1) $out/${tag}_bench_c5_kernel_stats.csv
+for w in 1 0; do ADF_WN_WIDE=$w timeout -k 10 300 python tests/diag/gpu_wn_report.py 4200 2 > /dev/null 2>&1; done
+cp gpurun_out/wn_parity_report_wide1.json $out/${tag}_wavenet_bf16_parity_wide.json; cp gpurun_out/wn_parity_report_wide0.json $out/${tag}_wavenet_bf16_parity_64.json
+if [ -f audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so ]; then
+  { for l in 0 5 11 35; do ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so timeout -k 10 200 python tools/wn_stamps.py $l 128 2>&1 | grep -v amdgpu.ids; done
+    echo "# --- 64-position route (ADF_WN_WIDE=0)"
+    ADF_WN_WIDE=0 ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so timeout -k 10 200 python tools/wn_stamps.py 5 128 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_wavenet_layer_stamps.txt
+fi
 ls -la $out
