@@ -10,5 +10,7 @@ from .config import WaveNetConfig, config_c5, config_c5_small  # noqa: F401
 from .scheduler import KarrasSchedule  # noqa: F401
 from .net import UNet1dBase  # noqa: F401
 from .wavenet import WaveNetNoise  # noqa: F401
+from .adm import UNetModel  # noqa: F401
+from .adm_config import ADMConfig, config_c4, config_c4_small  # noqa: F401
 from .diffusion import EluDiffusion  # noqa: F401
 from .samplers import EDMSampler, EDMAlphaSampler, DPMSampler, DPM2Sampler, DPM2MSampler, ADPM2Sampler, LMSSampler  # noqa: F401

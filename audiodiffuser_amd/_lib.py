@@ -53,10 +53,24 @@ class AdfWaveNetConfig(C.Structure):
                 ("dim_in", C.c_int32), ("dim_mid", C.c_int32), ("dim_out", C.c_int32), ("dtype", C.c_int32)]
 
 
+ADF_ADM_MAX_LEVELS = 8
+
+
+class AdfAdmConfig(C.Structure):
+    """``adf_adm_config`` of include/audiodiffuser_amd.h."""
+    _fields_ = [("in_channels", C.c_int32), ("model_channels", C.c_int32), ("out_channels", C.c_int32), ("num_res_blocks", C.c_int32),
+                ("n_mult", C.c_int32), ("channel_mult", C.c_int32 * ADF_ADM_MAX_LEVELS),
+                ("n_attention_ds", C.c_int32), ("attention_ds", C.c_int32 * ADF_ADM_MAX_LEVELS),
+                ("conv_resample", C.c_int32), ("num_heads", C.c_int32), ("num_head_channels", C.c_int32), ("use_scale_shift_norm", C.c_int32),
+                ("resblock_updown", C.c_int32), ("use_new_attention_order", C.c_int32), ("num_classes", C.c_int32), ("dtype", C.c_int32)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "adf_create": (C.c_int, [C.POINTER(AdfNetConfig), C.POINTER(C.c_void_p)]),
     "adf_wavenet_create": (C.c_int, [C.POINTER(AdfWaveNetConfig), C.POINTER(C.c_void_p)]),
+    "adf_adm_create": (C.c_int, [C.POINTER(AdfAdmConfig), C.POINTER(C.c_void_p)]),
+    "adf_set_image_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "adf_destroy": (None, [C.c_void_p]),
     "adf_last_error": (C.c_char_p, [C.c_void_p]),
     "adf_num_weights": (C.c_int, [C.c_void_p]),
@@ -126,6 +140,27 @@ def make_config(cfg: UNet1dConfig, dtype: int, flags: int = 0) -> AdfNetConfig:
     c.use_attention_bottleneck = 1 if cfg.use_attention_bottleneck else 0
     c.dtype, c.flags = dtype, flags
     c.num_classes = int(cfg.num_classes) if cfg.class_cond else 0
+    return c
+
+
+def make_adm_config(cfg, dtype: int) -> AdfAdmConfig:
+    c = AdfAdmConfig()
+    c.in_channels, c.model_channels, c.out_channels, c.num_res_blocks = cfg.in_channels, cfg.model_channels, cfg.out_channels, cfg.num_res_blocks
+    if len(cfg.channel_mult) > ADF_ADM_MAX_LEVELS or len(cfg.attention_ds) > ADF_ADM_MAX_LEVELS:
+        raise ValueError("too many levels")
+    c.n_mult = len(cfg.channel_mult)
+    for i, m in enumerate(cfg.channel_mult):
+        if int(m) != m:
+            raise ValueError("channel_mult entries must be integers")
+        c.channel_mult[i] = int(m)
+    c.n_attention_ds = len(cfg.attention_ds)
+    for i, d in enumerate(cfg.attention_ds):
+        c.attention_ds[i] = int(d)
+    c.conv_resample, c.num_heads, c.num_head_channels = int(cfg.conv_resample), cfg.num_heads, cfg.num_head_channels
+    c.use_scale_shift_norm, c.resblock_updown = int(cfg.use_scale_shift_norm), int(cfg.resblock_updown)
+    c.use_new_attention_order = int(cfg.use_new_attention_order)
+    c.num_classes = int(cfg.num_classes) if cfg.num_classes is not None else 0
+    c.dtype = dtype
     return c
 
 

@@ -11,6 +11,7 @@
 #include "adf_gemm.h"
 #include "adf_kernels.h"
 #include "adf_wavenet.h"
+#include "adf_conv2d.h"
 #include "adf_transformer.h"
 #include "adf_resblock_small.h"
 
@@ -68,6 +69,24 @@ struct WnConv {
     void* packed = nullptr;
     int cout = 0, cin = 0, K = 0;
 };
+// ADM-style 2-D U-Net (unet2d_oai.py:382-635): the module list of UNetModel.__init__ as data
+struct AdmRes { int cin = 0, cout = 0, film_off = 0; float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr; ConvW c1, c2, skip; bool has_skip = false; };
+struct AdmAttn { int c = 0, heads = 0; float *gw = nullptr, *gb = nullptr; ConvW qkv, proj; float* qkv_tmp = nullptr; };
+struct AdmLayer { int kind; int idx; };       // kind: 0 input conv, 1 ResBlock, 2 AttentionBlock, 3 Downsample, 4 Upsample
+struct AdmW {
+    adf_adm_config cfg;
+    int H = 0, W = 0;                    // image shape of the calls that follow (adf_set_image_shape)
+    std::vector<AdmRes> res;
+    std::vector<AdmAttn> attn;
+    std::vector<ConvW> resample;
+    std::vector<std::vector<AdmLayer>> input_blocks, output_blocks;
+    std::vector<AdmLayer> middle;
+    std::vector<int> skip_ch;            // channels of the input-block outputs, in push order
+    float *in_w = nullptr, *in_b = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
+    float *out_gw = nullptr, *out_gb = nullptr, *out_w = nullptr, *out_b = nullptr;
+    int input_ch = 0, final_ch = 0;
+};
+
 struct WnW {
     adf_wavenet_config cfg;
     WnConv in, sp;
@@ -142,6 +161,7 @@ struct adf_handle {
     std::map<std::pair<int, int>, Plan*> plans;
     Plan* last_plan = nullptr;
     WnW* wn = nullptr;                  // non-null: the handle is a WaveNetNoise (adf_wavenet_create), not a UNet1dBase
+    AdmW* adm = nullptr;                // non-null: the handle is an ADM-style UNetModel (adf_adm_create)
     // graphs are captured and replayed on a library-owned stream (the caller's stream may be the legacy
     // default stream, which cannot be captured); it is fenced against the caller's stream with events
     hipStream_t gstream = nullptr;
@@ -630,9 +650,11 @@ struct FwdIO {
 };
 
 int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
+int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
 
 int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     if (h->wn) return wn_forward(h, p, io, s);
+    if (h->adm) return adm_forward(h, p, io, s);
     const adf_net_config& c = h->cfg;
     Walker W{h, p, s};
     W.film2 = io.film2; W.film2_bstride = io.film2_bstride;
@@ -722,6 +744,14 @@ int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
     if (B < 1 || L < 1 || L % total) return fail(h, "length must be a positive multiple of the total down-sampling factor");
     if (adf_weights_missing(h)) return fail(h, "weights are not fully loaded");
     if (h->wn && !h->wn->packed && wn_pack_weights(h, s)) return 1;
+    if (h->adm) {
+        const AdmW& a = *h->adm;
+        int f = 1;
+        for (int i = 1; i < a.cfg.n_mult; ++i) f *= 2;
+        if (a.H < 1 || a.W < 1 || (long long)a.H * a.W != L) return fail(h, "UNetModel: call adf_set_image_shape(H, W) with H * W equal to the length argument first");
+        if (a.H % f || a.W % f || ((a.H / f) * (a.W / f)) % 64)
+            return fail(h, "UNetModel: H and W must be multiples of 2^(levels-1) and the coarsest level a multiple of 64 pixels");
+    }
     auto it = h->plans.find({B, L});
     if (it != h->plans.end()) { *out = it->second; h->last_plan = it->second; it->second->last_use = ++h->use_clock; return 0; }
     Plan* p = new Plan();
@@ -874,6 +904,209 @@ int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     sk.f32 = 1; sk.scale = f.skip_scale;
     p->taps.push_back(sk);
     W.check(launch_wn_final(wio, f, s));
+    return W.bad ? 1 : 0;
+}
+
+// ---- ADM-style 2-D U-Net ---------------------------------------------------------------------------------------------
+// The module list UNetModel.__init__ builds (unet2d_oai.py:467-594), registered in state_dict order.
+int adm_build_weights(adf_handle* h) {
+    AdmW& a = *h->adm;
+    const adf_adm_config& c = a.cfg;
+    const int mc = c.model_channels, ted = 4 * mc;
+    auto has_att = [&](int ds) { for (int i = 0; i < c.n_attention_ds; ++i) if (c.attention_ds[i] == ds) return true; return false; };
+    auto heads_of = [&](int ch) { return c.num_head_channels == -1 ? c.num_heads : ch / c.num_head_channels; };
+    // pass 1: structure
+    auto new_res = [&](int cin, int cout) { AdmRes r; r.cin = cin; r.cout = cout; r.has_skip = cin != cout; r.film_off = h->film_total; h->film_total += 2 * cout;
+                                            a.res.push_back(r); return AdmLayer{1, (int)a.res.size() - 1}; };
+    auto new_attn = [&](int ch) { AdmAttn t; t.c = ch; t.heads = heads_of(ch); a.attn.push_back(t); return AdmLayer{2, (int)a.attn.size() - 1}; };
+    int ch = a.input_ch = c.channel_mult[0] * mc;
+    a.input_blocks.push_back({AdmLayer{0, 0}});
+    std::vector<int> chans{ch};
+    int ds = 1;
+    for (int level = 0; level < c.n_mult; ++level) {
+        for (int k = 0; k < c.num_res_blocks; ++k) {
+            std::vector<AdmLayer> ls{new_res(ch, c.channel_mult[level] * mc)};
+            ch = c.channel_mult[level] * mc;
+            if (has_att(ds)) ls.push_back(new_attn(ch));
+            a.input_blocks.push_back(ls);
+            chans.push_back(ch);
+        }
+        if (level != c.n_mult - 1) {
+            a.resample.emplace_back();
+            a.resample.back().cin = ch; a.resample.back().cout = ch;
+            a.input_blocks.push_back({AdmLayer{3, (int)a.resample.size() - 1}});
+            chans.push_back(ch);
+            ds *= 2;
+        }
+    }
+    a.skip_ch = chans;
+    a.middle = {new_res(ch, ch), new_attn(ch), new_res(ch, ch)};
+    for (int level = c.n_mult - 1; level >= 0; --level) {
+        for (int i = 0; i <= c.num_res_blocks; ++i) {
+            const int ich = chans.back(); chans.pop_back();
+            std::vector<AdmLayer> ls{new_res(ch + ich, mc * c.channel_mult[level])};
+            ch = mc * c.channel_mult[level];
+            if (has_att(ds)) ls.push_back(new_attn(ch));
+            if (level && i == c.num_res_blocks) {
+                a.resample.emplace_back();
+                a.resample.back().cin = ch; a.resample.back().cout = ch;
+                ls.push_back(AdmLayer{4, (int)a.resample.size() - 1});
+                ds /= 2;
+            }
+            a.output_blocks.push_back(ls);
+        }
+    }
+    a.final_ch = ch;
+    if (a.final_ch != a.input_ch) return fail(h, "UNetModel: the last level's width must equal the first's (out conv, unet2d_oai.py:599)");
+    // pass 2: registry, in the module's registration order
+    Registrar R{h};
+    h->film_w = (float*)dalloc(h, (size_t)h->film_total * ted * 4);
+    h->film_b = (float*)dalloc(h, (size_t)h->film_total * 4);
+    if (!h->film_w || !h->film_b) R.ok = false;
+    a.t_w1 = R.reg_f32("time_embed.0.weight", (int64_t)ted * mc);
+    a.t_b1 = R.reg_f32("time_embed.0.bias", ted);
+    a.t_w2 = R.reg_f32("time_embed.2.weight", (int64_t)ted * ted);
+    a.t_b2 = R.reg_f32("time_embed.2.bias", ted);
+    auto reg_layer = [&](const AdmLayer& l, const std::string& pre) {
+        if (l.kind == 0) {
+            a.in_w = R.reg_f32(pre + ".weight", (int64_t)a.input_ch * c.in_channels * 9);
+            a.in_b = R.reg_f32(pre + ".bias", a.input_ch);
+        } else if (l.kind == 1) {
+            AdmRes& r = a.res[l.idx];
+            r.g1w = R.reg_f32(pre + ".in_layers.0.weight", r.cin);
+            r.g1b = R.reg_f32(pre + ".in_layers.0.bias", r.cin);
+            R.conv(pre + ".in_layers.2", r.c1, r.cout, r.cin, 9, true);
+            R.reg_f32(pre + ".emb_layers.1.weight", (int64_t)2 * r.cout * ted, h->film_w + (size_t)r.film_off * ted);
+            R.reg_f32(pre + ".emb_layers.1.bias", 2 * r.cout, h->film_b + r.film_off);
+            r.g2w = R.reg_f32(pre + ".out_layers.0.weight", r.cout);
+            r.g2b = R.reg_f32(pre + ".out_layers.0.bias", r.cout);
+            R.conv(pre + ".out_layers.3", r.c2, r.cout, r.cout, 9, true);
+            if (r.has_skip) R.conv(pre + ".skip_connection", r.skip, r.cout, r.cin, 1, true);
+        } else if (l.kind == 2) {
+            AdmAttn& t = a.attn[l.idx];
+            t.gw = R.reg_f32(pre + ".norm.weight", t.c);
+            t.gb = R.reg_f32(pre + ".norm.bias", t.c);
+            R.conv(pre + ".qkv", t.qkv, 3 * t.c, t.c, 1, true);
+            R.conv(pre + ".proj_out", t.proj, t.c, t.c, 1, true);
+            if (!c.use_new_attention_order) {
+                // QKVAttentionLegacy (:338-340) keeps each head's q | k | v rows together; the attention kernel reads q | k | v blocks:
+                // the rows of the weight and of the bias are permuted once at load (slot kinds 4 / 5)
+                t.qkv_tmp = (float*)dalloc(h, (size_t)3 * t.c * t.c * 4);
+                if (!t.qkv_tmp) R.ok = false;
+                Slot& sw = h->slots[pre + ".qkv.weight"]; sw.kind = 4; sw.frag = t.qkv_tmp; sw.f = t.heads;
+                Slot& sb = h->slots[pre + ".qkv.bias"]; sb.kind = 5; sb.f = t.heads; sb.cout = 3 * t.c;
+            }
+        } else {
+            ConvW& w = a.resample[l.idx];
+            R.conv(pre + (l.kind == 3 ? ".op" : ".conv"), w, w.cout, w.cin, 9, true);
+        }
+    };
+    for (size_t i = 0; i < a.input_blocks.size(); ++i)
+        for (size_t j = 0; j < a.input_blocks[i].size(); ++j) reg_layer(a.input_blocks[i][j], "input_blocks." + std::to_string(i) + "." + std::to_string(j));
+    for (size_t j = 0; j < a.middle.size(); ++j) reg_layer(a.middle[j], "middle_block." + std::to_string(j));
+    for (size_t i = 0; i < a.output_blocks.size(); ++i)
+        for (size_t j = 0; j < a.output_blocks[i].size(); ++j) reg_layer(a.output_blocks[i][j], "output_blocks." + std::to_string(i) + "." + std::to_string(j));
+    a.out_gw = R.reg_f32("out.0.weight", a.final_ch);
+    a.out_gb = R.reg_f32("out.0.bias", a.final_ch);
+    a.out_w = R.reg_f32("out.2.weight", (int64_t)c.out_channels * a.input_ch * 9);
+    a.out_b = R.reg_f32("out.2.bias", c.out_channels);
+    return R.ok ? 0 : fail(h, "device allocation failed while building the weight registry");
+}
+
+// UNetModel.forward (unet2d_oai.py:603-634) on channels-last activations; x / out are the reference's [B][C][H][W] fp32
+int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
+    AdmW& a = *h->adm;
+    const adf_adm_config& c = a.cfg;
+    Walker W{h, p, s};
+    p->arena_off = 0; p->stats_off = 0;
+    p->taps.clear(); p->rbs.clear();
+    const int B = p->B, ted = 4 * c.model_channels;
+    if (!p->dry && p->stats_bytes && hipMemsetAsync(p->stats, 0, p->stats_bytes, s) != hipSuccess) return fail(h, "hipMemsetAsync(stats) failed");
+    const float* film = io.film_pre ? io.film_pre : p->film;
+    const int film_bs = io.nb > 1 ? h->film_total : 0;
+    if (W.live() && !io.film_pre) {
+        W.check(launch_adm_time_embed(io.t, io.t_stride, io.nb, c.model_channels, a.t_w1, a.t_b1, a.t_w2, a.t_b2, ted, p->temb, s));
+        W.check(launch_film(p->temb, ted, h->film_w, ted, 0, h->film_b, p->film, io.nb, h->film_total, s));
+    }
+    struct T2 { Act t; int H, W; };
+    // GroupNorm32 (:10-21) (+ scale-shift, :262-267) of a tensor folded to the per-(sample, channel) table a conv prologue reads
+    auto gn_table = [&](const T2& x, const float* gamma, const float* beta, const float* fl) -> float* {
+        double* st = W.alloc_stats();
+        float* ab = (float*)W.alloc((size_t)B * x.t.C * 2 * 4);
+        if (W.live()) {
+            W.check(launch_gn_stats_any(x.t.p, h->bf16, B, x.t.L, x.t.C, 32, st, s));
+            GnFinalizeArgs g;
+            memset(&g, 0, sizeof(g));
+            g.stats0 = st; g.c0 = x.t.C; g.c1 = 0; g.L = x.t.L; g.G = 32; g.B = B; g.scale1 = 1.f; g.eps = 1e-5f;
+            g.gamma = gamma; g.beta = beta; g.film = fl; g.film_bstride = film_bs; g.ab = ab;
+            W.check(launch_gn_finalize(g, s));
+        }
+        return ab;
+    };
+    auto conv = [&](const T2& x, const ConvW& w, const float* ab, int act, int mode, const void* res) -> T2 {
+        T2 y;
+        y.H = mode == 1 ? x.H * 2 : (mode == 2 ? x.H / 2 : x.H);
+        y.W = mode == 1 ? x.W * 2 : (mode == 2 ? x.W / 2 : x.W);
+        y.t = W.new_act(w.cout, y.H * y.W);
+        if (W.live()) {
+            Conv2dArgs g;
+            g.x = x.t.p; g.ab = ab; g.act = act; g.B = B; g.H = y.H; g.W = y.W; g.cin = x.t.C; g.cout = w.cout; g.n_pad = w.n_pad;
+            g.taps = w.taps; g.mode = mode; g.w = w.w; g.nchunk = w.nchunk; g.bias = w.bias; g.res = res; g.out = y.t.p;
+            W.check(launch_conv2d(g, h->bf16, s));
+        }
+        return y;
+    };
+    auto run = [&](const std::vector<AdmLayer>& ls, T2 x) -> T2 {
+        for (const AdmLayer& l : ls) {
+            if (W.bad) break;
+            if (l.kind == 0) {
+                T2 y; y.H = x.H; y.W = x.W; y.t = W.new_act(a.input_ch, x.H * x.W);
+                if (W.live()) W.check(launch_conv2d_in(io.x, a.in_w, a.in_b, y.t.p, h->bf16, B, c.in_channels, x.H, x.W, a.input_ch, io.coef, io.coef_bstride, s));
+                x = y;
+            } else if (l.kind == 1) {                                   // ResBlock._forward, :248-272 (scale-shift form)
+                const AdmRes& r = a.res[l.idx];
+                const float* ab1 = gn_table(x, r.g1w, r.g1b, nullptr);
+                T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr);
+                const float* ab2 = gn_table(hh, r.g2w, r.g2b, film + r.film_off);
+                const void* skip = x.t.p;
+                if (r.has_skip) skip = conv(x, r.skip, nullptr, 0, 0, nullptr).t.p;
+                x = conv(hh, r.c2, ab2, 1, 0, skip);
+            } else if (l.kind == 2) {                                   // AttentionBlock._forward, :316-322
+                const AdmAttn& t = a.attn[l.idx];
+                const float* ab = gn_table(x, t.gw, t.gb, nullptr);
+                T2 xn; xn.H = x.H; xn.W = x.W; xn.t = W.new_act(t.c, x.t.L);
+                if (W.live()) W.check(launch_gn_apply(x.t.p, nullptr, t.c, 0, x.t.L, B, ab, 0, xn.t.p, h->bf16, s));
+                T2 qkv = conv(xn, t.qkv, nullptr, 0, 0, nullptr);
+                T2 att; att.H = x.H; att.W = x.W; att.t = W.new_act(t.c, x.t.L);
+                if (W.live()) W.check(launch_attention(qkv.t.p, att.t.p, h->bf16, B, x.t.L, t.c, t.heads, s));
+                x = conv(att, t.proj, nullptr, 0, 0, xn.t.p);          // the residual is the NORMALISED input (:318-322)
+            } else {
+                x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr);
+            }
+        }
+        return x;
+    };
+    T2 x; x.H = a.H; x.W = a.W; x.t = Act{};
+    std::vector<T2> hs;
+    for (size_t i = 0; i < a.input_blocks.size() && !W.bad; ++i) {
+        x = run(a.input_blocks[i], x);
+        W.tap("input_blocks." + std::to_string(i), x.t);
+        hs.push_back(x);
+    }
+    x = run(a.middle, x);
+    W.tap("middle_block", x.t);
+    for (size_t i = 0; i < a.output_blocks.size() && !W.bad; ++i) {
+        const T2 sk = hs.back(); hs.pop_back();
+        T2 cat; cat.H = x.H; cat.W = x.W; cat.t = W.new_act(x.t.C + sk.t.C, x.t.L);
+        if (sk.H != x.H || sk.W != x.W) { W.check("UNetModel: skip shape mismatch"); break; }
+        if (W.live()) W.check(launch_concat2(x.t.p, sk.t.p, x.t.C, sk.t.C, (long long)B * x.t.L, cat.t.p, h->bf16, s));
+        x = run(a.output_blocks[i], cat);
+        W.tap("output_blocks." + std::to_string(i), x.t);
+    }
+    const float* abo = gn_table(x, a.out_gw, a.out_gb, nullptr);
+    if (W.live())
+        W.check(launch_conv2d_out(x.t.p, abo, a.out_w, a.out_b, io.out, h->bf16, B, a.final_ch, x.H, x.W, c.out_channels, io.mode, io.x_noisy, io.coef,
+                                  io.coef_bstride, s));
     return W.bad ? 1 : 0;
 }
 
@@ -1441,6 +1674,45 @@ int adf_wavenet_create(const adf_wavenet_config* cfg, adf_handle** out) {
     return 0;
 }
 
+int adf_adm_create(const adf_adm_config* cfg, adf_handle** out) {
+    if (!cfg || !out) { g_create_error = "adf_adm_create: null argument"; return 1; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "adf_adm_create: no HIP device available"; return 1; }
+    const adf_adm_config& c = *cfg;
+    const int kc = c.dtype == ADF_DTYPE_BF16 ? 64 : 32;
+    if (c.dtype != ADF_DTYPE_F32 && c.dtype != ADF_DTYPE_BF16) { g_create_error = "adf_adm_create: bad dtype"; return 1; }
+    if (c.n_mult < 1 || c.n_mult > ADF_ADM_MAX_LEVELS || c.num_res_blocks < 1 || c.n_attention_ds < 0 || c.n_attention_ds > ADF_ADM_MAX_LEVELS) { g_create_error = "adf_adm_create: bad level / block counts"; return 1; }
+    if (c.model_channels < 32 || c.model_channels % 32 || c.model_channels % kc || c.model_channels > 256) { g_create_error = "adf_adm_create: model_channels must be a multiple of 32 (fp32) / 64 (bf16), at most 256"; return 1; }
+    if (c.in_channels < 1 || c.out_channels < 1 || c.out_channels > 4) { g_create_error = "adf_adm_create: in_channels >= 1, 1 <= out_channels <= 4"; return 1; }
+    if (!c.use_scale_shift_norm || c.resblock_updown || !c.conv_resample || c.num_classes > 0) {
+        g_create_error = "adf_adm_create: only the configuration of BASELINE config 4 is on the device (use_scale_shift_norm, conv resampling, no resblock up/down, unconditional)";
+        return 1;
+    }
+    for (int i = 0; i < c.n_mult; ++i) if (c.channel_mult[i] < 1) { g_create_error = "adf_adm_create: bad channel_mult"; return 1; }
+    adf_handle* h = new adf_handle();
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    // the fields of the U-Net config the shared plan / sampler code reads (embedding width 4 * channels = 4 * model_channels)
+    h->cfg.in_channels = c.in_channels; h->cfg.out_channels = c.out_channels; h->cfg.stride = 1; h->cfg.num_layers = 0;
+    h->cfg.channels = c.model_channels; h->cfg.dtype = c.dtype; h->cfg.resnet_groups = 32;
+    if (hipGetDevice(&h->device) != hipSuccess) { g_create_error = "adf_adm_create: hipGetDevice failed"; delete h; return 1; }
+    h->bf16 = c.dtype == ADF_DTYPE_BF16;
+    h->esz = h->bf16 ? 2 : 4;
+    h->kc = kRowBytes / h->esz;
+    h->adm = new AdmW();
+    h->adm->cfg = c;
+    if (adm_build_weights(h)) { g_create_error = h->err; adf_destroy(h); return 1; }
+    *out = h;
+    return 0;
+}
+
+int adf_set_image_shape(adf_handle* h, int H, int W) {
+    if (!h || !h->adm) return h ? fail(h, "adf_set_image_shape: not a UNetModel handle") : 1;
+    if (H < 1 || W < 1) return fail(h, "adf_set_image_shape: bad shape");
+    h->adm->H = H; h->adm->W = W;
+    return 0;
+}
+
 void adf_destroy(adf_handle* h) {
     if (!h) return;
     DeviceScope scope(h);
@@ -1451,6 +1723,7 @@ void adf_destroy(adf_handle* h) {
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
     delete h->wn;
+    delete h->adm;
     delete h;
 }
 
@@ -1472,6 +1745,12 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
     hipStream_t s = (hipStream_t)stream;
     if (sl.kind == 0) {
         if (hipMemcpyAsync(sl.dst, dev, (size_t)numel * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "hipMemcpyAsync failed");
+    } else if (sl.kind == 5) {               // qkv bias with the legacy head-major rows -> q | k | v rows
+        if (const char* e = launch_permute_qkv_rows(dev, (float*)sl.dst, sl.f, sl.cout / (3 * sl.f), 1, s)) return fail(h, e);
+    } else if (sl.kind == 4) {               // qkv weight: permute the rows into a scratch copy, then pack that
+        if (const char* e = launch_permute_qkv_rows(dev, (float*)sl.frag, sl.f, sl.cout / (3 * sl.f), sl.cin, s)) return fail(h, e);
+        if (const char* e = launch_pack_weight((const float*)sl.frag, sl.dst, h->bf16, 0, sl.cout, sl.cin, sl.K, 0, sl.n_offset, sl.n_pad, sl.nchunk, s))
+            return fail(h, e);
     } else {
         const char* e = launch_pack_weight(dev, sl.dst, h->bf16, sl.kind == 2 ? 1 : (sl.kind == 3 ? 2 : 0), sl.cout, sl.cin, sl.K, sl.f, sl.n_offset,
                                            sl.n_pad, sl.nchunk, s);
@@ -1634,6 +1913,11 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
             const adf_wavenet_config& wc = h->wn->cfg;
             if (const char* e = launch_wn_step_embed(p->coef_all + 1, 4, n_eval, h->wn->fc1w, h->wn->fc1b, h->wn->fc2w, h->wn->fc2b, wc.dim_in,
                                                      wc.dim_mid, wc.dim_out, p->temb_all, st))
+                return fail(h, e);
+        } else if (h->adm) {
+            const AdmW& am = *h->adm;
+            if (const char* e = launch_adm_time_embed(p->coef_all + 1, 4, n_eval, am.cfg.model_channels, am.t_w1, am.t_b1, am.t_w2, am.t_b2,
+                                                      4 * am.cfg.model_channels, p->temb_all, st))
                 return fail(h, e);
         } else {
             TimeEmbedArgs te;

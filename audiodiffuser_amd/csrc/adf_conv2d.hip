@@ -1,0 +1,414 @@
+// 2-D kernels of the ADM-style U-Net (BASELINE config 4).
+// Reference: src/models/backbones/unet2d_oai.py (GroupNorm32 :10-21, timestep_embedding :31-49, Upsample :102-127, Downsample
+// :130-158, ResBlock :162-272, AttentionBlock :274-322, UNetModel :382-635).
+//
+// conv2d_gemm_kernel: implicit GEMM, 64 pixels x 128 output channels per 4-wave workgroup, K walked as (channel chunk of 128 bytes)
+// x (tap); the activation chunk of a tap is GATHERED from the channels-last input with the tap's bounds test (zero padding), the
+// GroupNorm (+ scale-shift) affine and SiLU applied on the way into LDS; nearest-x2 upsampling and stride 2 are index maps of
+// the gather, so Upsample / Downsample cost no extra pass.  Register prefetch one iteration ahead, two barriers per iteration.
+// This is the first correct path for this row (fp32 parity + a bf16 bench line); it is not yet tuned like the 1-D resblock kernels.
+#include "adf_conv2d.h"
+
+namespace adf {
+
+#define C2_LAUNCH_CHECK(name) (hipGetLastError() == hipSuccess ? nullptr : "launch failed: " name)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 c2_bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float c2_f32x16_t;
+typedef float c2_f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kC2Pitch = 144;       // LDS row pitch: 128 bytes of K + 16 (conflict-free 16-byte fragment reads, adf_gemm.h)
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
+    constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int KC = 128 / (int)sizeof(T);           // channels per K chunk
+    constexpr int TM = 64, TN = 128;
+    __shared__ __attribute__((aligned(16))) char ldsA[TM * kC2Pitch];
+    __shared__ __attribute__((aligned(16))) char ldsW[TN * kC2Pitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int HW = a.H * a.W;
+    const long long m0 = (long long)blockIdx.x * TM;
+    const int n0 = blockIdx.y * TN;
+    const int Hin = a.mode == 1 ? a.H / 2 : (a.mode == 2 ? a.H * 2 : a.H);
+    const int Win = a.mode == 1 ? a.W / 2 : (a.mode == 2 ? a.W * 2 : a.W);
+
+    // the two activation pieces this thread stages per iteration: rows tid >> 3 and 32 + (tid >> 3), 16-byte piece tid & 7
+    const int c16 = tid & 7;
+    int pb[2], py[2], px[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const long long p = m0 + (tid >> 3) + 32 * k;
+        pb[k] = (int)(p / HW);
+        const int pp = (int)(p - (long long)pb[k] * HW);
+        py[k] = pp / a.W; px[k] = pp - py[k] * a.W;
+    }
+    const T* const xg = (const T*)a.x;
+    const char* const wg = (const char*)a.w;
+    const int nit = a.nchunk * a.taps;
+
+    u32x4_t ra[2], rw[4];
+    bool va[2];
+    auto load_regs = [&](int it) __attribute__((always_inline)) {
+        const int ck = it / a.taps, tap = it - ck * a.taps;
+        const int dy = a.taps == 9 ? tap / 3 : 1, dx = a.taps == 9 ? tap - (tap / 3) * 3 : 1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int sy, sx;
+            bool ok;
+            if (a.mode == 2) {
+                sy = 2 * py[k] + dy - 1; sx = 2 * px[k] + dx - 1;
+                ok = sy >= 0 && sy < Hin && sx >= 0 && sx < Win;
+            } else {
+                const int oy = py[k] + dy - 1, ox = px[k] + dx - 1;
+                ok = oy >= 0 && oy < a.H && ox >= 0 && ox < a.W;
+                sy = a.mode == 1 ? oy >> 1 : oy; sx = a.mode == 1 ? ox >> 1 : ox;
+            }
+            va[k] = ok;
+            const size_t off = ok ? (((size_t)pb[k] * Hin + sy) * Win + sx) * a.cin + (size_t)ck * KC + c16 * EPC : 0;
+            ra[k] = *(const u32x4_t*)(xg + off);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = (tid >> 3) + 32 * k;
+            const bool ok = n0 + row < a.n_pad;
+            rw[k] = *(const u32x4_t*)(wg + (((size_t)ck * a.taps + tap) * a.n_pad + (ok ? n0 + row : 0)) * 128 + c16 * 16);
+            if (!ok) rw[k] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_lds = [&](int it) __attribute__((always_inline)) {
+        const int ck = it / a.taps;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            u32x4_t v = ra[k];
+            if (!va[k]) v = u32x4_t{0u, 0u, 0u, 0u};                     // zero padding, applied after the activation
+            else if (a.ab) {
+                float f[EPC];
+                unpack16<T>(v, f);
+                const float* const ab = a.ab + ((size_t)pb[k] * a.cin + (size_t)ck * KC + c16 * EPC) * 2;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float t = fmaf(f[e], ab[2 * e], ab[2 * e + 1]);
+                    f[e] = a.act ? (kBf16 ? silu_f(t) : t / (1.0f + expf(-t))) : t;
+                }
+                v = pack16<T>(f);
+            }
+            *(u32x4_t*)(ldsA + ((tid >> 3) + 32 * k) * kC2Pitch + c16 * 16) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(u32x4_t*)(ldsW + ((tid >> 3) + 32 * k) * kC2Pitch + c16 * 16) = rw[k];
+    };
+
+    c2_f32x16_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    const char* const aRow = ldsA + (wm * 32 + r) * kC2Pitch;
+    const char* const wRow = ldsW + (wn * 64 + r) * kC2Pitch;
+
+    load_regs(0);
+    for (int it = 0; it < nit; ++it) {
+        if (it > 0) __syncthreads();
+        store_lds(it);
+        __syncthreads();
+        if (it + 1 < nit) load_regs(it + 1);
+        if constexpr (kBf16) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const c2_bf16x8_t fa = *(const c2_bf16x8_t*)(aRow + (ks * 2 + h) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const c2_bf16x8_t fb = *(const c2_bf16x8_t*)(wRow + j * 32 * kC2Pitch + (ks * 2 + h) * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                c2_f32x4_t fa[2], fb[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) fa[u] = *(const c2_f32x4_t*)(aRow + (ks * 4 + 2 * h + u) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) fb[j][u] = *(const c2_f32x4_t*)(wRow + j * 32 * kC2Pitch + (ks * 4 + 2 * h + u) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][e], fb[j][u][e], acc[j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, optional residual, store (accumulator layout: column r, rows (q & 3) + 8 (q >> 2) + 4 h) -------------
+    T* const og = (T*)a.out;
+    const T* const rg = (const T*)a.res;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + r;
+        if (col >= a.cout) continue;
+        const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const size_t o = (size_t)(m0 + row) * a.cout + col;
+            float v = acc[j][q] + bias;
+            if (rg) v += Elem<T>::ld(rg + o);
+            Elem<T>::st(og + o, v);
+        }
+    }
+}
+
+const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
+    const int kc = bf16 ? 64 : 32;
+    if (a.taps != 9 && a.taps != 1) return "conv2d: taps must be 9 or 1";
+    if (a.taps == 1 && a.mode != 0) return "conv2d: a 1x1 conv has no resampling mode";
+    if (a.cin % kc) return "conv2d: input channels must be a multiple of the 128-byte K chunk";
+    if (a.nchunk * kc != a.cin) return "conv2d: packed weight chunk count does not match the input channels";
+    if (((long long)a.H * a.W) % 64) return "conv2d: H*W must be a multiple of 64";
+    if (a.mode == 1 && ((a.H | a.W) & 1)) return "conv2d: upsampled output must have even height and width";
+    const long long tiles = (long long)a.B * a.H * a.W / 64;
+    const dim3 grid((unsigned)tiles, (unsigned)ceil_div(a.cout, 128)), blk(256);
+    if (bf16) hipLaunchKernelGGL(conv2d_gemm_kernel<bf16_t>, grid, blk, 0, s, a);
+    else hipLaunchKernelGGL(conv2d_gemm_kernel<float>, grid, blk, 0, s, a);
+    return C2_LAUNCH_CHECK("conv2d");
+}
+
+// ------------------------------------------------------------------------------------------------ first / last conv
+template <typename T>
+__global__ void __launch_bounds__(256) conv2d_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ out, int B, int cin, int H, int W, int cout,
+                                                        const float* __restrict__ coef, int coef_bstride) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    const int cpr = cout / EPC;
+    const long long total = (long long)B * H * W * cpr;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int cc = (int)(idx % cpr);
+        const long long p = idx / cpr;
+        const int b = (int)(p / ((long long)H * W));
+        const int pp = (int)(p - (long long)b * H * W);
+        const int y = pp / W, xx = pp - y * W;
+        const float sc = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
+        float f[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = bias[cc * EPC + e];
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
+                if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+                const float v = x[(((size_t)b * cin + ci) * H + sy) * W + sx] * sc;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = fmaf(w[((size_t)(cc * EPC + e) * cin + ci) * 9 + t], v, f[e]);
+            }
+        *(u32x4_t*)(out + p * cout + cc * EPC) = pack16<T>(f);
+    }
+}
+const char* launch_conv2d_in(const float* x, const float* w, const float* bias, void* out, int bf16, int B, int cin, int H, int W, int cout,
+                             const float* coef, int coef_bstride, hipStream_t s) {
+    if (cout % (bf16 ? 8 : 4)) return "conv2d_in: output channels must be a multiple of a 16-byte chunk";
+    const long long total = (long long)B * H * W * (cout / (bf16 ? 8 : 4));
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    if (bf16) hipLaunchKernelGGL(conv2d_in_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, w, bias, (bf16_t*)out, B, cin, H, W, cout, coef, coef_bstride);
+    else hipLaunchKernelGGL(conv2d_in_kernel<float>, dim3(blocks), dim3(256), 0, s, x, w, bias, (float*)out, B, cin, H, W, cout, coef, coef_bstride);
+    return C2_LAUNCH_CHECK("conv2d_in");
+}
+
+constexpr int kC2OutMax = 4;        // output channels of the last conv served by the vector kernel
+template <typename T>
+__global__ void __launch_bounds__(256) conv2d_out_kernel(const T* __restrict__ hx, const float* __restrict__ ab, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int B, int cin, int H, int W,
+                                                         int cout, int mode, const float* __restrict__ x_noisy, const float* __restrict__ coef,
+                                                         int coef_bstride) {
+    constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr int EPC = Elem<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const ws = (float*)smem;                    // [cout][9][cin]
+    for (int i = threadIdx.x; i < cout * cin * 9; i += 256) {
+        const int t = i % 9, ci = (i / 9) % cin, co = i / (9 * cin);
+        ws[(co * 9 + t) * cin + ci] = w[i];
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7;                   // 8 lanes share a pixel, each walks every 8th 16-byte piece of the channels
+    const long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long long npix = (long long)B * H * W;
+    const bool live = p < npix;
+    const int b = live ? (int)(p / ((long long)H * W)) : 0;
+    const int pp = live ? (int)(p - (long long)b * H * W) : 0;
+    const int y = pp / W, xx = pp - y * W;
+    const int cpr = cin / EPC;
+    float acc[kC2OutMax];
+#pragma unroll
+    for (int co = 0; co < kC2OutMax; ++co) acc[co] = 0.f;
+    if (live) {
+        for (int t = 0; t < 9; ++t) {
+            const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+            const T* const row = hx + (((size_t)b * H + sy) * W + sx) * cin;
+            for (int cc = sub; cc < cpr; cc += 8) {
+                float f[EPC];
+                unpack16<T>(*(const u32x4_t*)(row + cc * EPC), f);
+                const float* const abp = ab + ((size_t)b * cin + cc * EPC) * 2;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float tt = fmaf(f[e], abp[2 * e], abp[2 * e + 1]);
+                    f[e] = kBf16 ? silu_f(tt) : tt / (1.0f + expf(-tt));
+                }
+                for (int co = 0; co < cout; ++co) {
+                    const float* const wp = ws + (co * 9 + t) * cin + cc * EPC;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[co] = fmaf(wp[e], f[e], acc[co]);
+                }
+            }
+        }
+    }
+    for (int co = 0; co < cout; ++co) {
+        float v = acc[co];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (live && sub == 0) {
+            const float F = v + bias[co];
+            const size_t o = (((size_t)b * cout + co) * H + y) * W + xx;
+            if (mode == 0) out[o] = F;
+            else {
+                const float c_skip = coef[(size_t)b * coef_bstride + 2], c_out = coef[(size_t)b * coef_bstride + 3];
+                out[o] = fminf(fmaxf(fmaf(c_out, F, c_skip * x_noisy[o]), -1.0f), 1.0f);
+            }
+        }
+    }
+}
+const char* launch_conv2d_out(const void* h, const float* ab, const float* w, const float* bias, float* out, int bf16, int B, int cin, int H,
+                              int W, int cout, int mode, const float* x_noisy, const float* coef, int coef_bstride, hipStream_t s) {
+    if (cout > kC2OutMax) return "conv2d_out: more output channels than the vector kernel serves";
+    if (cin % (bf16 ? 8 : 4)) return "conv2d_out: input channels must be a multiple of a 16-byte chunk";
+    const size_t lds = (size_t)cout * cin * 9 * 4;
+    if (lds > 64 * 1024) return "conv2d_out: weights do not fit LDS";
+    const long long npix = (long long)B * H * W;
+    const dim3 grid((unsigned)((npix + 31) / 32)), blk(256);
+    if (bf16) hipLaunchKernelGGL(conv2d_out_kernel<bf16_t>, grid, blk, lds, s, (const bf16_t*)h, ab, w, bias, out, B, cin, H, W, cout, mode, x_noisy, coef, coef_bstride);
+    else hipLaunchKernelGGL(conv2d_out_kernel<float>, grid, blk, lds, s, (const float*)h, ab, w, bias, out, B, cin, H, W, cout, mode, x_noisy, coef, coef_bstride);
+    return C2_LAUNCH_CHECK("conv2d_out");
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__global__ void __launch_bounds__(256) concat2_kernel(const u32x4_t* __restrict__ s0, const u32x4_t* __restrict__ s1, int q0, int q1,
+                                                      long long rows, u32x4_t* __restrict__ out) {
+    const int q = q0 + q1;
+    const long long total = rows * q;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long row = idx / q;
+        const int c = (int)(idx - row * q);
+        out[idx] = c < q0 ? s0[row * q0 + c] : s1[row * q1 + (c - q0)];
+    }
+}
+const char* launch_concat2(const void* s0, const void* s1, int c0, int c1, long long rows, void* out, int bf16, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (c0 % epc || c1 % epc) return "concat2: channel counts must be multiples of a 16-byte chunk";
+    const long long total = rows * ((c0 + c1) / epc);
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(concat2_kernel, dim3(blocks), dim3(256), 0, s, (const u32x4_t*)s0, (const u32x4_t*)s1, c0 / epc, c1 / epc, rows, (u32x4_t*)out);
+    return C2_LAUNCH_CHECK("concat2");
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_stats_any_kernel(const T* __restrict__ x, int L, int C, int G, int rows_per_block, double* __restrict__ stats) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const s1 = (float*)smem;                    // [C] sums, [C] sums of squares of this block's rows
+    float* const s2 = s1 + C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) s1[i] = 0.f;
+    __syncthreads();
+    const int b = blockIdx.y, cpr = C / EPC;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = r0 + rows_per_block < L ? r0 + rows_per_block : L;
+    // a thread keeps ONE channel piece and strides over rows, so its partial sums stay in registers
+    for (int cc = threadIdx.x % cpr, lane_row = threadIdx.x / cpr, step = 256 / cpr > 0 ? 256 / cpr : 1; cc < cpr && lane_row < step; cc += cpr) {
+        float a1[EPC], a2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+        for (int row = r0 + lane_row; row < r1; row += step) {
+            float f[EPC];
+            unpack16<T>(*(const u32x4_t*)(x + ((size_t)b * L + row) * C + cc * EPC), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { a1[e] += f[e]; a2[e] = fmaf(f[e], f[e], a2[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { atomicAdd(&s1[cc * EPC + e], a1[e]); atomicAdd(&s2[cc * EPC + e], a2[e]); }
+    }
+    __syncthreads();
+    const int gs = C / G;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double d1 = 0.0, d2 = 0.0;
+        for (int c = g * gs; c < (g + 1) * gs; ++c) { d1 += (double)s1[c]; d2 += (double)s2[c]; }
+        atomicAdd(&stats[((size_t)b * G + g) * 2], d1);
+        atomicAdd(&stats[((size_t)b * G + g) * 2 + 1], d2);
+    }
+}
+const char* launch_gn_stats_any(const void* x, int bf16, int B, int L, int C, int G, double* stats, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (C % epc || C % G) return "gn_stats_any: C must be a multiple of a 16-byte chunk and of the group count";
+    if (C / epc > 256) return "gn_stats_any: more than 256 channel pieces per row";
+    int rows_per_block = 64;
+    while ((long long)ceil_div(L, rows_per_block) * B > 4096) rows_per_block *= 2;
+    const dim3 grid(ceil_div(L, rows_per_block), B);
+    const size_t lds = (size_t)2 * C * 4;
+    if (bf16) hipLaunchKernelGGL(gn_stats_any_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, L, C, G, rows_per_block, stats);
+    else hipLaunchKernelGGL(gn_stats_any_kernel<float>, grid, dim3(256), lds, s, (const float*)x, L, C, G, rows_per_block, stats);
+    return C2_LAUNCH_CHECK("gn_stats_any");
+}
+
+__global__ void __launch_bounds__(256) adm_time_embed_kernel(const float* __restrict__ t, int t_stride, int mc, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, int dim_out, float* __restrict__ emb) {
+    __shared__ float f[1024];
+    __shared__ float hdn[2048];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float tv = t[(size_t)b * t_stride];
+    const int half = mc / 2;
+    for (int i = tid; i < half; i += 256) {                           // :41-46, cosines first
+        const float ang = tv * expf(-9.210340371976184f * (float)i / (float)half);
+        f[i] = cosf(ang);
+        f[half + i] = sinf(ang);
+    }
+    if (tid == 0 && (mc & 1)) f[mc - 1] = 0.f;                         // :47-48
+    __syncthreads();
+    for (int j = tid; j < dim_out; j += 256) {
+        float acc = b1[j];
+        for (int i = 0; i < mc; ++i) acc = fmaf(w1[(size_t)j * mc + i], f[i], acc);
+        hdn[j] = acc / (1.0f + expf(-acc));                            // nn.SiLU, :457
+    }
+    __syncthreads();
+    for (int j = tid; j < dim_out; j += 256) {
+        float acc = b2[j];
+        for (int i = 0; i < dim_out; ++i) acc = fmaf(w2[(size_t)j * dim_out + i], hdn[i], acc);
+        emb[(size_t)b * dim_out + j] = acc;
+    }
+}
+const char* launch_adm_time_embed(const float* t, int t_stride, int nb, int mc, const float* w1, const float* b1, const float* w2,
+                                  const float* b2, int dim_out, float* emb, hipStream_t s) {
+    if (mc > 1024 || dim_out > 2048 || mc < 2) return "adm_time_embed: unsupported widths";
+    hipLaunchKernelGGL(adm_time_embed_kernel, dim3(nb), dim3(256), 0, s, t, t_stride, mc, w1, b1, w2, b2, dim_out, emb);
+    return C2_LAUNCH_CHECK("adm_time_embed");
+}
+
+__global__ void __launch_bounds__(256) permute_qkv_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int heads, int d, int cols) {
+    const long long total = (long long)3 * heads * d * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int col = (int)(idx % cols);
+        const int row = (int)(idx / cols);                 // destination row = (which * heads + h) * d + c
+        const int c = row % d, hh = (row / d) % heads, which = row / (d * heads);
+        dst[idx] = src[((size_t)(hh * 3 + which) * d + c) * cols + col];
+    }
+}
+const char* launch_permute_qkv_rows(const float* src, float* dst, int heads, int d, int cols, hipStream_t s) {
+    const long long total = (long long)3 * heads * d * cols;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(permute_qkv_rows_kernel, dim3(blocks), dim3(256), 0, s, src, dst, heads, d, cols);
+    return C2_LAUNCH_CHECK("permute_qkv_rows");
+}
+
+}  // namespace adf

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .adm_config import ADMConfig
 from .config import UNet1dConfig, WaveNetConfig
 from .weights import param_specs
 
@@ -42,6 +43,9 @@ class NativeHandle:
         if isinstance(cfg, WaveNetConfig):
             c = _lib.make_wavenet_config(cfg, _DTYPES[dtype])
             rc, what = self.lib.adf_wavenet_create(C.byref(c), C.byref(h)), "adf_wavenet_create"
+        elif isinstance(cfg, ADMConfig):
+            c = _lib.make_adm_config(cfg, _DTYPES[dtype])
+            rc, what = self.lib.adf_adm_create(C.byref(c), C.byref(h)), "adf_adm_create"
         else:
             c = _lib.make_config(cfg, _DTYPES[dtype], flags)
             rc, what = self.lib.adf_create(C.byref(c), C.byref(h)), "adf_create"
@@ -103,10 +107,21 @@ class NativeHandle:
                                               C.c_void_p(_stream_ptr(device))), "adf_set_condition")
 
     # ---- compute entry points (all tensors fp32, contiguous, on the handle's device) ----
+    def _length(self, x: torch.Tensor) -> int:
+        """The C ABI's length argument: L for [B, C, L]; H * W for the 2-D U-Net's [B, C, H, W] (after telling the handle the shape)."""
+        if x.ndim == 4:
+            if not isinstance(self.cfg, ADMConfig):
+                raise ValueError("a 4-D input needs the 2-D UNetModel")
+            self.check(self.lib.adf_set_image_shape(self.h, int(x.shape[2]), int(x.shape[3])), "adf_set_image_shape")
+            return int(x.shape[2] * x.shape[3])
+        if isinstance(self.cfg, ADMConfig):
+            raise ValueError("the 2-D UNetModel takes [B, C, H, W] inputs")
+        return int(x.shape[-1])
+
     def net_forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-        out = torch.empty((x.shape[0], self.cfg.out_channels, x.shape[-1]), device=x.device, dtype=torch.float32)
+        out = torch.empty((x.shape[0], self.cfg.out_channels) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
         self.check(self.lib.adf_net_forward(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()),
-                                            x.shape[0], x.shape[-1], C.c_void_p(_stream_ptr(x.device))), "adf_net_forward")
+                                            x.shape[0], self._length(x), C.c_void_p(_stream_ptr(x.device))), "adf_net_forward")
         return out
 
     def denoise(self, x: torch.Tensor, sigma_data: float, sigma: Optional[float] = None,
@@ -114,7 +129,7 @@ class NativeHandle:
         out = torch.empty_like(x)
         sp = C.c_void_p(sigmas.data_ptr()) if sigmas is not None else C.c_void_p(0)
         self.check(self.lib.adf_denoise(self.h, C.c_void_p(x.data_ptr()), sp, float(sigma if sigma is not None else 0.0),
-                                        float(sigma_data), C.c_void_p(out.data_ptr()), x.shape[0], x.shape[-1],
+                                        float(sigma_data), C.c_void_p(out.data_ptr()), x.shape[0], self._length(x),
                                         C.c_void_p(_stream_ptr(x.device))), "adf_denoise")
         return out
 
@@ -127,12 +142,12 @@ class NativeHandle:
         if injected is not None:
             if (injected.ndim != noise.ndim + 1 or tuple(injected.shape[1:]) != tuple(noise.shape) or injected.dtype != torch.float32
                     or injected.device != noise.device or not injected.is_contiguous()):
-                raise ValueError("injected noise must be a contiguous fp32 [n, B, C, L] tensor on the device of `noise`")
+                raise ValueError("injected noise must be a contiguous fp32 [n, *noise.shape] tensor on the device of `noise`")
             n_inj = int(injected.shape[0])
         ip = C.c_void_p(injected.data_ptr()) if injected is not None else C.c_void_p(0)
         with torch.cuda.device(noise.device):
             self.check(self.lib.adf_sampler_run(self.h, C.byref(desc), arr, sg.numel(), C.c_void_p(noise.data_ptr()), ip, n_inj,
-                                                C.c_void_p(out.data_ptr()), noise.shape[0], noise.shape[-1],
+                                                C.c_void_p(out.data_ptr()), noise.shape[0], self._length(noise),
                                                 C.c_void_p(_stream_ptr(noise.device))), "adf_sampler_run")
         return out
 
@@ -143,7 +158,7 @@ class NativeHandle:
     def tap(self, name: str, batch: int, device: torch.device) -> torch.Tensor:
         c, l = C.c_int(), C.c_int()
         self.check(self.lib.adf_debug_tap_shape(self.h, name.encode(), C.byref(c), C.byref(l)), "adf_debug_tap_shape")
-        out = torch.empty((batch, c.value, l.value), device=device, dtype=torch.float32)
+        out = torch.empty((batch, c.value, l.value), device=device, dtype=torch.float32)      # 2-D nets: l = H * W of the tap's level
         self.check(self.lib.adf_debug_tap_copy(self.h, name.encode(), C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr(device))),
                    "adf_debug_tap_copy")
         return out

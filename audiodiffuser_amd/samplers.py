@@ -60,8 +60,8 @@ def _draws(x: Tensor, n: int, injected: Optional[Tensor], needed: bool) -> Optio
 
 
 def _prep(noise: Tensor) -> Tensor:
-    if noise.ndim != 3:
-        raise ValueError("the HIP sampler expects waveforms shaped [B, C, L]")
+    if noise.ndim not in (3, 4):
+        raise ValueError("the HIP sampler expects waveforms shaped [B, C, L] (or [B, C, H, W] for the 2-D UNetModel)")
     return noise.detach().to(torch.float32).contiguous()
 
 

@@ -10,6 +10,8 @@
  *                                     DPM2Sampler.forward (src/models/components/sampler_edm.py:371-397, :284-300,
  *                                     :710-768, :470-493) and ADPM2Sampler.forward (stochastic_sampler_edm.py:85-100)
  *   the call site all of them sit behind: src/models/diffunet_complex_module.py:86-89
+ *   adf_adm_create                 <- UNetModel.__init__ (src/models/backbones/unet2d_oai.py:410-601); adf_net_forward on that handle
+ *                                     <- UNetModel.forward (:603-634)
  *   adf_wavenet_create             <- WaveNetNoise.__init__ (src/models/backbones/wavenet.py:153-167); the handle it returns goes
  *                                     through the same entry points: adf_load_weight (the module's state_dict keys, incl. the
  *                                     custom WeightNorm's weight_g / weight_v, wavenet.py:15-55), adf_net_forward
@@ -92,9 +94,27 @@ typedef struct adf_wavenet_config {
     int32_t dtype;                          /* ADF_DTYPE_*; BF16 (MFMA kernels) needs residual_channels = 256 */
 } adf_wavenet_config;
 
+/* Hyper-parameters of the ADM-style UNetModel (unet2d_oai.py:410-430).  attention_ds holds the downsample factors at which
+ * attention runs -- what the constructor derives from `attention_resolutions` and `image_size` (:433-436). */
+#define ADF_ADM_MAX_LEVELS 8
+typedef struct adf_adm_config {
+    int32_t in_channels, model_channels, out_channels, num_res_blocks;
+    int32_t n_mult; int32_t channel_mult[ADF_ADM_MAX_LEVELS];
+    int32_t n_attention_ds; int32_t attention_ds[ADF_ADM_MAX_LEVELS];
+    int32_t conv_resample, num_heads, num_head_channels, use_scale_shift_norm, resblock_updown, use_new_attention_order;
+    int32_t num_classes;                    /* 0 = unconditional (class-conditional nets are not on the device yet) */
+    int32_t dtype;
+} adf_adm_config;
+
 typedef struct adf_handle adf_handle;
 
 int adf_create(const adf_net_config* cfg, adf_handle** out);
+/* A UNetModel (ADM) handle: x / out of adf_net_forward, adf_denoise, adf_sampler_run are [B][C][H][W] fp32 with L = H * W, the
+ * shape given by adf_set_image_shape before the call.  On the device: the configuration of BASELINE config 4 (scale-shift norm,
+ * conv resampling, no resblock up/down, unconditional), either attention order.  Debug taps: "input_blocks.<i>", "middle_block",
+ * "output_blocks.<i>" (the outputs of the reference's blocks). */
+int adf_adm_create(const adf_adm_config* cfg, adf_handle** out);
+int adf_set_image_shape(adf_handle* h, int H, int W);
 /* A WaveNetNoise handle.  x / out of adf_net_forward, adf_denoise, adf_sampler_run are [B][1][T] (the reference's forward takes
  * audio [B][T] and returns [B][1][T]: same memory); any T >= 1.  Debug taps: "y<n>" = input of residual layer n including its
  * diffusion-step addend (kept while all of them fit 256 MiB), "skip" = the normalised skip sum. */

@@ -1,0 +1,122 @@
+"""ADM-style 2-D U-Net ``UNetModel`` (BASELINE configs[3]): plugin contract on CPU; on the GPU the HIP path
+through the C ABI in fp32 mode against the REFERENCE's own outputs (fixtures of oracle/gen_golden_next.py): network output, every
+block output, the default 71 M-parameter net at 1 x 80 x 256, and config 4's 35-step churn sampler (69 evaluations, injected draws);
+bf16 mode against fp32 as a storage-precision figure."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import audiodiffuser_amd as A
+from audiodiffuser_amd import _lib
+from audiodiffuser_amd.adm_config import param_specs, generate_weights
+from oracle import unet2d_oai as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = torch.from_numpy
+FP32_TOL = 1e-3        # north-star bar, relative to the reference
+FP32_TIGHT = 5e-5      # exact-fp32 FMA chains in another summation order (measured ~2e-6)
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "next_golden.npz"))
+
+
+def make(cfg, dtype="fp32", seed=3):
+    w = generate_weights(cfg, seed=seed)
+    net = A.UNetModel.from_config(cfg, compute_dtype=dtype)
+    net.load_state_dict(w, strict=True)
+    return net, w
+
+
+def test_plugin_state_dict_contract_and_refusals():
+    cfg = A.config_c4()
+    net = A.UNetModel(in_channels=1, out_channels=1)                        # every other argument the reference's default
+    sd, specs = net.state_dict(), param_specs(cfg)
+    assert list(sd) == list(specs) and all(tuple(sd[k].shape) == specs[k][0] for k in specs)
+    assert sum(p.numel() for p in net.parameters()) == 70950273
+    assert float(sd["out.2.weight"].abs().max()) == 0.0 and float(sd["middle_block.1.proj_out.weight"].abs().max()) == 0.0   # zero_module
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 1, 16, 32), torch.zeros(1))
+    for kw in ({"num_classes": 4}, {"resblock_updown": True}, {"use_scale_shift_norm": False}, {"conv_resample": False}):
+        with pytest.raises(NotImplementedError):
+            A.UNetModel(**kw)
+    assert C.sizeof(_lib.AdfAdmConfig) == 4 * (4 + 1 + 8 + 1 + 8 + 8)
+    c = _lib.make_adm_config(cfg, _lib.DTYPE_BF16)
+    assert (c.n_mult, list(c.channel_mult)[:4], c.n_attention_ds, c.attention_ds[0]) == (4, [1, 2, 2, 4], 1, 16)
+
+
+@pytest.mark.gpu
+def test_fp32_forward_and_block_outputs_vs_reference_golden(gold):
+    cfg = A.config_c4_small()
+    net, _ = make(cfg)
+    net = net.cuda()
+    x, t = T(gold["adm_small_x"]), T(gold["adm_small_t"])
+    y = net(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    assert y.shape == x.shape
+    e = rel(y.cpu(), T(gold["adm_small_y"]))
+    assert e < FP32_TIGHT < FP32_TOL, e
+    hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+    names = hd.tap_names()
+    assert len(names) == 9
+    for k in names:
+        tap = hd.tap(k, 2, torch.device("cuda")).cpu()
+        et = rel(tap.reshape(2, -1)[:, ::16], T(gold[f"adm_small_tap_{k}"]))
+        assert et < FP32_TIGHT, (k, et)
+
+
+@pytest.mark.gpu
+def test_fp32_new_attention_order_vs_oracle():
+    """use_new_attention_order=True (no row permutation of the qkv weights) with per-head width 16."""
+    cfg = A.ADMConfig(**{**A.config_c4_small().to_kwargs(), "use_new_attention_order": True, "num_head_channels": 16})
+    net, w = make(cfg, seed=8)
+    g = torch.Generator().manual_seed(2)
+    x, t = torch.randn(3, 1, 16, 32, generator=g), torch.tensor([0.2, -0.7, 1.0])
+    with torch.no_grad():
+        ref = O.unet2d_forward(w, cfg, x, t)
+    assert rel(net.cuda()(x.cuda(), t.cuda()).cpu(), ref) < FP32_TIGHT
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_config4_full_size_fp32_and_bf16(gold):
+    """The BASELINE config-4 network itself (default constructor, 1 x 80 x 256): fp32 against the reference's output; bf16 against
+    fp32 as a storage-precision figure."""
+    cfg = A.config_c4()
+    net, _ = make(cfg, seed=4)
+    x, t = T(gold["adm_c4_x"]), T(gold["adm_c4_t"])
+    y = net.cuda()(x.cuda(), t.cuda()).cpu()
+    assert rel(y, T(gold["adm_c4_y"])) < FP32_TIGHT
+    net16, _ = make(cfg, "bf16", seed=4)
+    y16 = net16.cuda()(x.cuda(), t.cuda()).cpu()
+    e = float((y16 - y).norm() / y.norm())
+    assert e < 5e-2, e
+
+
+@pytest.mark.gpu
+def test_config4_sampler_with_injected_draws_vs_reference_golden(gold):
+    """EDMSampler(s_churn=40, s_noise=1.003, s_tmin=0.05, s_tmax=50, num_steps=35): 69 evaluations on a 4-D state, the
+    reference's randn_like draws injected; eager and graph-replayed; the denoise wrapper at one sigma."""
+    cfg = A.config_c4_small()
+    net, w = make(cfg)
+    net = net.cuda()
+    diff = A.EluDiffusion(sigma_data=0.5)
+    noise, draws, sig = T(gold["adm_samp_noise"]), T(gold["adm_samp_draws"]), T(gold["adm_samp_sigmas"])
+    for use_graph in (False, True, True):
+        smp = A.EDMSampler(s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, num_steps=35, use_graph=use_graph)
+        y = smp(noise.cuda(), fn=diff.denoise_fn, net=net, sigmas=sig, injected_noise=draws.cuda()).cpu()
+        assert y.shape == noise.shape
+        assert rel(y, T(gold["adm_samp_y"])) < 2e-4, (use_graph, rel(y, T(gold["adm_samp_y"])))
+    from oracle import edm as E
+    with torch.no_grad():
+        d = diff.denoise_fn(noise.cuda(), net=net, inference=True, sigma=1.7).cpu()
+        ref = E.denoise(lambda xi, ti, **kw: O.unet2d_forward(w, cfg, xi, ti), noise, 0.5, sigma=1.7)
+    assert rel(d, ref) < FP32_TIGHT
