@@ -40,9 +40,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {"c1": "BASELINE configs[0] network", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2]", "tiny": "unit-test network",
-             "c5": "BASELINE configs[4]"}
+             "c5": "BASELINE configs[4]", "c4": "BASELINE configs[3]"}
 # per-config defaults of --batch (per GPU), --length, --num-steps: c5 = 1024 waveforms over 8 GPUs, 22050 samples, 6-step sampler
-DEFAULTS = {"c5": (128, 22050, 6)}
+# c4 = one 80 x 256 mel block per sample (length = 80 * 256 bins), 35-step stochastic EDM sampler; BASELINE gives no batch: 16
+DEFAULTS = {"c5": (128, 22050, 6), "c4": (16, 80 * 256, 35)}
+C4_SHAPE = (80, 256)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 SURVEY_REFERENCE_CONFIG1_S = 3.81    # the reference itself, config 1, in the build container (8 threads)
@@ -53,12 +55,12 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "tiny", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "tiny", "c5", "c4"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=None, help="waveforms per GPU (default 64; c5: 128)")
     ap.add_argument("--length", type=int, default=None, help="samples per waveform (default 16384; c5: 22050)")
     ap.add_argument("--num-steps", type=int, default=None, help="sigma schedule length N (Heun => 2N-1 NFE; default 50; c5: 6)")
-    ap.add_argument("--sampler", default=None, choices=["heun", "dpm"], help="default: heun, dpm for --config c3")
+    ap.add_argument("--sampler", default=None, choices=["heun", "dpm", "churn"], help="default: heun; dpm for --config c3; churn (the stochastic EDM sampler of configs[3]) for c4")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
@@ -73,7 +75,7 @@ def parse(argv=None):
     a.length = dl if a.length is None else a.length
     a.num_steps = dn if a.num_steps is None else a.num_steps
     if a.sampler is None:
-        a.sampler = "dpm" if a.config == "c3" else "heun"
+        a.sampler = "dpm" if a.config == "c3" else ("churn" if a.config == "c4" else "heun")
     return a
 
 
@@ -199,6 +201,64 @@ def wavenet_roofline(hd, cfg, batch, length, dtype, iters, device):
     return out
 
 
+def adm_conv_flops(cfg, batch, H, W):
+    """Multiply-add flops x 2 of every convolution / 1x1 projection / attention contraction of one UNetModel pass (from the structure)."""
+    from audiodiffuser_amd.adm_config import structure
+    s = structure(cfg)
+    fl = 0.0
+    hw = {0: (H, W)}
+    def run(layers, h, w):
+        nonlocal fl
+        for l in layers:
+            if l.kind == "conv":
+                fl += 2.0 * h * w * 9 * l.cin * l.cout
+            elif l.kind == "res":
+                fl += 2.0 * h * w * (9 * l.cin * l.cout + 9 * l.cout * l.cout + (l.cin * l.cout if l.cin != l.cout else 0))
+            elif l.kind == "attn":
+                fl += 2.0 * h * w * (3 * l.cin * l.cin + l.cin * l.cin) + 4.0 * (h * w) ** 2 * l.cin
+            elif l.kind == "down":
+                h, w = h // 2, w // 2
+                fl += 2.0 * h * w * 9 * l.cin * l.cout
+            elif l.kind == "up":
+                h, w = h * 2, w * 2
+                fl += 2.0 * h * w * 9 * l.cin * l.cout
+        return h, w
+    h, w = H, W
+    for blk in s.input_blocks:
+        h, w = run(blk, h, w)
+    h, w = run(s.middle, h, w)
+    for blk in s.output_blocks:
+        h, w = run(blk, h, w)
+    fl += 2.0 * h * w * 9 * s.input_ch * cfg.out_channels
+    return fl * batch
+
+
+def adm_pass_row(net, cfg, x, device, iters):
+    """One eager network pass timed with events on the launch stream (the pass launches on torch's current stream)."""
+    import torch
+    t = torch.zeros(x.shape[0], device=device)
+    net(x, t)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = max(2, min(iters, 5))
+    e0.record()
+    for _ in range(n):
+        net(x, t)
+    e1.record()
+    torch.cuda.synchronize()
+    return {"pass_ms": e0.elapsed_time(e1) / n, "flops": adm_conv_flops(cfg, x.shape[0], x.shape[2], x.shape[3])}
+
+
+def adm_roofline(net, cfg, x, device, dtype):
+    """First-path figure for this row: the GEMM flops of one network pass (3x3 / 1x1 convs, attention) over the pass time."""
+    row = adm_pass_row(net, cfg, x, device, 5)
+    tfs = row["flops"] / (row["pass_ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv2d_gemm_kernel (implicit GEMM over channels-last pixels), whole network pass",
+            "definition": "multiply-add flops x 2 of every conv / projection / attention contraction of one UNetModel pass / the eager pass time (events on the launch "
+                          "stream): a per-pass figure, not a single launch; the kernel is a first correct path, not tuned yet",
+            "level": -1, "conv": 0, "pass_ms": row["pass_ms"], "algorithmic_flops": row["flops"], "mfma_TFLOPs": tfs, "achieved": tfs,
+            "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS[dtype], "traffic": None}
+
+
 def pmc_traffic(a, level: int, conv: int):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured now: two child runs of
     `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --roofline-only --roofline-level K` (FETCH_SIZE and WRITE_SIZE
@@ -283,9 +343,14 @@ def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
     from oracle import edm as E, samplers as S
     cores = physical_cores()
     prev = torch.get_num_threads()
-    out = {"unit": "audio-samples/s", "kind": "port", "cpu_model": cpu_model(), "physical_cores": cores}
+    out = {"unit": "mel-bins/s" if isinstance(cfg, A.ADMConfig) else "audio-samples/s", "kind": "port", "cpu_model": cpu_model(), "physical_cores": cores}
     try:
-        if isinstance(cfg, A.WaveNetConfig):
+        if isinstance(cfg, A.ADMConfig):
+            from audiodiffuser_amd.adm_config import generate_weights as generate_adm_weights
+            from oracle import unet2d_oai as OA
+            w = generate_adm_weights(cfg, seed=0)
+            fn = lambda xx, sigma=None, sigmas=None: E.denoise(lambda xi, ti, **kw: OA.unet2d_forward(w, cfg, xi, ti), xx, 0.2, sigma=sigma, sigmas=sigmas)
+        elif isinstance(cfg, A.WaveNetConfig):
             from audiodiffuser_amd.weights import generate_wavenet_weights
             from oracle import wavenet as OW
             w = generate_wavenet_weights(cfg, seed=0)
@@ -294,9 +359,11 @@ def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
         else:
             w = generate_weights(cfg, seed=0)
             fn = E.make_denoiser(w, cfg, 0.2)
-        heavy = isinstance(cfg, A.WaveNetConfig)       # 0.83 TFLOP per waveform and evaluation: a smaller sample keeps the leg bounded
+        heavy = isinstance(cfg, (A.WaveNetConfig, A.ADMConfig))       # 0.83 / 0.2 TFLOP per sample and evaluation: a smaller sample keeps the leg bounded
         b = 1 if heavy else 2
         x = generate_noise(0, b, length) * 3.0
+        if isinstance(cfg, A.ADMConfig):
+            x = x.reshape(b, 1, *C4_SHAPE)
         reps = []
         with torch.no_grad():
             # torch's CPU convolutions do not scale to every core of a large host (oversubscription): give the CPU its best
@@ -324,7 +391,7 @@ def cpu_baseline(cfg, length, nfe_per_waveform, gpu_value):
                     "sample": f"same network and sampler as the GPU line: oracle denoiser at batch {b}, 1 warm-up + 3 x {per} evaluations, median "
                               f"{dt:.3f} s per evaluation (repeats {', '.join('%.3f' % r for r in reps)}), scaled to {nfe_per_waveform} evaluations per waveform"})
         del w, fn
-        if isinstance(cfg, A.WaveNetConfig):
+        if isinstance(cfg, (A.WaveNetConfig, A.ADMConfig)):
             out["gpu_over_cpu_same_workload"] = gpu_value / out["value"] if out.get("value") else None
             return out
         # ---- SURVEY.md 8(d) protocol on configs[0] ------------------------------------------------------------------
@@ -381,6 +448,9 @@ def gpu_config1(device):
 
 # ---------------------------------------------------------------------------------------------------- main
 def make_sampler(A, a):
+    if a.sampler == "churn":     # configs[3]: EDMSampler(s_churn=40, s_noise=1.003, s_tmin=0.05, s_tmax=50) -- 2N - 1 evaluations, one draw per step
+        return A.EDMSampler(s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, num_steps=a.num_steps, use_heun=True,
+                            use_graph=not a.no_graph), 2 * a.num_steps - 1
     if a.sampler == "heun":
         return A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=a.num_steps, use_heun=True, use_graph=not a.no_graph), 2 * a.num_steps - 1
     return A.DPMSampler(1.0, order=3, num_steps=a.num_steps, multisteps=True, x0_pred=True, log_time_spacing=False,
@@ -420,7 +490,13 @@ def main():
     from audiodiffuser_amd.distributed import rank_noise, gather_samples
 
     wavenet = a.config == "c5"
-    if wavenet:
+    adm = a.config == "c4"
+    if adm:
+        from audiodiffuser_amd.adm_config import generate_weights as generate_adm_weights
+        cfg = A.config_c4()
+        make_net = lambda dt: A.UNetModel.from_config(cfg, compute_dtype=dt)
+        make_weights = lambda: generate_adm_weights(cfg, seed=0)
+    elif wavenet:
         from audiodiffuser_amd.weights import generate_wavenet_weights
         cfg = A.config_c5()
         make_net = lambda dt: A.WaveNetNoise.from_config(cfg, compute_dtype=dt)
@@ -437,9 +513,17 @@ def main():
     sampler, nfe = make_sampler(A, a)
     global_batch = a.batch * world
     noise = rank_noise(global_batch, a.length, rank, world).to(device)
+    extra = {}
+    if adm:
+        if a.length != C4_SHAPE[0] * C4_SHAPE[1]:
+            raise SystemExit("--config c4 runs on 80 x 256 mel blocks")
+        noise = noise.reshape(noise.shape[0], 1, *C4_SHAPE).contiguous()
+    if a.sampler == "churn":     # synthetic per-step draws (the plugin would draw them itself; fixed here so every step times the same work)
+        g = torch.Generator(device=device).manual_seed(4321 + rank)
+        extra["injected_noise"] = torch.randn((a.num_steps,) + tuple(noise.shape), generator=g, device=device)
 
     def step():
-        y = sampler(noise, fn=diff.denoise_fn, net=net, sigmas=sigmas)
+        y = sampler(noise, fn=diff.denoise_fn, net=net, sigmas=sigmas, **extra)
         return gather_samples(y, global_batch)
 
     def fence():
@@ -451,7 +535,9 @@ def main():
     if a.roofline_only:
         net(noise[:a.batch], torch.zeros(a.batch, device=device))
         torch.cuda.synchronize()
-        if wavenet:
+        if adm:
+            rows = [adm_pass_row(net, cfg, noise[:a.batch], device, a.roofline_iters)]
+        elif wavenet:
             rows = wavenet_rows(hd, a.batch, a.length, a.roofline_iters, device, [max(a.roofline_level, 0)])
         else:
             rows = replay_rows(hd, a.batch, a.length, a.roofline_iters, device, a.roofline_level, a.roofline_conv)
@@ -474,15 +560,18 @@ def main():
     clamped = float(out.abs().max()) <= 1.0 + 1e-6
     waveforms = global_batch * a.steps
     value = waveforms * a.length / dt
-    sname = "Heun" if a.sampler == "heun" else "DPM-Solver multistep"
+    sname = {"heun": "Heun", "dpm": "DPM-Solver multistep", "churn": "stochastic EDM (Heun + churn)"}[a.sampler]
     res = {
-        "metric": f"audio samples/sec ({a.length}-sample waveform, {a.num_steps}-step {sname})", "value": value, "unit": "audio-samples/s",
+        "metric": (f"mel bins/sec (80 x 256 mel block, {a.num_steps}-step {sname})" if adm else
+                   f"audio samples/sec ({a.length}-sample waveform, {a.num_steps}-step {sname})"), "value": value,
+        "unit": "mel-bins/s" if adm else "audio-samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "waveforms_per_s": waveforms / dt, "nfe_per_waveform": nfe, "finite": finite, "clamped": clamped,
         "rccl_ranks": dist.get_world_size() if world > 1 else 1,
         "config": {"workload": f"{WORKLOADS.get(a.config, a.config)}: " + (f"WaveNetNoise {cfg.residual_layers} x {cfg.residual_channels} ch (unconditional, as the reference class is)"
-                                                                            if wavenet else f"UNet1d {cfg.channels} ch") + f" ({a.config}), {a.length}-sample waveforms, "
+                                                                            if wavenet else (f"ADM UNetModel {cfg.model_channels} ch x {cfg.channel_mult}, 1 x 80 x 256 mel blocks" if adm
+                                                                                             else f"UNet1d {cfg.channels} ch")) + f" ({a.config}), {a.length}-sample waveforms, "
                                f"KarrasSchedule N={a.num_steps} {a.sampler}, batch {a.batch}/GPU, random-init weights",
                    "global_batch": global_batch, "sampler": a.sampler, "num_steps": a.num_steps, "nfe": nfe,
                    "hipgraph": not a.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
@@ -490,10 +579,14 @@ def main():
     if rank == 0:
         net(noise[:a.batch], torch.zeros(a.batch, device=device))       # one eager pass: the replay reads its operands
         torch.cuda.synchronize()
-        rf = (wavenet_roofline(hd, cfg, a.batch, a.length, a.dtype, min(a.roofline_iters, 10), device) if wavenet
-              else roofline(hd, a.batch, a.length, a.dtype, a.roofline_iters, device))
+        if adm:
+            rf = adm_roofline(net, cfg, noise[:a.batch], device, a.dtype)
+        elif wavenet:
+            rf = wavenet_roofline(hd, cfg, a.batch, a.length, a.dtype, min(a.roofline_iters, 10), device)
+        else:
+            rf = roofline(hd, a.batch, a.length, a.dtype, a.roofline_iters, device)
         res["roofline"] = rf
-        if rf and world == 1 and not a.no_pmc:
+        if rf and world == 1 and not a.no_pmc and not adm:
             traffic, detail = pmc_traffic(a, rf["level"], rf["conv"])
             rf["traffic"] = traffic
             rf["traffic_source"] = detail
@@ -504,7 +597,8 @@ def main():
             net32.load_state_dict(make_weights())
             net32 = net32.to(device)
             t1 = time.perf_counter()
-            y32 = sampler(noise[:nb].contiguous(), fn=diff.denoise_fn, net=net32, sigmas=sigmas)
+            extra32 = {k: v[:, :nb].contiguous() for k, v in extra.items()}       # the same per-step draws as the timed run
+            y32 = sampler(noise[:nb].contiguous(), fn=diff.denoise_fn, net=net32, sigmas=sigmas, **extra32)
             torch.cuda.synchronize()
             t32 = time.perf_counter() - t1
             y16 = out[:nb].to(torch.float64)

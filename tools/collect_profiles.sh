@@ -60,4 +60,9 @@ if [ -f audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so ]; then
     echo "# --- 64-position route (ADF_WN_WIDE=0)"
     ADF_WN_WIDE=0 ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so timeout -k 10 200 python tools/wn_stamps.py 5 128 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_wavenet_layer_stamps.txt
 fi
+echo "[11] ADM 2-D U-Net (config 4): bench line, kernel trace"
+timeout -k 10 600 python bench.py --config c4 --steps 1 --warmup 1 2>/dev/null | tail -1 > $out/${tag}_bench_c4_adm.json
+rm -rf /tmp/p6
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 bench.py --config c4 --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-precision-check > /tmp/p6.log 2>&1 || { tail -5 /tmp/p6.log; exit 1; }
+cp $(ls /tmp/p6/*/*kernel_stats.csv | head -1) $out/${tag}_bench_c4_kernel_stats.csv
 ls -la $out
