@@ -2,10 +2,11 @@
 // Reference: src/models/backbones/unet2d_oai.py (GroupNorm32 :10-21, timestep_embedding :31-49, Upsample :102-127, Downsample
 // :130-158, ResBlock :162-272, AttentionBlock :274-322, UNetModel :382-635).
 //
-// conv2d_gemm_kernel: implicit GEMM, 64 pixels x 128 output channels per 4-wave workgroup, K walked as (channel chunk of 128 bytes)
-// x (tap); the activation chunk of a tap is GATHERED from the channels-last input with the tap's bounds test (zero padding), the
-// GroupNorm (+ scale-shift) affine and SiLU applied on the way into LDS; nearest-x2 upsampling and stride 2 are index maps of
-// the gather, so Upsample / Downsample cost no extra pass.  Register prefetch one iteration ahead, two barriers per iteration.
+// conv2d_gemm_kernel: implicit GEMM, 128 (or 64) pixels x 128 output channels per workgroup of 8 (4) waves, K walked as (channel
+// chunk of 128 bytes) x (tap); the activation chunk of a tap is GATHERED from the channels-last input with the tap's bounds test
+// (zero padding), the GroupNorm (+ scale-shift) affine and SiLU applied on the way into LDS; nearest-x2 upsampling and stride 2 are
+// index maps of the gather, so Upsample / Downsample cost no extra pass.  Register prefetch one iteration ahead into the other of
+// two LDS stages (one barrier per iteration); the output tile leaves through LDS as 16-byte pieces with the residual added there.
 // This is the first correct path for this row (fp32 parity + a bf16 bench line); it is not yet tuned like the 1-D resblock kernels.
 #include "adf_conv2d.h"
 
@@ -19,29 +20,37 @@ typedef float c2_f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kC2Pitch = 144;       // LDS row pitch: 128 bytes of K + 16 (conflict-free 16-byte fragment reads, adf_gemm.h)
 
-template <typename T>
-__global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
+template <typename T, int TM>
+__global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a) {
     constexpr bool kBf16 = sizeof(T) == 2;
     constexpr int EPC = Elem<T>::kPerChunk;
     constexpr int KC = 128 / (int)sizeof(T);           // channels per K chunk
-    constexpr int TM = 64, TN = 128;
-    __shared__ __attribute__((aligned(16))) char ldsA[TM * kC2Pitch];
-    __shared__ __attribute__((aligned(16))) char ldsW[TN * kC2Pitch];
+    constexpr int TN = 128;
+    constexpr int NT = TM * 4;                         // threads: TM / 32 wave rows x 2 wave columns, a wave owns 32 pixels x 64 channels
+    constexpr int STAGE = (TM + TN) * kC2Pitch;        // one LDS stage: activations, then weights
+    constexpr int PO = TN * (int)sizeof(T) + 16;       // row pitch of the output tile in LDS
+    static_assert(TM * PO <= 2 * STAGE, "the output tile reuses the two stages");
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    // the (a, b) prologue table of this tile's image: read from global it costs four 16-byte loads per staged activation piece
+    // (4x the bytes of the activations themselves, 57 % of the first version's time went there); a tile lies inside one image
+    __shared__ __attribute__((aligned(16))) float abs_[2 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave >> 1, wn = wave & 1;
     const int HW = a.H * a.W;
     const long long m0 = (long long)blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
     const int Hin = a.mode == 1 ? a.H / 2 : (a.mode == 2 ? a.H * 2 : a.H);
     const int Win = a.mode == 1 ? a.W / 2 : (a.mode == 2 ? a.W * 2 : a.W);
 
-    // the two activation pieces this thread stages per iteration: rows tid >> 3 and 32 + (tid >> 3), 16-byte piece tid & 7
-    const int c16 = tid & 7;
-    int pb[2], py[2], px[2];
+    // staging: TM * 8 activation pieces and TN * 8 weight pieces of 16 bytes per iteration; thread -> (row tid >> 3 (+ NT / 8 ...), piece tid & 7)
+    constexpr int RPT = NT / 8;                        // rows covered by one sweep of the workgroup
+    constexpr int NA = TM / RPT, NW = TN / RPT;        // sweeps: 2 for the activations, 2 (TM = 128) or 4 (TM = 64) for the weights
+    const int c16 = tid & 7, srow = tid >> 3;
+    int pb[NA], py[NA], px[NA];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const long long p = m0 + (tid >> 3) + 32 * k;
+    for (int k = 0; k < NA; ++k) {
+        const long long p = m0 + srow + RPT * k;
         pb[k] = (int)(p / HW);
         const int pp = (int)(p - (long long)pb[k] * HW);
         py[k] = pp / a.W; px[k] = pp - py[k] * a.W;
@@ -49,14 +58,18 @@ __global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
     const T* const xg = (const T*)a.x;
     const char* const wg = (const char*)a.w;
     const int nit = a.nchunk * a.taps;
+    if (a.ab) {
+        const float* const abg = a.ab + (size_t)(m0 / HW) * a.cin * 2;
+        for (int i = tid; i < 2 * a.cin; i += NT) abs_[i] = abg[i];
+    }
 
-    u32x4_t ra[2], rw[4];
-    bool va[2];
+    u32x4_t ra[NA], rw[NW];
+    bool va[NA];
     auto load_regs = [&](int it) __attribute__((always_inline)) {
         const int ck = it / a.taps, tap = it - ck * a.taps;
         const int dy = a.taps == 9 ? tap / 3 : 1, dx = a.taps == 9 ? tap - (tap / 3) * 3 : 1;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NA; ++k) {
             int sy, sx;
             bool ok;
             if (a.mode == 2) {
@@ -72,8 +85,8 @@ __global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
             ra[k] = *(const u32x4_t*)(xg + off);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = (tid >> 3) + 32 * k;
+        for (int k = 0; k < NW; ++k) {
+            const int row = srow + RPT * k;
             const bool ok = n0 + row < a.n_pad;
             rw[k] = *(const u32x4_t*)(wg + (((size_t)ck * a.taps + tap) * a.n_pad + (ok ? n0 + row : 0)) * 128 + c16 * 16);
             if (!ok) rw[k] = u32x4_t{0u, 0u, 0u, 0u};
@@ -81,14 +94,15 @@ __global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
     };
     auto store_lds = [&](int it) __attribute__((always_inline)) {
         const int ck = it / a.taps;
+        char* const st = lds + (it & 1) * STAGE;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NA; ++k) {
             u32x4_t v = ra[k];
             if (!va[k]) v = u32x4_t{0u, 0u, 0u, 0u};                     // zero padding, applied after the activation
             else if (a.ab) {
                 float f[EPC];
                 unpack16<T>(v, f);
-                const float* const ab = a.ab + ((size_t)pb[k] * a.cin + (size_t)ck * KC + c16 * EPC) * 2;
+                const float* const ab = abs_ + (ck * KC + c16 * EPC) * 2;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float t = fmaf(f[e], ab[2 * e], ab[2 * e + 1]);
@@ -96,10 +110,10 @@ __global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
                 }
                 v = pack16<T>(f);
             }
-            *(u32x4_t*)(ldsA + ((tid >> 3) + 32 * k) * kC2Pitch + c16 * 16) = v;
+            *(u32x4_t*)(st + (srow + RPT * k) * kC2Pitch + c16 * 16) = v;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *(u32x4_t*)(ldsW + ((tid >> 3) + 32 * k) * kC2Pitch + c16 * 16) = rw[k];
+        for (int k = 0; k < NW; ++k) *(u32x4_t*)(st + (TM + srow + RPT * k) * kC2Pitch + c16 * 16) = rw[k];
     };
 
     c2_f32x16_t acc[2];
@@ -107,15 +121,17 @@ __global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-    const char* const aRow = ldsA + (wm * 32 + r) * kC2Pitch;
-    const char* const wRow = ldsW + (wn * 64 + r) * kC2Pitch;
 
+    // one barrier per iteration: while iteration `it` computes from stage it & 1, the registers of iteration it + 1 (loaded before
+    // the MFMAs) are written to the other stage afterwards
     load_regs(0);
+    __syncthreads();                                   // the prologue table is in LDS
+    store_lds(0);
+    __syncthreads();
     for (int it = 0; it < nit; ++it) {
-        if (it > 0) __syncthreads();
-        store_lds(it);
-        __syncthreads();
         if (it + 1 < nit) load_regs(it + 1);
+        const char* const aRow = lds + (it & 1) * STAGE + (wm * 32 + r) * kC2Pitch;
+        const char* const wRow = lds + (it & 1) * STAGE + (TM + wn * 64 + r) * kC2Pitch;
         if constexpr (kBf16) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -144,39 +160,280 @@ __global__ void __launch_bounds__(256) conv2d_gemm_kernel(const Conv2dArgs a) {
                         for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][e], fb[j][u][e], acc[j], 0, 0, 0);
             }
         }
+        if (it + 1 < nit) store_lds(it + 1);
+        __syncthreads();
     }
 
-    // ---- epilogue: bias, optional residual, store (accumulator layout: column r, rows (q & 3) + 8 (q >> 2) + 4 h) -------------
-    T* const og = (T*)a.out;
-    const T* const rg = (const T*)a.res;
+    // ---- epilogue: accumulators (+ bias) -> LDS tile -> 16-byte pieces (+ residual) -> global ---------------------------------
+    // (accumulator layout: column r, rows (q & 3) + 8 (q >> 2) + 4 h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + r;
-        if (col >= a.cout) continue;
-        const float bias = a.bias ? a.bias[col] : 0.f;
+        const int lc = wn * 64 + j * 32 + r;
+        const float bias = (a.bias && n0 + lc < a.cout) ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            const size_t o = (size_t)(m0 + row) * a.cout + col;
-            float v = acc[j][q] + bias;
-            if (rg) v += Elem<T>::ld(rg + o);
-            Elem<T>::st(og + o, v);
+            Elem<T>::st((T*)(lds + row * PO) + lc, acc[j][q] + bias);
         }
     }
+    __syncthreads();
+    constexpr int PPR = TN / EPC;                      // 16-byte pieces per tile row
+    T* const og = (T*)a.out;
+    const T* const rg = (const T*)a.res;
+    for (int idx = tid; idx < TM * PPR; idx += NT) {
+        const int row = idx / PPR, pc = idx - row * PPR;
+        const int col = n0 + pc * EPC;
+        if (col >= a.cout) continue;                   // cout is a multiple of the piece (checked by the launcher)
+        u32x4_t v = *(const u32x4_t*)(lds + row * PO + pc * 16);
+        const size_t o = (size_t)(m0 + row) * a.cout + col;
+        if (rg) {
+            float f[EPC], g[EPC];
+            unpack16<T>(v, f);
+            unpack16<T>(*(const u32x4_t*)(rg + o), g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] += g[e];
+            v = pack16<T>(f);
+        }
+        *(u32x4_t*)(og + o) = v;
+    }
+}
+
+// The same-size 3x3 convs (the two convs of every ResBlock: > 90 % of the network's flops) on SPATIAL tiles: TH x 32 output pixels
+// per workgroup.  A K chunk of the (TH + 2) x 34 halo is gathered, activated and staged ONCE and serves all nine taps -- a tap is a
+// row offset into the halo -- so the GroupNorm / SiLU prologue and the gather's address arithmetic run once per halo pixel and chunk
+// instead of once per pixel, chunk AND tap (the per-tap gather above spends ~4x the MFMA cycles on vector work); the weight slab of a
+// (chunk, tap) is the only thing staged per iteration.  A wave owns one tile row (32 pixels) x 64 channels.
+template <typename T, int TH>
+__global__ void __launch_bounds__(TH * 128) conv2d_tile_kernel(const Conv2dArgs a) {
+    constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int KC = 128 / (int)sizeof(T);
+    constexpr int TW = 32, TM = TH * TW, TN = 128;
+    constexpr int NT = TH * 128;                       // 2 TH waves
+    constexpr int HR = (TH + 2) * (TW + 2);            // halo rows
+    constexpr int ASTAGE = HR * kC2Pitch, WSTAGE = TN * kC2Pitch;
+    constexpr int PO = TN * (int)sizeof(T) + 16;
+    // (the output tile of the epilogue reuses the stages and the table; the launcher sizes the allocation for the larger of the two)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const ldsA = lds;                            // ONE halo stage (restaged between chunks behind a barrier): with two the
+                                                       // workgroup takes 104 KB and a CU holds a single one, whose start-up, barriers
+                                                       // and epilogue nothing overlaps (K is only 18 iterations at 128 channels)
+    char* const ldsW = lds + ASTAGE;                   // 2 weight stages
+    float* const abs_ = (float*)(ldsW + 2 * WSTAGE);   // [cin][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * TH;
+    const int b = bid / tiles_y;
+    const int n0 = blockIdx.y * TN;
+    const T* const xg = (const T*)a.x + (size_t)b * a.H * a.W * a.cin;
+    const char* const wg = (const char*)a.w;
+    if (a.ab) {
+        const float* const abg = a.ab + (size_t)b * a.cin * 2;
+        for (int i = tid; i < 2 * a.cin; i += NT) abs_[i] = abg[i];
+    }
+
+    // halo pieces of this thread: piece ids tid + k NT over HR * 8 pieces; (pixel offset, validity) are fixed for the whole kernel
+    constexpr int NHP = (HR * 8 + NT - 1) / NT;
+    int hoff[NHP];                                     // element offset of the halo pixel's channel 0, or -1 = outside the image / no piece
+#pragma unroll
+    for (int k = 0; k < NHP; ++k) {
+        const int id = tid + k * NT;
+        const int row = id >> 3;
+        const int hy = row / (TW + 2), hx = row - hy * (TW + 2);
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        hoff[k] = (id < HR * 8 && y >= 0 && y < a.H && x >= 0 && x < a.W) ? (y * a.W + x) * a.cin + (id & 7) * EPC : -1;
+    }
+    u32x4_t ra[NHP], rw[2];
+    auto load_a = [&](int ck) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NHP; ++k) ra[k] = *(const u32x4_t*)(xg + (hoff[k] >= 0 ? hoff[k] + ck * KC : 0));
+    };
+    auto store_a = [&](int ck) __attribute__((always_inline)) {
+        char* const st = ldsA;
+#pragma unroll
+        for (int k = 0; k < NHP; ++k) {
+            const int id = tid + k * NT;
+            if (id >= HR * 8) continue;
+            u32x4_t v = ra[k];
+            if (hoff[k] < 0) v = u32x4_t{0u, 0u, 0u, 0u};                 // zero padding, applied after the activation
+            else if (a.ab) {
+                float f[EPC];
+                unpack16<T>(v, f);
+                const float* const ab = abs_ + (ck * KC + (id & 7) * EPC) * 2;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float t = fmaf(f[e], ab[2 * e], ab[2 * e + 1]);
+                    f[e] = a.act ? (kBf16 ? silu_f(t) : t / (1.0f + expf(-t))) : t;
+                }
+                v = pack16<T>(f);
+            }
+            *(u32x4_t*)(st + (id >> 3) * kC2Pitch + (id & 7) * 16) = v;
+        }
+    };
+    // weight slabs travel TWO iterations ahead in two register sets (one iteration of 8 MFMAs per wave does not cover an L2 round trip)
+    constexpr int NWP = TN * 8 / NT;                   // weight pieces per thread and iteration: 2 (TH = 4) or 4 (TH = 2)
+    u32x4_t rwv[2][NWP];
+    auto load_w = [&](int it, u32x4_t (&rv)[NWP]) __attribute__((always_inline)) {     // it = ck * 9 + tap: the packed order [chunk][tap]
+#pragma unroll
+        for (int k = 0; k < NWP; ++k) {
+            const int id = tid + k * NT, row = id >> 3;
+            const bool ok = n0 + row < a.n_pad;
+            rv[k] = *(const u32x4_t*)(wg + ((size_t)it * a.n_pad + (ok ? n0 + row : 0)) * 128 + (id & 7) * 16);
+            if (!ok) rv[k] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_w = [&](int it, const u32x4_t (&rv)[NWP]) __attribute__((always_inline)) {
+        char* const st = ldsW + (it & 1) * WSTAGE;
+#pragma unroll
+        for (int k = 0; k < NWP; ++k) { const int id = tid + k * NT; *(u32x4_t*)(st + (id >> 3) * kC2Pitch + (id & 7) * 16) = rv[k]; }
+    };
+    (void)rw;
+
+    c2_f32x16_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+    const int nit = a.nchunk * 9;
+    load_a(0);
+    load_w(0, rwv[0]);
+    if (nit > 1) load_w(1, rwv[1]);
+    __syncthreads();                                   // the prologue table is in LDS
+    store_a(0);
+    store_w(0, rwv[0]);
+    __syncthreads();
+    // iteration `it` (register set s = it & 1 holds W(it + 1) on entry): issue W(it + 2) into the set that W(it) came from, compute
+    // from LDS stage it & 1, store W(it + 1) into the other stage
+    auto iteration = [&](int it, u32x4_t (&r_next)[NWP], u32x4_t (&r_free)[NWP]) __attribute__((always_inline)) {
+        const int ck = it / 9, tap = it - ck * 9;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        if (it + 2 < nit) load_w(it + 2, r_free);
+        if (tap == 0 && ck + 1 < a.nchunk) load_a(ck + 1);          // the next chunk's halo travels during this chunk's nine taps
+        const char* const aRow = ldsA + ((wm + dy) * (TW + 2) + r + dx) * kC2Pitch;
+        const char* const wRow = ldsW + (it & 1) * WSTAGE + (wn * 64 + r) * kC2Pitch;
+        if constexpr (kBf16) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const c2_bf16x8_t fa = *(const c2_bf16x8_t*)(aRow + (ks * 2 + h) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const c2_bf16x8_t fb = *(const c2_bf16x8_t*)(wRow + j * 32 * kC2Pitch + (ks * 2 + h) * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                c2_f32x4_t fa[2], fb[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) fa[u] = *(const c2_f32x4_t*)(aRow + (ks * 4 + 2 * h + u) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) fb[j][u] = *(const c2_f32x4_t*)(wRow + j * 32 * kC2Pitch + (ks * 4 + 2 * h + u) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][e], fb[j][u][e], acc[j], 0, 0, 0);
+            }
+        }
+        if (it + 1 < nit) store_w(it + 1, r_next);
+        if (tap == 8 && ck + 1 < a.nchunk) {                          // every wave must have left this chunk's halo before it is replaced
+            __syncthreads();
+            store_a(ck + 1);
+        }
+        __syncthreads();
+    };
+    for (int it = 0; it < nit; it += 2) {
+        iteration(it, rwv[1], rwv[0]);
+        if (it + 1 < nit) iteration(it + 1, rwv[0], rwv[1]);
+    }
+
+    // ---- epilogue through LDS (as conv2d_gemm_kernel): tile row wm, pixel r of that row ------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lc = wn * 64 + j * 32 + r;
+        const float bias = (a.bias && n0 + lc < a.cout) ? a.bias[n0 + lc] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            Elem<T>::st((T*)(lds + row * PO) + lc, acc[j][q] + bias);
+        }
+    }
+    __syncthreads();
+    constexpr int PPR = TN / EPC;
+    T* const og = (T*)a.out + (size_t)b * a.H * a.W * a.cout;
+    const T* const rg = a.res ? (const T*)a.res + (size_t)b * a.H * a.W * a.cout : nullptr;
+    for (int idx = tid; idx < TM * PPR; idx += NT) {
+        const int row = idx / PPR, pc = idx - row * PPR;
+        const int col = n0 + pc * EPC;
+        if (col >= a.cout) continue;
+        u32x4_t v = *(const u32x4_t*)(lds + row * PO + pc * 16);
+        const size_t o = ((size_t)(ty0 + row / TW) * a.W + tx0 + (row % TW)) * a.cout + col;
+        if (rg) {
+            float f[EPC], g[EPC];
+            unpack16<T>(v, f);
+            unpack16<T>(*(const u32x4_t*)(rg + o), g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] += g[e];
+            v = pack16<T>(f);
+        }
+        *(u32x4_t*)(og + o) = v;
+    }
+}
+
+template <typename T, int TH>
+static const char* launch_conv2d_tile(const Conv2dArgs& a, hipStream_t s) {
+    constexpr int HR = (TH + 2) * 34;
+    const size_t stages = (size_t)HR * kC2Pitch + 2 * 128 * kC2Pitch + (size_t)2 * a.cin * 4;
+    const size_t otile = (size_t)TH * 32 * (128 * sizeof(T) + 16);
+    const size_t lds = stages > otile ? stages : otile;
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr = attr_done[current_device()];
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv2d_tile_kernel<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return "conv2d_tile: hipFuncSetAttribute failed";
+        attr = true;
+    }
+    const dim3 grid((unsigned)(a.B * (a.H / TH) * (a.W / 32)), (unsigned)ceil_div(a.cout, 128)), blk(TH * 128);
+    hipLaunchKernelGGL((conv2d_tile_kernel<T, TH>), grid, blk, lds, s, a);
+    return C2_LAUNCH_CHECK("conv2d_tile");
 }
 
 const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     const int kc = bf16 ? 64 : 32;
     if (a.taps != 9 && a.taps != 1) return "conv2d: taps must be 9 or 1";
     if (a.taps == 1 && a.mode != 0) return "conv2d: a 1x1 conv has no resampling mode";
-    if (a.cin % kc) return "conv2d: input channels must be a multiple of the 128-byte K chunk";
+    if (a.cin % kc || a.cin > 1024) return "conv2d: input channels must be a multiple of the 128-byte K chunk, at most 1024";
     if (a.nchunk * kc != a.cin) return "conv2d: packed weight chunk count does not match the input channels";
+    if (a.cout % (bf16 ? 8 : 4)) return "conv2d: output channels must be a multiple of a 16-byte piece";
+    const long long px = (long long)a.B * a.H * a.W;
     if (((long long)a.H * a.W) % 64) return "conv2d: H*W must be a multiple of 64";
     if (a.mode == 1 && ((a.H | a.W) & 1)) return "conv2d: upsampled output must have even height and width";
-    const long long tiles = (long long)a.B * a.H * a.W / 64;
-    const dim3 grid((unsigned)tiles, (unsigned)ceil_div(a.cout, 128)), blk(256);
-    if (bf16) hipLaunchKernelGGL(conv2d_gemm_kernel<bf16_t>, grid, blk, 0, s, a);
-    else hipLaunchKernelGGL(conv2d_gemm_kernel<float>, grid, blk, 0, s, a);
+    const unsigned ny = (unsigned)ceil_div(a.cout, 128);
+    // same-size 3x3: spatial tiles (the halo staged once per chunk serves all nine taps); route switch for the parity tests
+    static const int tile_route = adf_route_switch("ADF_CONV2D_TILE", 1);
+    if (tile_route && a.taps == 9 && a.mode == 0 && a.W % 32 == 0 && (long long)a.H * a.W * a.cin < (1ll << 31)) {
+        if (a.H % 4 == 0 && px / 128 * ny >= 128) return bf16 ? launch_conv2d_tile<bf16_t, 4>(a, s) : launch_conv2d_tile<float, 4>(a, s);
+        if (a.H % 2 == 0) return bf16 ? launch_conv2d_tile<bf16_t, 2>(a, s) : launch_conv2d_tile<float, 2>(a, s);
+    }
+    // 128-pixel tiles (each weight piece staged once per 128 pixels) when the image divides and the grid still fills the chip
+    if (((long long)a.H * a.W) % 128 == 0 && px / 128 * ny >= 512) {
+        const dim3 grid((unsigned)(px / 128), ny), blk(512);
+        if (bf16) hipLaunchKernelGGL((conv2d_gemm_kernel<bf16_t, 128>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((conv2d_gemm_kernel<float, 128>), grid, blk, 0, s, a);
+    } else {
+        const dim3 grid((unsigned)(px / 64), ny), blk(256);
+        if (bf16) hipLaunchKernelGGL((conv2d_gemm_kernel<bf16_t, 64>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((conv2d_gemm_kernel<float, 64>), grid, blk, 0, s, a);
+    }
     return C2_LAUNCH_CHECK("conv2d");
 }
 
@@ -186,6 +443,14 @@ __global__ void __launch_bounds__(256) conv2d_in_kernel(const float* __restrict_
                                                         T* __restrict__ out, int B, int cin, int H, int W, int cout,
                                                         const float* __restrict__ coef, int coef_bstride) {
     constexpr int EPC = Elem<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const ws = (float*)smem;                    // [cin][9][cout] + bias [cout]
+    for (int i = threadIdx.x; i < cout * cin * 9; i += 256) {
+        const int t = i % 9, ci = (i / 9) % cin, co = i / (9 * cin);
+        ws[(ci * 9 + t) * cout + co] = w[i];
+    }
+    for (int i = threadIdx.x; i < cout; i += 256) ws[cin * 9 * cout + i] = bias[i];
+    __syncthreads();
     const int cpr = cout / EPC;
     const long long total = (long long)B * H * W * cpr;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -197,15 +462,22 @@ __global__ void __launch_bounds__(256) conv2d_in_kernel(const float* __restrict_
         const float sc = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
         float f[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) f[e] = bias[cc * EPC + e];
-        for (int ci = 0; ci < cin; ++ci)
+        for (int e = 0; e < EPC; ++e) f[e] = ws[cin * 9 * cout + cc * EPC + e];
+        for (int ci = 0; ci < cin; ++ci) {
+            float v[9];
+#pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
-                if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-                const float v = x[(((size_t)b * cin + ci) * H + sy) * W + sx] * sc;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) f[e] = fmaf(w[((size_t)(cc * EPC + e) * cin + ci) * 9 + t], v, f[e]);
+                const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                v[t] = ok ? x[(((size_t)b * cin + ci) * H + sy) * W + sx] * sc : 0.0f;
             }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float* const wp = ws + (ci * 9 + t) * cout + cc * EPC;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = fmaf(wp[e], v[t], f[e]);
+            }
+        }
         *(u32x4_t*)(out + p * cout + cc * EPC) = pack16<T>(f);
     }
 }
@@ -213,9 +485,11 @@ const char* launch_conv2d_in(const float* x, const float* w, const float* bias, 
                              const float* coef, int coef_bstride, hipStream_t s) {
     if (cout % (bf16 ? 8 : 4)) return "conv2d_in: output channels must be a multiple of a 16-byte chunk";
     const long long total = (long long)B * H * W * (cout / (bf16 ? 8 : 4));
-    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    if (bf16) hipLaunchKernelGGL(conv2d_in_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, w, bias, (bf16_t*)out, B, cin, H, W, cout, coef, coef_bstride);
-    else hipLaunchKernelGGL(conv2d_in_kernel<float>, dim3(blocks), dim3(256), 0, s, x, w, bias, (float*)out, B, cin, H, W, cout, coef, coef_bstride);
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const size_t lds = ((size_t)cout * cin * 9 + cout) * 4;
+    if (lds > 64 * 1024) return "conv2d_in: weights do not fit LDS";
+    if (bf16) hipLaunchKernelGGL(conv2d_in_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, x, w, bias, (bf16_t*)out, B, cin, H, W, cout, coef, coef_bstride);
+    else hipLaunchKernelGGL(conv2d_in_kernel<float>, dim3(blocks), dim3(256), lds, s, x, w, bias, (float*)out, B, cin, H, W, cout, coef, coef_bstride);
     return C2_LAUNCH_CHECK("conv2d_in");
 }
 

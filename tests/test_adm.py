@@ -86,6 +86,19 @@ def test_fp32_new_attention_order_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_fp32_larger_batch_and_image_vs_oracle():
+    """B = 8 at 32 x 64: enough tiles for the 4 x 32-pixel spatial route of the 3x3 convs at the first level (the fixtures above run the
+    2 x 32 route and, where the width is not a multiple of 32, the per-tap gather kernel)."""
+    cfg = A.config_c4_small()
+    net, w = make(cfg, seed=9)
+    g = torch.Generator().manual_seed(5)
+    x, t = torch.randn(8, 1, 32, 64, generator=g), torch.linspace(-1.0, 1.0, 8)
+    with torch.no_grad():
+        ref = O.unet2d_forward(w, cfg, x, t)
+    assert rel(net.cuda()(x.cuda(), t.cuda()).cpu(), ref) < FP32_TIGHT
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_config4_full_size_fp32_and_bf16(gold):
     """The BASELINE config-4 network itself (default constructor, 1 x 80 x 256): fp32 against the reference's output; bf16 against
