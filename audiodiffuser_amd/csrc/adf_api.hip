@@ -1028,13 +1028,13 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         W.check(launch_adm_time_embed(io.t, io.t_stride, io.nb, c.model_channels, a.t_w1, a.t_b1, a.t_w2, a.t_b2, ted, p->temb, s));
         W.check(launch_film(p->temb, ted, h->film_w, ted, 0, h->film_b, p->film, io.nb, h->film_total, s));
     }
-    struct T2 { Act t; int H, W; };
+    struct T2 { Act t; int H, W; double* st = nullptr; };     // st: GroupNorm statistics of the tensor, when its producer reduced them
     // GroupNorm32 (:10-21) (+ scale-shift, :262-267) of a tensor folded to the per-(sample, channel) table a conv prologue reads
     auto gn_table = [&](const T2& x, const float* gamma, const float* beta, const float* fl) -> float* {
-        double* st = W.alloc_stats();
+        double* st = x.st ? x.st : W.alloc_stats();
         float* ab = (float*)W.alloc((size_t)B * x.t.C * 2 * 4);
         if (W.live()) {
-            W.check(launch_gn_stats_any(x.t.p, h->bf16, B, x.t.L, x.t.C, 32, st, s));
+            if (!x.st) W.check(launch_gn_stats_any(x.t.p, h->bf16, B, x.t.L, x.t.C, 32, st, s));
             GnFinalizeArgs g;
             memset(&g, 0, sizeof(g));
             g.stats0 = st; g.c0 = x.t.C; g.c1 = 0; g.L = x.t.L; g.G = 32; g.B = B; g.scale1 = 1.f; g.eps = 1e-5f;
@@ -1043,8 +1043,11 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         }
         return ab;
     };
-    auto conv = [&](const T2& x, const ConvW& w, const float* ab, int act, int mode, const void* res) -> T2 {
+    // stats: also reduce the GroupNorm statistics of the output in the epilogue (where a GroupNorm reads this tensor next)
+    auto conv = [&](const T2& x, const ConvW& w, const float* ab, int act, int mode, const void* res, bool stats) -> T2 {
         T2 y;
+        const int gsz = w.cout / 32;
+        if (stats && w.cout % 32 == 0 && gsz >= 1 && 128 % gsz == 0 && (w.cout <= 128 || w.cout % 128 == 0)) y.st = W.alloc_stats();
         y.H = mode == 1 ? x.H * 2 : (mode == 2 ? x.H / 2 : x.H);
         y.W = mode == 1 ? x.W * 2 : (mode == 2 ? x.W / 2 : x.W);
         y.t = W.new_act(w.cout, y.H * y.W);
@@ -1052,6 +1055,7 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
             Conv2dArgs g;
             g.x = x.t.p; g.ab = ab; g.act = act; g.B = B; g.H = y.H; g.W = y.W; g.cin = x.t.C; g.cout = w.cout; g.n_pad = w.n_pad;
             g.taps = w.taps; g.mode = mode; g.w = w.w; g.nchunk = w.nchunk; g.bias = w.bias; g.res = res; g.out = y.t.p;
+            g.stats = y.st; g.stats_groups = 32;
             W.check(launch_conv2d(g, h->bf16, s));
         }
         return y;
@@ -1066,22 +1070,22 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
             } else if (l.kind == 1) {                                   // ResBlock._forward, :248-272 (scale-shift form)
                 const AdmRes& r = a.res[l.idx];
                 const float* ab1 = gn_table(x, r.g1w, r.g1b, nullptr);
-                T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr);
+                T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr, true);
                 const float* ab2 = gn_table(hh, r.g2w, r.g2b, film + r.film_off);
                 const void* skip = x.t.p;
-                if (r.has_skip) skip = conv(x, r.skip, nullptr, 0, 0, nullptr).t.p;
-                x = conv(hh, r.c2, ab2, 1, 0, skip);
+                if (r.has_skip) skip = conv(x, r.skip, nullptr, 0, 0, nullptr, false).t.p;
+                x = conv(hh, r.c2, ab2, 1, 0, skip, true);
             } else if (l.kind == 2) {                                   // AttentionBlock._forward, :316-322
                 const AdmAttn& t = a.attn[l.idx];
                 const float* ab = gn_table(x, t.gw, t.gb, nullptr);
                 T2 xn; xn.H = x.H; xn.W = x.W; xn.t = W.new_act(t.c, x.t.L);
                 if (W.live()) W.check(launch_gn_apply(x.t.p, nullptr, t.c, 0, x.t.L, B, ab, 0, xn.t.p, h->bf16, s));
-                T2 qkv = conv(xn, t.qkv, nullptr, 0, 0, nullptr);
+                T2 qkv = conv(xn, t.qkv, nullptr, 0, 0, nullptr, false);
                 T2 att; att.H = x.H; att.W = x.W; att.t = W.new_act(t.c, x.t.L);
                 if (W.live()) W.check(launch_attention(qkv.t.p, att.t.p, h->bf16, B, x.t.L, t.c, t.heads, s));
-                x = conv(att, t.proj, nullptr, 0, 0, xn.t.p);          // the residual is the NORMALISED input (:318-322)
+                x = conv(att, t.proj, nullptr, 0, 0, xn.t.p, true);    // the residual is the NORMALISED input (:318-322)
             } else {
-                x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr);
+                x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr, l.kind == 3);
             }
         }
         return x;

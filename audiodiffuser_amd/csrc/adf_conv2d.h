@@ -25,6 +25,8 @@ struct Conv2dArgs {
     const float* bias;
     const void* res;        // optional, same layout / type as out
     void* out;
+    double* stats;          // optional [B][stats_groups][2]: (sum, sumsq) of the STORED output (after bias and residual) per GroupNorm group,
+    int stats_groups;       // accumulated with fp64 atomics into a pre-zeroed buffer -- the statistics the next GroupNorm reads
 };
 const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s);
 

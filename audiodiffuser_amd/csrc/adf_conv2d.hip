@@ -20,6 +20,63 @@ typedef float c2_f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kC2Pitch = 144;       // LDS row pitch: 128 bytes of K + 16 (conflict-free 16-byte fragment reads, adf_gemm.h)
 
+// Tail of both conv kernels: the output tile sits in LDS ([TM][PO], bias added); every thread walks 16-byte pieces of ONE piece column
+// (NT is a multiple of the pieces per row), adds the residual, stores, and -- if asked -- reduces the GroupNorm statistics of what it
+// stored: per-thread partial sums -> lanes of a wave that share the piece column (shuffles) -> per-channel sums in LDS -> per-group fp64
+// atomics.  pix(row) maps a tile row to its pixel's element offset / cout inside the image.
+template <typename T, int TM, int TN, int NT, typename FP>
+__device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, int PO, int tid, int n0, int b, T* og, const T* rg, FP pix) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int PPR = TN / EPC;
+    static_assert(NT % PPR == 0 && PPR <= 64 && 64 % PPR == 0, "a thread keeps one piece column");
+    const int pc = tid % PPR;
+    const int col = n0 + pc * EPC;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (col < a.cout) {
+        for (int row = tid / PPR; row < TM; row += NT / PPR) {
+            u32x4_t v = *(const u32x4_t*)(lds + row * PO + pc * 16);
+            const size_t o = pix(row) * a.cout + col;
+            float f[EPC];
+            unpack16<T>(v, f);
+            if (rg) {
+                float g[EPC];
+                unpack16<T>(*(const u32x4_t*)(rg + o), g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] += g[e];
+            }
+            v = pack16_stored<T>(f);
+            *(u32x4_t*)(og + o) = v;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] += f[e]; s2[e] = fmaf(f[e], f[e], s2[e]); }
+        }
+    }
+    if (!a.stats) return;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+#pragma unroll
+        for (int o = PPR; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+    __syncthreads();                                   // every thread has read its rows of the tile: LDS is free
+    float* const c1 = (float*)lds;                     // [TN] sums, [TN] sums of squares
+    float* const c2 = c1 + TN;
+    for (int i = tid; i < 2 * TN; i += NT) c1[i] = 0.f;
+    __syncthreads();
+    if ((tid & 63) < PPR) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { atomicAdd(&c1[pc * EPC + e], s1[e]); atomicAdd(&c2[pc * EPC + e], s2[e]); }
+    }
+    __syncthreads();
+    const int gs = a.cout / a.stats_groups;
+    if (tid < TN / gs && n0 + tid * gs < a.cout) {
+        double d1 = 0.0, d2 = 0.0;
+        for (int c = tid * gs; c < (tid + 1) * gs; ++c) { d1 += (double)c1[c]; d2 += (double)c2[c]; }
+        double* const st = a.stats + ((size_t)b * a.stats_groups + (n0 + tid * gs) / gs) * 2;
+        atomicAdd(st, d1);
+        atomicAdd(st + 1, d2);
+    }
+}
+
 template <typename T, int TM>
 __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a) {
     constexpr bool kBf16 = sizeof(T) == 2;
@@ -177,25 +234,7 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
         }
     }
     __syncthreads();
-    constexpr int PPR = TN / EPC;                      // 16-byte pieces per tile row
-    T* const og = (T*)a.out;
-    const T* const rg = (const T*)a.res;
-    for (int idx = tid; idx < TM * PPR; idx += NT) {
-        const int row = idx / PPR, pc = idx - row * PPR;
-        const int col = n0 + pc * EPC;
-        if (col >= a.cout) continue;                   // cout is a multiple of the piece (checked by the launcher)
-        u32x4_t v = *(const u32x4_t*)(lds + row * PO + pc * 16);
-        const size_t o = (size_t)(m0 + row) * a.cout + col;
-        if (rg) {
-            float f[EPC], g[EPC];
-            unpack16<T>(v, f);
-            unpack16<T>(*(const u32x4_t*)(rg + o), g);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] += g[e];
-            v = pack16<T>(f);
-        }
-        *(u32x4_t*)(og + o) = v;
-    }
+    c2_store_tile<T, TM, TN, NT>(a, lds, PO, tid, n0, (int)(m0 / HW), (T*)a.out, (const T*)a.res, [&](int row) { return (size_t)(m0 + row); });
 }
 
 // The same-size 3x3 convs (the two convs of every ResBlock: > 90 % of the network's flops) on SPATIAL tiles: TH x 32 output pixels
@@ -368,25 +407,9 @@ __global__ void __launch_bounds__(TH * 128) conv2d_tile_kernel(const Conv2dArgs 
         }
     }
     __syncthreads();
-    constexpr int PPR = TN / EPC;
     T* const og = (T*)a.out + (size_t)b * a.H * a.W * a.cout;
     const T* const rg = a.res ? (const T*)a.res + (size_t)b * a.H * a.W * a.cout : nullptr;
-    for (int idx = tid; idx < TM * PPR; idx += NT) {
-        const int row = idx / PPR, pc = idx - row * PPR;
-        const int col = n0 + pc * EPC;
-        if (col >= a.cout) continue;
-        u32x4_t v = *(const u32x4_t*)(lds + row * PO + pc * 16);
-        const size_t o = ((size_t)(ty0 + row / TW) * a.W + tx0 + (row % TW)) * a.cout + col;
-        if (rg) {
-            float f[EPC], g[EPC];
-            unpack16<T>(v, f);
-            unpack16<T>(*(const u32x4_t*)(rg + o), g);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] += g[e];
-            v = pack16<T>(f);
-        }
-        *(u32x4_t*)(og + o) = v;
-    }
+    c2_store_tile<T, TM, TN, NT>(a, lds, PO, tid, n0, b, og, rg, [&](int row) { return (size_t)(ty0 + row / TW) * a.W + tx0 + (row % TW); });
 }
 
 template <typename T, int TH>
@@ -414,6 +437,10 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     if (a.cin % kc || a.cin > 1024) return "conv2d: input channels must be a multiple of the 128-byte K chunk, at most 1024";
     if (a.nchunk * kc != a.cin) return "conv2d: packed weight chunk count does not match the input channels";
     if (a.cout % (bf16 ? 8 : 4)) return "conv2d: output channels must be a multiple of a 16-byte piece";
+    if (a.stats) {
+        const int gs = a.stats_groups > 0 ? a.cout / a.stats_groups : 0;
+        if (gs < 1 || a.cout % a.stats_groups || 128 % gs || (a.cout > 128 && a.cout % 128)) return "conv2d: statistics need a group size dividing the 128-channel tile";
+    }
     const long long px = (long long)a.B * a.H * a.W;
     if (((long long)a.H * a.W) % 64) return "conv2d: H*W must be a multiple of 64";
     if (a.mode == 1 && ((a.H | a.W) & 1)) return "conv2d: upsampled output must have even height and width";
