@@ -10,6 +10,18 @@
 // This is the first correct path for this row (fp32 parity + a bf16 bench line); it is not yet tuned like the 1-D resblock kernels.
 #include "adf_conv2d.h"
 
+#ifdef ADF_C2_STAMP
+// diagnostic build (tools/build_variant.sh c2stamp -DADF_C2_STAMP; tools/c2_stamps.py): s_memtime at the phase boundaries of the spatial-tile
+// kernel, all waves of one workgroup in the middle of the grid
+namespace adf { __device__ unsigned long long adf_c2_stamps[8 * 16]; }
+extern "C" int adf_debug_c2_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adf::adf_c2_stamps), sizeof(unsigned long long) * 8 * 16);
+}
+#define C2_STAMP(i) do { if (stamped && lane == 0) adf_c2_stamps[wave * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define C2_STAMP(i) do { } while (0)
+#endif
+
 namespace adf {
 
 #define C2_LAUNCH_CHECK(name) (hipGetLastError() == hipSuccess ? nullptr : "launch failed: " name)
@@ -230,7 +242,8 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            Elem<T>::st((T*)(lds + row * PO) + lc, acc[j][q] + bias);
+            if constexpr (kBf16) *(unsigned short*)(lds + row * PO + lc * 2) = f32_to_bf16_hw(acc[j][q] + bias);
+            else *(float*)(lds + row * PO + lc * 4) = acc[j][q] + bias;
         }
     }
     __syncthreads();
@@ -242,13 +255,15 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
 // row offset into the halo -- so the GroupNorm / SiLU prologue and the gather's address arithmetic run once per halo pixel and chunk
 // instead of once per pixel, chunk AND tap (the per-tap gather above spends ~4x the MFMA cycles on vector work); the weight slab of a
 // (chunk, tap) is the only thing staged per iteration.  A wave owns one tile row (32 pixels) x 64 channels.
-template <typename T, int TH>
-__global__ void __launch_bounds__(TH * 128) conv2d_tile_kernel(const Conv2dArgs a) {
+// WR = tile rows per wave: with one row a wave's 32 x 64 tile reads 3 KB of fragments from LDS per two MFMAs and the kernel runs at the
+// LDS read bandwidth (128 B/clk/CU) at a third of the matrix rate; two rows (64 x 64 per wave, four MFMAs per 4 KB) halve that.
+template <typename T, int TH, int WR>
+__global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2dArgs a) {
     constexpr bool kBf16 = sizeof(T) == 2;
     constexpr int EPC = Elem<T>::kPerChunk;
     constexpr int KC = 128 / (int)sizeof(T);
     constexpr int TW = 32, TM = TH * TW, TN = 128;
-    constexpr int NT = TH * 128;                       // 2 TH waves
+    constexpr int NT = TH / WR * 128;                  // 2 TH / WR waves
     constexpr int HR = (TH + 2) * (TW + 2);            // halo rows
     constexpr int ASTAGE = HR * kC2Pitch, WSTAGE = TN * kC2Pitch;
     constexpr int PO = TN * (int)sizeof(T) + 16;
@@ -270,6 +285,10 @@ __global__ void __launch_bounds__(TH * 128) conv2d_tile_kernel(const Conv2dArgs 
     const int n0 = blockIdx.y * TN;
     const T* const xg = (const T*)a.x + (size_t)b * a.H * a.W * a.cin;
     const char* const wg = (const char*)a.w;
+#ifdef ADF_C2_STAMP
+    const bool stamped = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
+#endif
+    C2_STAMP(0);
     if (a.ab) {
         const float* const abg = a.ab + (size_t)b * a.cin * 2;
         for (int i = tid; i < 2 * a.cin; i += NT) abs_[i] = abg[i];
@@ -332,20 +351,24 @@ __global__ void __launch_bounds__(TH * 128) conv2d_tile_kernel(const Conv2dArgs 
     };
     (void)rw;
 
-    c2_f32x16_t acc[2];
+    c2_f32x16_t acc[WR][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < WR; ++i)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     const int nit = a.nchunk * 9;
     load_a(0);
     load_w(0, rwv[0]);
     if (nit > 1) load_w(1, rwv[1]);
     __syncthreads();                                   // the prologue table is in LDS
+    C2_STAMP(1);
     store_a(0);
     store_w(0, rwv[0]);
     __syncthreads();
+    C2_STAMP(2);
     // iteration `it` (register set s = it & 1 holds W(it + 1) on entry): issue W(it + 2) into the set that W(it) came from, compute
     // from LDS stage it & 1, store W(it + 1) into the other stage
     auto iteration = [&](int it, u32x4_t (&r_next)[NWP], u32x4_t (&r_free)[NWP]) __attribute__((always_inline)) {
@@ -353,34 +376,41 @@ __global__ void __launch_bounds__(TH * 128) conv2d_tile_kernel(const Conv2dArgs 
         const int dy = tap / 3, dx = tap - dy * 3;
         if (it + 2 < nit) load_w(it + 2, r_free);
         if (tap == 0 && ck + 1 < a.nchunk) load_a(ck + 1);          // the next chunk's halo travels during this chunk's nine taps
-        const char* const aRow = ldsA + ((wm + dy) * (TW + 2) + r + dx) * kC2Pitch;
+        const char* const aRow = ldsA + ((wm * WR + dy) * (TW + 2) + r + dx) * kC2Pitch;      // tile row wm * WR (+ i): one halo row further
         const char* const wRow = ldsW + (it & 1) * WSTAGE + (wn * 64 + r) * kC2Pitch;
         if constexpr (kBf16) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const c2_bf16x8_t fa = *(const c2_bf16x8_t*)(aRow + (ks * 2 + h) * 16);
+                c2_bf16x8_t fa[WR], fb[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const c2_bf16x8_t fb = *(const c2_bf16x8_t*)(wRow + j * 32 * kC2Pitch + (ks * 2 + h) * 16);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
-                }
+                for (int i = 0; i < WR; ++i) fa[i] = *(const c2_bf16x8_t*)(aRow + i * (TW + 2) * kC2Pitch + (ks * 2 + h) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = *(const c2_bf16x8_t*)(wRow + j * 32 * kC2Pitch + (ks * 2 + h) * 16);
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                c2_f32x4_t fa[2], fb[2][2];
+                c2_f32x4_t fa[WR][2], fb[2][2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) fa[u] = *(const c2_f32x4_t*)(aRow + (ks * 4 + 2 * h + u) * 16);
+                for (int i = 0; i < WR; ++i)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) fa[i][u] = *(const c2_f32x4_t*)(aRow + i * (TW + 2) * kC2Pitch + (ks * 4 + 2 * h + u) * 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) fb[j][u] = *(const c2_f32x4_t*)(wRow + j * 32 * kC2Pitch + (ks * 4 + 2 * h + u) * 16);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < WR; ++i)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][e], fb[j][u][e], acc[j], 0, 0, 0);
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][u][e], fb[j][u][e], acc[i][j], 0, 0, 0);
             }
         }
         if (it + 1 < nit) store_w(it + 1, r_next);
@@ -392,27 +422,36 @@ __global__ void __launch_bounds__(TH * 128) conv2d_tile_kernel(const Conv2dArgs 
     };
     for (int it = 0; it < nit; it += 2) {
         iteration(it, rwv[1], rwv[0]);
+        if (it == 0) C2_STAMP(3);
         if (it + 1 < nit) iteration(it + 1, rwv[0], rwv[1]);
+        if (it == 0) C2_STAMP(4);
+        if (it == 8) C2_STAMP(5);
     }
+    C2_STAMP(6);
 
-    // ---- epilogue through LDS (as conv2d_gemm_kernel): tile row wm, pixel r of that row ------------------------------------------
+    // ---- epilogue through LDS (as conv2d_gemm_kernel): tile rows wm * WR + i, pixel = accumulator row -------------------------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lc = wn * 64 + j * 32 + r;
         const float bias = (a.bias && n0 + lc < a.cout) ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            Elem<T>::st((T*)(lds + row * PO) + lc, acc[j][q] + bias);
-        }
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (wm * WR + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if constexpr (kBf16) *(unsigned short*)(lds + row * PO + lc * 2) = f32_to_bf16_hw(acc[i][j][q] + bias);
+                else *(float*)(lds + row * PO + lc * 4) = acc[i][j][q] + bias;
+            }
     }
     __syncthreads();
     T* const og = (T*)a.out + (size_t)b * a.H * a.W * a.cout;
     const T* const rg = a.res ? (const T*)a.res + (size_t)b * a.H * a.W * a.cout : nullptr;
+    C2_STAMP(7);
     c2_store_tile<T, TM, TN, NT>(a, lds, PO, tid, n0, b, og, rg, [&](int row) { return (size_t)(ty0 + row / TW) * a.W + tx0 + (row % TW); });
+    C2_STAMP(8);
 }
 
-template <typename T, int TH>
+template <typename T, int TH, int WR>
 static const char* launch_conv2d_tile(const Conv2dArgs& a, hipStream_t s) {
     constexpr int HR = (TH + 2) * 34;
     const size_t stages = (size_t)HR * kC2Pitch + 2 * 128 * kC2Pitch + (size_t)2 * a.cin * 4;
@@ -421,12 +460,12 @@ static const char* launch_conv2d_tile(const Conv2dArgs& a, hipStream_t s) {
     static bool attr_done[kMaxDevices] = {};
     bool& attr = attr_done[current_device()];
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv2d_tile_kernel<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv2d_tile_kernel<T, TH, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return "conv2d_tile: hipFuncSetAttribute failed";
         attr = true;
     }
-    const dim3 grid((unsigned)(a.B * (a.H / TH) * (a.W / 32)), (unsigned)ceil_div(a.cout, 128)), blk(TH * 128);
-    hipLaunchKernelGGL((conv2d_tile_kernel<T, TH>), grid, blk, lds, s, a);
+    const dim3 grid((unsigned)(a.B * (a.H / TH) * (a.W / 32)), (unsigned)ceil_div(a.cout, 128)), blk(TH / WR * 128);
+    hipLaunchKernelGGL((conv2d_tile_kernel<T, TH, WR>), grid, blk, lds, s, a);
     return C2_LAUNCH_CHECK("conv2d_tile");
 }
 
@@ -448,8 +487,12 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     // same-size 3x3: spatial tiles (the halo staged once per chunk serves all nine taps); route switch for the parity tests
     static const int tile_route = adf_route_switch("ADF_CONV2D_TILE", 1);
     if (tile_route && a.taps == 9 && a.mode == 0 && a.W % 32 == 0 && (long long)a.H * a.W * a.cin < (1ll << 31)) {
-        if (a.H % 4 == 0 && px / 128 * ny >= 128) return bf16 ? launch_conv2d_tile<bf16_t, 4>(a, s) : launch_conv2d_tile<float, 4>(a, s);
-        if (a.H % 2 == 0) return bf16 ? launch_conv2d_tile<bf16_t, 2>(a, s) : launch_conv2d_tile<float, 2>(a, s);
+        // a workgroup re-reads every weight slab from L2: at 128 pixels per workgroup that stream (16 KB per iteration against 64 MFMAs) runs at
+        // the L2 -> CU rate and bounds the kernel; 256 pixels per workgroup halve it
+        static const int big = adf_route_switch("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
+        if (big && a.H % 8 == 0 && px / 256 * ny >= 512) return bf16 ? launch_conv2d_tile<bf16_t, 8, 2>(a, s) : launch_conv2d_tile<float, 8, 2>(a, s);
+        if (a.H % 4 == 0 && px / 128 * ny >= 128) return bf16 ? launch_conv2d_tile<bf16_t, 4, 1>(a, s) : launch_conv2d_tile<float, 4, 1>(a, s);
+        if (a.H % 2 == 0) return bf16 ? launch_conv2d_tile<bf16_t, 2, 1>(a, s) : launch_conv2d_tile<float, 2, 1>(a, s);
     }
     // 128-pixel tiles (each weight piece staged once per 128 pixels) when the image divides and the grid still fills the chip
     if (((long long)a.H * a.W) % 128 == 0 && px / 128 * ny >= 512) {
