@@ -3,9 +3,8 @@
 mapping.  See oracle/unet1d.py for the rules on who may import this package.
 
 Parity status: PINNED against the reference itself (``src/models/backbones/unet2d_oai.py`` imported on CPU in
-the build container by ``oracle/gen_golden_next.py``; fixtures in ``tests/golden/next_golden.npz``).  There is no
-device path for this network yet: this file and its fixtures are the groundwork the HIP conv2d path will be
-held to.
+the build container by ``oracle/gen_golden_next.py``; fixtures in ``tests/golden/next_golden.npz``).  The HIP path
+(audiodiffuser_amd/csrc/adf_conv2d.hip, ``adf_adm_create``) is held to these fixtures by tests/test_adm.py.
 
 Every function cites the reference lines it restates (paths relative to the reference repo root; all line
 numbers are in ``src/models/backbones/unet2d_oai.py`` unless another file is named).

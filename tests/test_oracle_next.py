@@ -1,7 +1,7 @@
 """CPU: the oracles of the two next hot-path rows (SURVEY.md 8f rows 3 and 4 -- the ADM 2-D U-Net of BASELINE config 4
 and the DiffWave ``WaveNetNoise`` of config 5) reproduce fixtures that are outputs of the reference modules themselves
-(imported on CPU by oracle/gen_golden_next.py in the build container).  The ADM net has no device path yet; these
-fixtures are what its HIP path will be held to."""
+(imported on CPU by oracle/gen_golden_next.py in the build container).  Both have a device path held to these fixtures
+(tests/test_adm.py, tests/test_wavenet.py); the constructor variants of the ADM net that are not on the device are pinned here only."""
 import os
 
 import numpy as np
