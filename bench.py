@@ -42,8 +42,8 @@ if ROOT not in sys.path:
 WORKLOADS = {"c1": "BASELINE configs[0] network", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2]", "tiny": "unit-test network",
              "c5": "BASELINE configs[4]", "c4": "BASELINE configs[3]"}
 # per-config defaults of --batch (per GPU), --length, --num-steps: c5 = 1024 waveforms over 8 GPUs, 22050 samples, 6-step sampler
-# c4 = one 80 x 256 mel block per sample (length = 80 * 256 bins), 35-step stochastic EDM sampler; BASELINE gives no batch: 16
-DEFAULTS = {"c5": (128, 22050, 6), "c4": (16, 80 * 256, 35)}
+# c4 = one 80 x 256 mel block per sample (length = 80 * 256 bins), 35-step stochastic EDM sampler; BASELINE gives no batch: 64 as configs[1]
+DEFAULTS = {"c5": (128, 22050, 6), "c4": (64, 80 * 256, 35)}
 C4_SHAPE = (80, 256)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}

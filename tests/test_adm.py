@@ -99,6 +99,19 @@ def test_fp32_larger_batch_and_image_vs_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_both_conv_routes_in_a_child_process(tile):
+    """ADF_CONV2D_TILE=0 sends every 3x3 conv through the per-tap gather kernel, 1 (default) the same-size ones through the spatial-tile
+    kernel; the switch is read once per process."""
+    import json, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "gpu_adm_report.py")], capture_output=True, text=True,
+                       env=dict(os.environ, ADF_CONV2D_TILE=tile), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["route_tile"] == tile and rep["max_rel"] < FP32_TIGHT, rep
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_config4_full_size_fp32_and_bf16(gold):
     """The BASELINE config-4 network itself (default constructor, 1 x 80 x 256): fp32 against the reference's output; bf16 against
