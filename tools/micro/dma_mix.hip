@@ -6,6 +6,8 @@
 //   3 both, W by waves 0-3 and A by waves 4-7 (separate in-order queues: A is only waited for at the end of the K block)
 //   4 as 2, A from an L2-resident window (is it the HBM latency or the path?)   5 as 2, A spread over the three sub-steps
 //   6 as 3, but the A waves issue their 8 pieces over the three sub-steps (3 + 3 + 2)
+//   7 as 2, but the weight slab travels global_load_dwordx4 -> registers -> ds_write_b128 instead of LDS-DMA (does the register return path
+//     overlap the DMA path?)
 // hipcc --offload-arch=gfx950 -O3 dma_mix.hip -o dma_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -52,6 +54,15 @@ __global__ void __launch_bounds__(512) mix(const char* __restrict__ a, const cha
                 } else if (MODE == 3) {
                     if (wave < 4) { issue_w(4, wave * 4); WAIT(0); }
                     else { if (sub == 0) issue_a(8, (wave - 4) * 8); if (sub == 2) WAIT(0); }
+                } else if (MODE == 7) {
+                    const char* wb = w + (size_t)((s % 12) * 16384) + (size_t)wave * 2048;
+                    const unsigned stW = 98304u + (unsigned)((s & 1) * 16384) + (unsigned)wave * 2048u + (unsigned)lane * 16u;
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    u4 r0, r1;
+                    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" : "=&v"(r0), "=&v"(r1) : "v"(voffW), "s"(wb) : "memory");
+                    if (sub == 0) { issue_a(4, wave * 4); asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1) :: "memory"); }
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1) :: "memory");
+                    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(stW), "v"(r0), "v"(r1) : "memory");
                 } else if (MODE == 6) {
                     if (wave < 4) { issue_w(4, wave * 4); WAIT(0); }
                     else { const int f = (wave - 4) * 8; if (sub == 0) issue_a(3, f); else if (sub == 1) issue_a(3, f + 3); else { issue_a(2, f + 6); WAIT(0); } }
@@ -73,11 +84,12 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int tiles = 16;                                  // 256 blocks x 16 tiles x 128 KB = 512 MB of A per launch
     const char* names[] = {"W only (16 KB / sub-step, L2)", "A only (32 KB / K block, HBM)", "both, one queue per wave (rb order)",
-                           "both, W waves 0-3 / A waves 4-7", "both, A from an L2 window", "both, A spread over sub-steps", "split waves, A spread"};
-    for (int mode = 0; mode < 7; ++mode) {
+                           "both, W waves 0-3 / A waves 4-7", "both, A from an L2 window", "both, A spread over sub-steps", "split waves, A spread",
+                           "both, W through registers"};
+    for (int mode = 0; mode < 8; ++mode) {
         auto launch = [&]() {
 #define L(M) hipFuncSetAttribute((const void*)mix<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(mix<M>, dim3(256), dim3(512), 131072, 0, a, w, cyc, tiles, (size_t)16 << 20)
-            switch (mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; case 4: L(4); break; case 5: L(5); break; default: L(6); }
+            switch (mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; case 4: L(4); break; case 5: L(5); break; case 6: L(6); break; default: L(7); }
         };
         launch(); hipDeviceSynchronize();
         hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
