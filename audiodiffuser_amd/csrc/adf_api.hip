@@ -1060,32 +1060,45 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         }
         return y;
     };
-    auto run = [&](const std::vector<AdmLayer>& ls, T2 x) -> T2 {
+    // every stored tensor is recorded for the parity tests: "<block>.<j>" = output of the block's layer j, "<block>.<j>.h1" = a ResBlock's
+    // first conv, "<block>.<j>.skip" its 1x1 skip conv, "<block>.<j>.xn / .qkv / .att" the attention block's internals
+    auto run = [&](const std::vector<AdmLayer>& ls, T2 x, const std::string& bname) -> T2 {
+        int lj = -1;
         for (const AdmLayer& l : ls) {
+            ++lj;
+            const std::string ln = bname + "." + std::to_string(lj);
             if (W.bad) break;
             if (l.kind == 0) {
                 T2 y; y.H = x.H; y.W = x.W; y.t = W.new_act(a.input_ch, x.H * x.W);
                 if (W.live()) W.check(launch_conv2d_in(io.x, a.in_w, a.in_b, y.t.p, h->bf16, B, c.in_channels, x.H, x.W, a.input_ch, io.coef, io.coef_bstride, s));
                 x = y;
+                W.tap(ln, x.t);
             } else if (l.kind == 1) {                                   // ResBlock._forward, :248-272 (scale-shift form)
                 const AdmRes& r = a.res[l.idx];
                 const float* ab1 = gn_table(x, r.g1w, r.g1b, nullptr);
                 T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr, true);
+                W.tap(ln + ".h1", hh.t);
                 const float* ab2 = gn_table(hh, r.g2w, r.g2b, film + r.film_off);
                 const void* skip = x.t.p;
-                if (r.has_skip) skip = conv(x, r.skip, nullptr, 0, 0, nullptr, false).t.p;
+                if (r.has_skip) { T2 sk2 = conv(x, r.skip, nullptr, 0, 0, nullptr, false); W.tap(ln + ".skip", sk2.t); skip = sk2.t.p; }
                 x = conv(hh, r.c2, ab2, 1, 0, skip, true);
+                W.tap(ln, x.t);
             } else if (l.kind == 2) {                                   // AttentionBlock._forward, :316-322
                 const AdmAttn& t = a.attn[l.idx];
                 const float* ab = gn_table(x, t.gw, t.gb, nullptr);
                 T2 xn; xn.H = x.H; xn.W = x.W; xn.t = W.new_act(t.c, x.t.L);
                 if (W.live()) W.check(launch_gn_apply(x.t.p, nullptr, t.c, 0, x.t.L, B, ab, 0, xn.t.p, h->bf16, s));
+                W.tap(ln + ".xn", xn.t);
                 T2 qkv = conv(xn, t.qkv, nullptr, 0, 0, nullptr, false);
+                W.tap(ln + ".qkv", qkv.t);         // q | k | v blocks (the rows were permuted at load for the legacy order)
                 T2 att; att.H = x.H; att.W = x.W; att.t = W.new_act(t.c, x.t.L);
                 if (W.live()) W.check(launch_attention(qkv.t.p, att.t.p, h->bf16, B, x.t.L, t.c, t.heads, s));
+                W.tap(ln + ".att", att.t);
                 x = conv(att, t.proj, nullptr, 0, 0, xn.t.p, true);    // the residual is the NORMALISED input (:318-322)
+                W.tap(ln, x.t);
             } else {
                 x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr, l.kind == 3);
+                W.tap(ln, x.t);
             }
         }
         return x;
@@ -1093,18 +1106,18 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     T2 x; x.H = a.H; x.W = a.W; x.t = Act{};
     std::vector<T2> hs;
     for (size_t i = 0; i < a.input_blocks.size() && !W.bad; ++i) {
-        x = run(a.input_blocks[i], x);
+        x = run(a.input_blocks[i], x, "input_blocks." + std::to_string(i));
         W.tap("input_blocks." + std::to_string(i), x.t);
         hs.push_back(x);
     }
-    x = run(a.middle, x);
+    x = run(a.middle, x, "middle_block");
     W.tap("middle_block", x.t);
     for (size_t i = 0; i < a.output_blocks.size() && !W.bad; ++i) {
         const T2 sk = hs.back(); hs.pop_back();
         T2 cat; cat.H = x.H; cat.W = x.W; cat.t = W.new_act(x.t.C + sk.t.C, x.t.L);
         if (sk.H != x.H || sk.W != x.W) { W.check("UNetModel: skip shape mismatch"); break; }
         if (W.live()) W.check(launch_concat2(x.t.p, sk.t.p, x.t.C, sk.t.C, (long long)B * x.t.L, cat.t.p, h->bf16, s));
-        x = run(a.output_blocks[i], cat);
+        x = run(a.output_blocks[i], cat, "output_blocks." + std::to_string(i));
         W.tap("output_blocks." + std::to_string(i), x.t);
     }
     const float* abo = gn_table(x, a.out_gw, a.out_gb, nullptr);

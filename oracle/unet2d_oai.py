@@ -8,6 +8,13 @@ the build container by ``oracle/gen_golden_next.py``; fixtures in ``tests/golden
 
 Every function cites the reference lines it restates (paths relative to the reference repo root; all line
 numbers are in ``src/models/backbones/unet2d_oai.py`` unless another file is named).
+
+Arithmetic modes as in oracle/unet1d.py.  ``storage="bf16"`` rounds where the HIP throughput mode of adf_conv2d.hip holds bf16:
+every stored activation, the activated conv operand ``silu(a x + b)``, the GEMM weights; a conv with a residual stores
+``r(r(conv + bias) + residual)`` (its output tile is rounded in LDS before the residual is added); GroupNorm statistics are those
+of the stored tensor; the first conv (vector kernel, fp32 weights), the last conv (fp32 weights, fp32 activation, fp32 output),
+the attention softmax and P V (vector kernel, fp32) and the embedding path are not rounded inside.  ``force`` / ``errs``: teacher
+forcing per recorded tensor, as in oracle/unet1d.py.
 """
 from __future__ import annotations
 
@@ -17,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from .unet1d import label_embedding
+from .unet1d import label_embedding, Storage, FP32, rel_l2
 
 P = Dict[str, torch.Tensor]
 Spec = Tuple[Tuple[int, ...], str]
@@ -45,25 +52,38 @@ def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -
     return emb
 
 
-def conv2d(p: P, pre: str, x: torch.Tensor, stride: int = 1) -> torch.Tensor:
+def conv2d(p: P, pre: str, x: torch.Tensor, stride: int = 1, q: Storage = FP32, round_w: bool = True) -> torch.Tensor:
     w = p[f"{pre}.weight"]
+    if q.bf16 and round_w:
+        w = q.w(w)
     return F.conv2d(x, w, p[f"{pre}.bias"], stride=stride, padding=w.shape[-1] // 2)
 
 
-def upsample(p: P, pre: str, x: torch.Tensor, use_conv: bool) -> torch.Tensor:
+def upsample(p: P, pre: str, x: torch.Tensor, use_conv: bool, q: Storage = FP32) -> torch.Tensor:
     """:122-127 -- nearest x2, then the 3x3 conv."""
     x = F.interpolate(x, scale_factor=2, mode="nearest")
-    return conv2d(p, f"{pre}.conv", x) if use_conv else x
+    return q.r(conv2d(p, f"{pre}.conv", x, q=q)) if use_conv else x
 
 
-def downsample(p: P, pre: str, x: torch.Tensor, use_conv: bool) -> torch.Tensor:
+def downsample(p: P, pre: str, x: torch.Tensor, use_conv: bool, q: Storage = FP32) -> torch.Tensor:
     """:146-158 -- 3x3 stride-2 conv (padding 1), or a 2x2 average pool."""
-    return conv2d(p, f"{pre}.op", x, stride=2) if use_conv else F.avg_pool2d(x, 2, 2)
+    return q.r(conv2d(p, f"{pre}.op", x, stride=2, q=q)) if use_conv else F.avg_pool2d(x, 2, 2)
 
 
-def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: bool) -> torch.Tensor:
-    """:248-272.  ``emb`` is the 4*model_channels embedding; the block applies SiLU + Linear to it (:214-220)."""
+def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: bool, q: Storage = FP32, rec=None) -> torch.Tensor:
+    """:248-272.  ``emb`` is the 4*model_channels embedding; the block applies SiLU + Linear to it (:214-220).
+    ``rec(suffix, tensor)`` records / forces the stored tensors of the device path (``.h1``, ``.skip``)."""
     pre = l.pre
+    rec = rec or (lambda _n, v: v)
+    if q.bf16:                              # the device configuration only (scale-shift norm, no resampling inside the block)
+        assert scale_shift and not (l.up or l.down)
+        h = q.r(F.silu(group_norm32(p, f"{pre}.in_layers.0", x)))
+        h = rec(".h1", q.r(conv2d(p, f"{pre}.in_layers.2", h, q=q)))
+        e = F.linear(F.silu(emb), p[f"{pre}.emb_layers.1.weight"], p[f"{pre}.emb_layers.1.bias"])[:, :, None, None]
+        scale, shift = torch.chunk(e, 2, dim=1)
+        h2 = q.r(F.silu(group_norm32(p, f"{pre}.out_layers.0", h) * (1 + scale) + shift))
+        skip = rec(".skip", q.r(conv2d(p, f"{pre}.skip_connection", x, q=q))) if l.cin != l.cout else x
+        return q.r(q.r(conv2d(p, f"{pre}.out_layers.3", h2, q=q)) + skip)
     h = F.silu(group_norm32(p, f"{pre}.in_layers.0", x))
     if l.up or l.down:                     # :249-254: resample the activated h and the raw x, then convolve
         if l.up:
@@ -72,7 +92,7 @@ def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: 
         else:
             h = F.avg_pool2d(h, 2, 2)
             x = F.avg_pool2d(x, 2, 2)
-    h = conv2d(p, f"{pre}.in_layers.2", h)
+    h = rec(".h1", conv2d(p, f"{pre}.in_layers.2", h))
     e = F.linear(F.silu(emb), p[f"{pre}.emb_layers.1.weight"], p[f"{pre}.emb_layers.1.bias"])[:, :, None, None]
     if scale_shift:                        # :262-267
         scale, shift = torch.chunk(e, 2, dim=1)
@@ -80,7 +100,7 @@ def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: 
     else:                                  # :268-270
         h = group_norm32(p, f"{pre}.out_layers.0", h + e)
     h = conv2d(p, f"{pre}.out_layers.3", F.silu(h))       # dropout is the identity at inference
-    skip = conv2d(p, f"{pre}.skip_connection", x) if l.cin != l.cout else x
+    skip = rec(".skip", conv2d(p, f"{pre}.skip_connection", x)) if l.cin != l.cout else x
     return skip + h
 
 
@@ -99,25 +119,47 @@ def qkv_attention(qkv: torch.Tensor, heads: int, legacy: bool) -> torch.Tensor:
     return torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, n)
 
 
-def attention_block(p: P, l: _Layer, x: torch.Tensor, heads: int, legacy: bool) -> torch.Tensor:
-    """:316-322.  The residual is added to the NORMALISED input (the reference reassigns ``x = self.norm(x)``)."""
+def attention_block(p: P, l: _Layer, x: torch.Tensor, heads: int, legacy: bool, q: Storage = FP32, rec=None) -> torch.Tensor:
+    """:316-322.  The residual is added to the NORMALISED input (the reference reassigns ``x = self.norm(x)``).
+    ``rec``: ``.xn``, ``.qkv`` (in the device's q | k | v row order), ``.att``."""
     b, c = x.shape[:2]
-    xn = group_norm32(p, f"{l.pre}.norm", x.reshape(b, c, -1))
-    qkv = F.conv1d(xn, p[f"{l.pre}.qkv.weight"], p[f"{l.pre}.qkv.bias"])
-    h = qkv_attention(qkv, heads, legacy)
-    h = F.conv1d(h, p[f"{l.pre}.proj_out.weight"], p[f"{l.pre}.proj_out.bias"])
-    return (xn + h).reshape(x.shape)
+    rec = rec or (lambda _n, v: v)
+    sp = x.shape
+    xn = rec(".xn", q.r(group_norm32(p, f"{l.pre}.norm", x.reshape(b, c, -1))).reshape(sp)).reshape(b, c, -1)
+    wq = q.w(p[f"{l.pre}.qkv.weight"]) if q.bf16 else p[f"{l.pre}.qkv.weight"]
+    qkv = q.r(F.conv1d(xn, wq, p[f"{l.pre}.qkv.bias"]))
+    if rec is not None:
+        ch = c // heads
+        if legacy:      # device rows: (which, head, c) <- reference rows (head, which, c)
+            dev = qkv.reshape(b, heads, 3, ch, -1).permute(0, 2, 1, 3, 4).reshape(b, 3 * c, -1)
+            dev = rec(".qkv", dev.reshape(b, 3 * c, *sp[2:])).reshape(b, 3, heads, ch, -1)
+            qkv = dev.permute(0, 2, 1, 3, 4).reshape(b, 3 * c, -1)
+        else:
+            qkv = rec(".qkv", qkv.reshape(b, 3 * c, *sp[2:])).reshape(b, 3 * c, -1)
+    h = rec(".att", q.r(qkv_attention(qkv, heads, legacy)).reshape(sp)).reshape(b, c, -1)
+    wp = q.w(p[f"{l.pre}.proj_out.weight"]) if q.bf16 else p[f"{l.pre}.proj_out.weight"]
+    h = q.r(F.conv1d(h, wp, p[f"{l.pre}.proj_out.bias"]))
+    return q.r(xn + h).reshape(x.shape)
 
 
 # ------------------------------------------------------------------ the network
 def unet2d_forward(p: P, cfg: ADMConfig, x: torch.Tensor, t: torch.Tensor, classes: Optional[torch.Tensor] = None,
-                   cond_drop_prob: float = 0.0, taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                   cond_drop_prob: float = 0.0, taps: Optional[Dict[str, torch.Tensor]] = None, storage: str = "fp32",
+                   force: Optional[Dict[str, torch.Tensor]] = None, errs: Optional[Dict[str, float]] = None) -> torch.Tensor:
     """``UNetModel.forward`` :603-634.  x: [B, in_channels, H, W], t: [B] (the EDM wrapper passes c_noise).
-    ``taps`` (optional) receives the output of every input / middle / output block under the block's module name."""
+    ``taps`` (optional) receives the output of every input / middle / output block under the block's module name, and under
+    ``<block>.<j>`` (+ ``.h1 / .skip / .xn / .qkv / .att``) every tensor the device path stores.  ``force`` maps names to tensors
+    shaped [B, C, H*W] (the device's tap copies) or [B, C, H, W]."""
     assert (classes is not None) == (cfg.num_classes is not None), "must specify y if and only if the model is class-conditional"
     s = structure(cfg)
+    q = Storage(storage)
 
     def rec(name, v):
+        if force is not None and name in force:
+            f = force[name].reshape(v.shape)
+            if errs is not None:
+                errs[name] = rel_l2(v, f)
+            v = f
         if taps is not None:
             taps[name] = v
         return v
@@ -130,16 +172,18 @@ def unet2d_forward(p: P, cfg: ADMConfig, x: torch.Tensor, t: torch.Tensor, class
 
     def run(layers: List[_Layer], h: torch.Tensor) -> torch.Tensor:
         for l in layers:
+            sub = lambda sfx, v, _pre=l.pre: rec(_pre + sfx, v)
             if l.kind == "conv":
-                h = conv2d(p, l.pre, h)
+                h = q.r(conv2d(p, l.pre, h, q=q, round_w=False))      # vector kernel on the device: fp32 weights
             elif l.kind == "res":
-                h = res_block(p, l, h, emb, cfg.use_scale_shift_norm)
+                h = res_block(p, l, h, emb, cfg.use_scale_shift_norm, q, sub)
             elif l.kind == "attn":
-                h = attention_block(p, l, h, cfg.heads(l.cin), not cfg.use_new_attention_order)
+                h = attention_block(p, l, h, cfg.heads(l.cin), not cfg.use_new_attention_order, q, sub)
             elif l.kind == "down":
-                h = downsample(p, l.pre, h, cfg.conv_resample)
+                h = downsample(p, l.pre, h, cfg.conv_resample, q)
             elif l.kind == "up":
-                h = upsample(p, l.pre, h, cfg.conv_resample)
+                h = upsample(p, l.pre, h, cfg.conv_resample, q)
+            h = rec(l.pre, h)
         return h
 
     hs = []
@@ -151,4 +195,4 @@ def unet2d_forward(p: P, cfg: ADMConfig, x: torch.Tensor, t: torch.Tensor, class
     for i, blk in enumerate(s.output_blocks):
         h = rec(f"output_blocks.{i}", run(blk, torch.cat([h, hs.pop()], dim=1)))
     h = F.silu(group_norm32(p, "out.0", h))
-    return conv2d(p, "out.2", h)
+    return conv2d(p, "out.2", h, q=q, round_w=False)      # vector kernel on the device: fp32 activation and weights

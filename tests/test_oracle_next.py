@@ -105,6 +105,30 @@ def test_adm_config4_sampler_with_injected_draws(gold):
     assert rel(y, T(gold["adm_samp_y"])) < 5e-5
 
 
+def test_adm_bf16_storage_mode_and_teacher_forcing():
+    cfg = A.config_c4_small()
+    w = A.generate_weights(cfg, seed=3)
+    g = torch.Generator().manual_seed(2)
+    x, t = torch.randn(2, 1, 16, 32, generator=g), torch.tensor([0.3, -0.5])
+    t32, t16 = {}, {}
+    with torch.no_grad():
+        y32 = A.unet2d_forward(w, cfg, x, t, taps=t32)
+        y16 = A.unet2d_forward(w, cfg, x, t, taps=t16, storage="bf16")
+    assert 1e-4 < A.rel_l2(y16, y32) < 5e-2
+    assert set(t16) == set(t32) and "input_blocks.3.1.qkv" in t16 and "middle_block.0.h1" in t16
+    forced = {k: v.reshape(v.shape[0], v.shape[1], -1).clone() for k, v in t16.items()}       # the device's [B, C, H*W] tap layout
+    errs = {}
+    with torch.no_grad():
+        A.unet2d_forward(w, cfg, x, t, storage="bf16", force=forced, errs=errs)
+    assert max(errs.values()) < 1e-6                      # forcing a run with its own taps changes nothing
+    forced["middle_block.0.h1"] = forced["middle_block.0.h1"] + 0.05 * forced["middle_block.0.h1"].flip(-1)
+    errs = {}
+    with torch.no_grad():
+        A.unet2d_forward(w, cfg, x, t, storage="bf16", force=forced, errs=errs)
+    bad = {k for k, e in errs.items() if e > 1e-6}
+    assert bad == {"middle_block.0.h1", "middle_block.0"}, bad      # the forced tensor and its one consumer
+
+
 def test_timestep_embedding_layout():
     e = A.timestep_embedding(torch.tensor([0.0, 2.0]), 8)
     assert torch.equal(e[0], torch.tensor([1.0, 1, 1, 1, 0, 0, 0, 0]))       # cosines first (:46)

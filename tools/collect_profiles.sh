@@ -8,9 +8,9 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 echo "[1/9] bench.py"; timeout -k 10 400 python bench.py --steps 2 --warmup 1 2>/dev/null | tail -1 > $out/${tag}_bench.json || exit 1
 echo "[2/9] kernel trace of bench.py"; rm -rf /tmp/p1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/p1.log 2>&1 || { tail -5 /tmp/p1.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-check --no-pmc > /tmp/p1.log 2>&1 || { tail -5 /tmp/p1.log; exit 1; }
 cp $(ls /tmp/p1/*/*kernel_stats.csv | head -1) $out/${tag}_bench_kernel_stats.csv
-python3 tools/trace_summary.py $(ls /tmp/p1/*/*kernel_trace.csv | head -1) 198 --grid | sed "s#/tmp/p1/[^ ]*#rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline#" > $out/${tag}_bench_per_nfe_summary.txt
+python3 tools/trace_summary.py $(ls /tmp/p1/*/*kernel_trace.csv | head -1) 198 --grid | sed "s#/tmp/p1/[^ ]*#rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-check --no-pmc#" > $out/${tag}_bench_per_nfe_summary.txt
 echo "[3/9] kernel trace of the resblock replay"; rm -rf /tmp/p2
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python3 bench.py --roofline-only --roofline-iters 50 > /tmp/p2.log 2>&1 || { tail -5 /tmp/p2.log; exit 1; }
 cp $(ls /tmp/p2/*/*kernel_stats.csv | head -1) $out/${tag}_roofline_replay_kernel_stats.csv
