@@ -19,7 +19,7 @@ ADF_MAX_LAYERS = 12
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_SEPARATE_GN_STATS = 1
 SAMPLER_EDM, SAMPLER_EDM_ALPHA, SAMPLER_DPM_MULTISTEP, SAMPLER_DPM2, SAMPLER_ADPM2 = 0, 1, 2, 3, 4
-SAMPLER_LMS, SAMPLER_DPM_SINGLESTEP, SAMPLER_DPM2M = 5, 6, 7
+SAMPLER_LMS, SAMPLER_DPM_SINGLESTEP, SAMPLER_DPM2M, SAMPLER_UNIPC = 5, 6, 7, 8
 
 
 class AdfNetConfig(C.Structure):

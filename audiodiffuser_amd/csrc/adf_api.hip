@@ -1621,6 +1621,121 @@ int run_adpm2(SamplerCtx& c, float** result) {
     return 0;
 }
 
+// UniPCSampler.forward (sampler_edm.py:996-1053, variant 'bh2').  Every coefficient depends on the grid only: computed on the host
+// in fp32 in the reference's order of operations (the small solves of :934, :942 by Gaussian elimination with partial pivoting, as
+// LAPACK's gesv does); one launch per predictor / corrector formula.
+static void unipc_solve(int n, float A[3][3], float* b, float* x) {
+    int piv[3] = {0, 1, 2};
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int i = k + 1; i < n; ++i) if (fabsf(A[piv[i]][k]) > fabsf(A[piv[p]][k])) p = i;
+        std::swap(piv[k], piv[p]);
+        for (int i = k + 1; i < n; ++i) {
+            const float f = A[piv[i]][k] / A[piv[k]][k];
+            for (int j = k; j < n; ++j) A[piv[i]][j] -= f * A[piv[k]][j];
+            b[piv[i]] -= f * b[piv[k]];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        float acc = b[piv[k]];
+        for (int j = k + 1; j < n; ++j) acc -= A[piv[k]][j] * x[j];
+        x[k] = acc / A[piv[k]][k];
+    }
+}
+
+int run_unipc(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const bool logsp = d.log_time_spacing != 0, eps = d.eps_pred != 0;
+    const int steps = logsp ? d.num_steps : d.num_steps - 1;          // :828
+    const int order = d.order;
+    if (order < 1 || order > 3) return c.count_only ? 1 : fail(c.h, "UniPCSampler: order must be 1, 2 or 3");
+    if (steps < order || c.nsig < 2 || (!logsp && c.nsig < steps + 1)) return c.count_only ? 1 : fail(c.h, "UniPCSampler: not enough steps / sigmas");
+    const DpmGrid G = dpm_grid(c.sig, c.nsig, steps, logsp);
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* XT = c.count_only ? nullptr : p->sb[2];
+    float* MB[4] = {c.count_only ? nullptr : p->sb[6], c.count_only ? nullptr : p->sb[7], c.count_only ? nullptr : p->sb[8], c.count_only ? nullptr : p->sb[9]};
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    // history, oldest first (as the reference's lists); a free buffer of MB receives the next model value
+    std::vector<float*> ml; std::vector<float> gl;
+    auto free_buf = [&]() -> float* { for (float* b : MB) if (std::find(ml.begin(), ml.end(), b) == ml.end()) return b; return MB[0]; };
+    float* m_first = free_buf();
+    if (c.model(X, G.sig(G.g[0]), m_first)) return 1;
+    ml.push_back(m_first); gl.push_back(G.g[0]);
+    auto update = [&](float g_cur, int ord, bool corr, float** x_io, float** m_out) -> int {
+        const float g0 = gl.back();
+        const float h = G.lam(g_cur) - G.lam(g0);
+        float rks[3]; int K = 0;
+        const float* mk[2] = {nullptr, nullptr};
+        for (int i = 1; i < ord; ++i) { rks[K] = (G.lam(gl[gl.size() - 1 - i]) - G.lam(g0)) / h; mk[K] = ml[ml.size() - 1 - i]; ++K; }
+        rks[K] = 1.0f;
+        const float hh = eps ? h : -h;
+        const float h_phi_1 = expm1f(hh);
+        float h_phi_k = h_phi_1 / hh - 1.0f;
+        const float B_h = expm1f(hh);
+        float R[3][3], bb[3];
+        float fact = 1.0f;
+        for (int i = 1; i <= ord; ++i) {
+            for (int j = 0; j < ord; ++j) R[i - 1][j] = i == 1 ? 1.0f : (i == 2 ? rks[j] : rks[j] * rks[j]);
+            bb[i - 1] = h_phi_k * fact / B_h;
+            fact *= (float)(i + 1);
+            h_phi_k = h_phi_k / hh - 1.0f / fact;
+        }
+        float rhos_p[3] = {0.f, 0.f, 0.f}, rhos_c[3] = {0.f, 0.f, 0.f};
+        if (K > 0) {
+            if (ord == 2) rhos_p[0] = 0.5f;
+            else { float A2[3][3], b2[3]; for (int i = 0; i < ord - 1; ++i) { b2[i] = bb[i]; for (int j = 0; j < ord - 1; ++j) A2[i][j] = R[i][j]; } unipc_solve(ord - 1, A2, b2, rhos_p); }
+        }
+        if (corr) {
+            if (ord == 1) rhos_c[0] = 0.5f;
+            else { float A2[3][3], b2[3]; for (int i = 0; i < ord; ++i) { b2[i] = bb[i]; for (int j = 0; j < ord; ++j) A2[i][j] = R[i][j]; } unipc_solve(ord, A2, b2, rhos_c); }
+        }
+        const float sc = G.sig(g_cur);
+        UniPcArgs u;
+        memset(&u, 0, sizeof(u));
+        u.a = eps ? 1.0f : sc / G.sig(g0);
+        u.hp = eps ? sc * h_phi_1 : h_phi_1;
+        u.sb = eps ? sc * B_h : B_h;
+        u.K = K; u.m0 = ml.back(); u.m[0] = mk[0]; u.m[1] = mk[1];
+        for (int k = 0; k < K; ++k) { u.rk[k] = rks[k]; u.rho[k] = rhos_p[k]; }
+        u.mt = nullptr;
+        float* xin = *x_io;
+        float* xt = corr ? XT : (xin == X ? XN : X);
+        if (!c.count_only && c.ck(launch_unipc(xt, xin, u, c.n, c.s))) return 1;      // predictor (:951-957 / :973-979)
+        *m_out = nullptr;
+        if (corr) {
+            float* mt = free_buf();
+            if (c.model(xt, sc, mt)) return 1;
+            for (int k = 0; k < K; ++k) u.rho[k] = rhos_c[k];
+            u.rho_t = rhos_c[ord - 1]; u.mt = mt;
+            float* xo = xin == X ? XN : X;
+            if (!c.count_only && c.ck(launch_unipc(xo, xin, u, c.n, c.s))) return 1;  // corrector (:959-967 / :981-990)
+            *m_out = mt; *x_io = xo;
+        } else {
+            *x_io = xt;
+        }
+        return 0;
+    };
+    float* x = X;
+    for (int step = 1; step < order; ++step) {                         // :1013-1022
+        float* m = nullptr;
+        if (update(G.g[step], step, true, &x, &m)) return 1;
+        gl.push_back(G.g[step]); ml.push_back(m);
+    }
+    for (int step = order; step <= steps; ++step) {                    // :1025-1051
+        float* m = nullptr;
+        const int so = order < steps + 1 - step ? order : steps + 1 - step;
+        if (update(G.g[step], so, step != steps, &x, &m)) return 1;
+        for (int i = 0; i + 1 < order; ++i) { gl[i] = gl[i + 1]; ml[i] = ml[i + 1]; }
+        gl.back() = G.g[step];
+        if (step < steps) ml.back() = m;
+    }
+    if (!c.count_only && c.ck(launch_clamp(x, c.n, c.s))) return 1;
+    *result = x;
+    return 0;
+}
+
 int run_sampler(SamplerCtx& c, float** result) {
     switch (c.d->kind) {
         case ADF_SAMPLER_DPM2: return run_dpm2(c, result);
@@ -1631,6 +1746,7 @@ int run_sampler(SamplerCtx& c, float** result) {
         case ADF_SAMPLER_DPM_SINGLESTEP: return run_dpm_single(c, result);
         case ADF_SAMPLER_LMS: return run_lms(c, result);
         case ADF_SAMPLER_DPM2M: return run_dpm2m(c, result);
+        case ADF_SAMPLER_UNIPC: return run_unipc(c, result);
         default: return c.count_only ? 1 : fail(c.h, "unknown sampler kind");
     }
 }

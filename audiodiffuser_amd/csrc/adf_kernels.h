@@ -91,6 +91,10 @@ const char* launch_lms(float* x, const float* den, float sigma, const LmsArgs& a
 // out = (a*x - b*e0) + c*(e1 - e0) (e1 may be null), optionally clamped to [-1, 1]: the single-step DPM-Solver updates
 const char* launch_lincomb(float* out, const float* x, const float* e0, const float* e1, float a, float b, float c, int clampit,
                            long long n, hipStream_t s);
+// UniPCSampler.multistep_uni_pc_update (sampler_edm.py:872-994), one predictor or corrector formula per launch, the reference's order
+// of operations:  xt_ = a*x - hp*m0;  res = sum_{k<K} rho[k] * ((m[k] - m0) / rk[k])  (+ rho_t * (mt - m0) if mt);  out = xt_ - sb*res
+struct UniPcArgs { float a, hp, sb; int K; float rk[2], rho[2], rho_t; const float* m0; const float* m[2]; const float* mt; };
+const char* launch_unipc(float* out, const float* x, const UniPcArgs& a, long long n, hipStream_t s);
 const char* launch_dstep(float* x_next, const float* x_base, const float* x_eval, const float* den, float sigma, float dt, long long n,
                          hipStream_t st);
 const char* launch_clamp(float* x, long long n, hipStream_t st);

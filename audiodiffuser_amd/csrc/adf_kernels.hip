@@ -1135,6 +1135,23 @@ const char* launch_dstep(float* xn, const float* xb, const float* xe, const floa
     hipLaunchKernelGGL(dstep_kernel, dim3(ew_grid(n)), dim3(256), 0, st, xn, xb, xe, den, sigma, dt, n);
     return ADF_LAUNCH_CHECK("dstep");
 }
+__global__ void __launch_bounds__(256) unipc_kernel(float* __restrict__ out, const float* __restrict__ x, const UniPcArgs a, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float m0 = a.m0[i];
+        const float xt = a.a * x[i] - a.hp * m0;
+        float res = 0.f;
+        if (a.K > 0) res = res + a.rho[0] * ((a.m[0][i] - m0) / a.rk[0]);
+        if (a.K > 1) res = res + a.rho[1] * ((a.m[1][i] - m0) / a.rk[1]);
+        if (a.mt) res = res + a.rho_t * (a.mt[i] - m0);
+        out[i] = xt - a.sb * res;
+    }
+}
+const char* launch_unipc(float* out, const float* x, const UniPcArgs& a, long long n, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(unipc_kernel, dim3(blocks), dim3(256), 0, s, out, x, a, n);
+    return ADF_LAUNCH_CHECK("unipc");
+}
+
 const char* launch_clamp(float* x, long long n, hipStream_t st) {
     hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, n);
     return ADF_LAUNCH_CHECK("clamp");

@@ -463,3 +463,92 @@ class ADPM2Sampler(nn.Module):
             x = x + d_mid * (s_down - s)
             x = x + (injected_noise[i] if injected_noise is not None else torch.randn_like(x)) * s_up
         return x.clamp(-1.0, 1.0)
+
+
+class UniPCSampler(nn.Module):
+    """Uni-PC (sampler_edm.py:807-1053, variant 'bh2'): multistep predictor-corrector, NFE = its step count -- ``num_steps`` on a lambda
+    grid linear between the first and the last sigma (``log_time_spacing``, the default) or ``num_steps - 1`` on the sigma list itself.
+    The reference only runs on 4-D states (hard-coded ``einsum('k,bkchw->bchw')``); here any state shape works."""
+
+    def __init__(self, num_steps: int = 20, order: int = 2, cond_scale: float = 1.0, x0_pred: bool = True,
+                 log_time_spacing: bool = True, use_graph: bool = True):
+        super().__init__()
+        self.order, self.cond_scale, self.x0_pred, self.log_time_spacing = order, cond_scale, x0_pred, log_time_spacing
+        self._ctor_steps = num_steps
+        self.num_steps = num_steps if log_time_spacing else num_steps - 1        # as the reference stores it (:828)
+        self.use_graph = use_graph
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_UNIPC, int(self._ctor_steps)
+        d.s_tmin = d.s_tmax = d.s_churn = 0.0
+        d.s_noise = 1.0
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, int(self.order), sigma_data, int(self.use_graph)
+        d.log_time_spacing, d.eps_pred = int(self.log_time_spacing), int(not self.x0_pred)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
+        assert self.num_steps >= self.order                                        # :1001
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
+        # ---- interface-compatibility branch (same recurrences as tensor ops around a foreign fn / net) ----------------------------
+        steps, order = self.num_steps, self.order
+        if self.log_time_spacing:
+            grid = torch.linspace(-sigmas[0].log(), -sigmas[-1].log(), steps + 1).to(noise.device)
+            lam, sig = (lambda v: v), (lambda v: v.neg().exp())
+        else:
+            grid = sigmas.to(noise.device)
+            lam, sig = (lambda v: -v.log()), (lambda v: v)
+
+        def model(x_, g):
+            den = fn(x_, net=net, sigma=sig(g), inference=True, cond_scale=self.cond_scale, **kwargs)
+            return den if self.x0_pred else (x_ - den) / sig(g)
+
+        def update(x_, ml, gl, g_cur, ord_, corr):
+            g0, m0 = gl[-1], ml[-1]
+            h = (lam(g_cur) - lam(g0)).view(-1)
+            rks, d1s = [], []
+            for i in range(1, ord_):
+                rk = (lam(gl[-(i + 1)]) - lam(g0)) / h
+                rks.append(rk)
+                d1s.append((ml[-(i + 1)] - m0) / rk)
+            rks = torch.tensor([float(r) for r in rks] + [1.0], device=noise.device)
+            hh = -h if self.x0_pred else h
+            h_phi_1 = torch.expm1(hh)
+            h_phi_k, b_h, fact = h_phi_1 / hh - 1, torch.expm1(hh), 1
+            R, b = [], []
+            for i in range(1, ord_ + 1):
+                R.append(torch.pow(rks, i - 1))
+                b.append(h_phi_k * fact / b_h)
+                fact *= i + 1
+                h_phi_k = h_phi_k / hh - 1 / fact
+            R, b = torch.stack(R), torch.cat(b)
+            rho_p = (torch.tensor([0.5], device=noise.device) if ord_ == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])) if d1s else None
+            scale = 1.0 if self.x0_pred else sig(g_cur)
+            xt_ = sig(g_cur) / sig(g0) * x_ - h_phi_1 * m0 if self.x0_pred else x_ - sig(g_cur) * h_phi_1 * m0
+            comb = lambda rho: sum(rho[k] * d for k, d in enumerate(d1s)) if d1s else 0
+            x_t, m_t = xt_ - scale * b_h * comb(rho_p), None
+            if corr:
+                rho_c = torch.tensor([0.5], device=noise.device) if ord_ == 1 else torch.linalg.solve(R, b)
+                m_t = model(x_t, g_cur)
+                x_t = xt_ - scale * b_h * (comb(rho_c[:-1]) + rho_c[-1] * (m_t - m0))
+            return x_t, m_t
+
+        x = sigmas[0] * noise
+        ml, gl = [model(x, grid[0])], [grid[0]]
+        for step in range(1, order):
+            x, m = update(x, ml, gl, grid[step], step, True)
+            gl.append(grid[step]); ml.append(m)
+        for step in range(order, steps + 1):
+            x, m = update(x, ml, gl, grid[step], min(order, steps + 1 - step), step != steps)
+            for i in range(order - 1):
+                gl[i], ml[i] = gl[i + 1], ml[i + 1]
+            gl[-1] = grid[step]
+            if step < steps:
+                ml[-1] = m
+        return x.clamp(-1.0, 1.0)

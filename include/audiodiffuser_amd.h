@@ -8,7 +8,7 @@
  *                                     (src/models/components/diffusion.py:32-63, :232-241; components/utils.py:20-22)
  *   adf_sampler_run                <- EDMSampler.forward / EDMAlphaSampler.forward / DPMSampler.forward (multistep) /
  *                                     DPM2Sampler.forward (src/models/components/sampler_edm.py:371-397, :284-300,
- *                                     :710-768, :470-493) and ADPM2Sampler.forward (stochastic_sampler_edm.py:85-100)
+ *                                     :710-768, :470-493), ADPM2Sampler.forward (stochastic_sampler_edm.py:85-100), UniPCSampler.forward (:996-1053)
  *   the call site all of them sit behind: src/models/diffunet_complex_module.py:86-89
  *   adf_adm_create                 <- UNetModel.__init__ (src/models/backbones/unet2d_oai.py:410-601); adf_net_forward on that handle
  *                                     <- UNetModel.forward (:603-634)
@@ -70,6 +70,7 @@ typedef struct adf_net_config {
 #define ADF_SAMPLER_ADPM2 4     /* ADPM2Sampler ("DPM2 a Karras", ancestral)     stochastic_sampler_edm.py:35-100 */
 #define ADF_SAMPLER_LMS 5       /* LMSSampler ("LMS Karras"), order 1..4         sampler_edm.py:1134-1190 */
 #define ADF_SAMPLER_DPM2M 7     /* DPM2MSampler ("DPM-Solver++(2M) Karras"); needs num_steps + 1 sigmas   sampler_edm.py:1056-1131 */
+#define ADF_SAMPLER_UNIPC 8     /* UniPCSampler (variant bh2), order 1..3, x0 or noise prediction, both spacings   sampler_edm.py:807-1053 */
 #define ADF_SAMPLER_DPM_SINGLESTEP 6 /* DPMSampler(multisteps=False, x0_pred=True) sampler_edm.py:568-622, :769-805 */
 
 typedef struct adf_sampler_desc {
@@ -78,12 +79,12 @@ typedef struct adf_sampler_desc {
     float s_tmin, s_tmax, s_churn, s_noise;  /* EDM */
     int32_t use_heun;    /* EDM, EDM_ALPHA */
     float alpha;         /* EDM_ALPHA */
-    int32_t order;       /* DPM: 1..3; LMS: 1..4 */
+    int32_t order;       /* DPM, UniPC: 1..3; LMS: 1..4 */
     float sigma_data;    /* EluDiffusion.sigma_data */
     int32_t use_graph;   /* capture the whole step loop into one hipGraph and replay it */
     float rho, eta;      /* ADPM2 */
-    int32_t log_time_spacing;  /* DPM (both kinds): the reference's log_time_spacing flag (sampler_edm.py:518, :546-556) */
-    int32_t eps_pred;          /* DPM (both kinds): 1 = the reference's x0_pred=False (noise prediction, :700-706) */
+    int32_t log_time_spacing;  /* DPM (both kinds), UniPC: the reference's log_time_spacing flag (sampler_edm.py:518, :546-556, :824) */
+    int32_t eps_pred;          /* DPM (both kinds), UniPC: 1 = the reference's x0_pred=False (noise prediction, :700-706, :841-846) */
 } adf_sampler_desc;
 
 /* Hyper-parameters of WaveNetNoise (wavenet.py:154-157) and of the ResidualGroup it builds (:120: dim_in 128, dim_mid 512,

@@ -32,10 +32,10 @@ def import_next():
     from src.models.backbones.unet2d_oai import UNetModel
     from src.models.backbones.wavenet import WaveNetNoise
     from src.models.components.diffusion import EluDiffusion
-    from src.models.components.sampler_edm import EDMSampler
+    from src.models.components.sampler_edm import EDMSampler, UniPCSampler
     from src.models.components.scheduler import KarrasSchedule
     return dict(UNetModel=UNetModel, WaveNetNoise=WaveNetNoise, EluDiffusion=EluDiffusion, EDMSampler=EDMSampler,
-                KarrasSchedule=KarrasSchedule)
+                KarrasSchedule=KarrasSchedule, UniPCSampler=UniPCSampler)
 
 
 def load_into(net, weights):
@@ -179,6 +179,26 @@ def main():
     out["adm_samp_draws"] = draws.numpy()
     out["adm_samp_sigmas"] = sigmas.numpy()
     out["adm_samp_y"] = xs_ref.numpy()
+
+    # ---- UniPCSampler (sampler_edm.py:807-1053): only runs on 4-D states in the reference, so it is pinned here, on the small ADM net -----
+    report["unipc"] = {}
+    sig10 = ref["KarrasSchedule"](sigma_min=0.002, sigma_max=80.0, rho=7.0, num_steps=10)()
+    out["unipc_sigmas"] = sig10.numpy()
+
+    def fn_plain(x, net=None, sigma=None, sigmas=None, **kw):
+        return diff.denoise_fn(x, net=net, sigma=sigma, sigmas=sigmas, **kw)
+
+    for tag, kw in (("o2_log", dict(order=2, log_time_spacing=True)), ("o3_log", dict(order=3, log_time_spacing=True)),
+                    ("o1_log", dict(order=1, log_time_spacing=True)), ("o2_sig", dict(order=2, log_time_spacing=False)),
+                    ("o3_sig", dict(order=3, log_time_spacing=False)), ("o2_log_eps", dict(order=2, log_time_spacing=True, x0_pred=False))):
+        smp = ref["UniPCSampler"](num_steps=10, **kw)
+        with torch.no_grad():
+            yr = smp(noise, fn=fn_plain, net=net, sigmas=sig10)
+            yo = S.unipc_sampler(noise, fn_o, sig10, 10, **kw)
+        e = rel_err(yo, yr)
+        assert torch.isfinite(yr).all() and e < 2e-5, (tag, e)
+        report["unipc"][tag] = e
+        out[f"unipc_{tag}_y"] = yr.numpy()
     del net
 
     # ================================================================= WaveNetNoise

@@ -313,3 +313,80 @@ def adpm2_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_s
         x = x + d_mid * (s_down - s)
         x = x + (injected_noise[i] if injected_noise is not None else torch.randn_like(x)) * s_up
     return x.clamp(-1.0, 1.0)
+
+
+def unipc_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int, order: int = 2,
+                  log_time_spacing: bool = True, x0_pred: bool = True, trace: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+    """UniPCSampler (sampler_edm.py:807-1053; variant 'bh2'): multistep predictor-corrector, NFE = its step count.  The
+    reference only runs on 4-D states (hard-coded einsum 'k,bkchw->bchw', :955); this restatement sums the same terms in
+    the same order for any shape.  ``num_steps`` is the constructor argument: the loop makes num_steps steps on a lambda
+    grid that is linear between the first and the last sigma (log_time_spacing, :862-866) or num_steps - 1 steps on the sigma
+    list itself (:828, :868-870).  x0_pred=False: the model value is (x - D) / sigma (:841-846).  Final clamp (:1053)."""
+    steps = num_steps if log_time_spacing else num_steps - 1
+    assert steps >= order
+    grid, lam, sig, _ = _dpm_grid(sigmas, steps, log_time_spacing)
+    model = (lambda x_, g: fn(x_, sigma=sig(g))) if x0_pred else (lambda x_, g: (x_ - fn(x_, sigma=sig(g))) / sig(g))
+
+    def update(x, m_list, g_list, g_cur, ord_, use_corrector):                 # multistep_uni_pc_update, :872-994
+        g0, m0 = g_list[-1], m_list[-1]
+        h = (lam(g_cur) - lam(g0)).view(-1)
+        rks, d1s = [], []
+        for i in range(1, ord_):
+            rk = (lam(g_list[-(i + 1)]) - lam(g0)) / h
+            rks.append(rk)
+            d1s.append((m_list[-(i + 1)] - m0) / rk)
+        rks.append(1.0)
+        rks = torch.tensor(rks)
+        hh = -h if x0_pred else h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        b_h = torch.expm1(hh)
+        fact = 1
+        R, b = [], []
+        for i in range(1, ord_ + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / b_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        R, b = torch.stack(R), torch.cat(b)
+        rhos_p = None
+        if d1s:
+            rhos_p = torch.tensor([0.5]) if ord_ == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+        rhos_c = (torch.tensor([0.5]) if ord_ == 1 else torch.linalg.solve(R, b)) if use_corrector else None
+        scale = sig(g_cur) if not x0_pred else 1.0
+        if x0_pred:
+            xt_ = sig(g_cur) / sig(g0) * x - h_phi_1 * m0
+        else:
+            xt_ = x - sig(g_cur) * h_phi_1 * m0
+
+        def comb(rhos):                                                       # einsum('k,bkchw->bchw'): k ascending
+            acc = 0
+            for k, d in enumerate(d1s):
+                acc = acc + rhos[k] * d
+            return acc
+
+        x_t = xt_ - scale * b_h * (comb(rhos_p) if d1s else 0)
+        m_t = None
+        if use_corrector:
+            m_t = model(x_t, g_cur)
+            x_t = xt_ - scale * b_h * ((comb(rhos_c[:-1]) if d1s else 0) + rhos_c[-1] * (m_t - m0))
+        return x_t, m_t
+
+    x = sigmas[0] * noise
+    m_list, g_list = [model(x, grid[0])], [grid[0]]
+    for step in range(1, order):                                               # :1013-1022
+        x, m = update(x, m_list, g_list, grid[step], step, True)
+        g_list.append(grid[step])
+        m_list.append(m)
+        if trace is not None:
+            trace.append(x.clone())
+    for step in range(order, steps + 1):                                       # :1025-1051
+        x, m = update(x, m_list, g_list, grid[step], min(order, steps + 1 - step), step != steps)
+        for i in range(order - 1):
+            g_list[i], m_list[i] = g_list[i + 1], m_list[i + 1]
+        g_list[-1] = grid[step]
+        if step < steps:
+            m_list[-1] = m
+        if trace is not None:
+            trace.append(x.clone())
+    return x.clamp(-1.0, 1.0)

@@ -182,3 +182,38 @@ def test_config4_sampler_with_injected_draws_vs_reference_golden(gold):
         d = diff.denoise_fn(noise.cuda(), net=net, inference=True, sigma=1.7).cpu()
         ref = E.denoise(lambda xi, ti, **kw: O.unet2d_forward(w, cfg, xi, ti), noise, 0.5, sigma=1.7)
     assert rel(d, ref) < FP32_TIGHT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["o2_log", "o3_log", "o1_log", "o2_sig", "o3_sig", "o2_log_eps"])
+def test_unipc_sampler_on_the_device_vs_reference_golden(gold, tag):
+    """UniPCSampler (4-D states only in the reference) on the device, eager and graph-replayed, against the REFERENCE's results."""
+    cases = {"o2_log": dict(order=2, log_time_spacing=True), "o3_log": dict(order=3, log_time_spacing=True),
+             "o1_log": dict(order=1, log_time_spacing=True), "o2_sig": dict(order=2, log_time_spacing=False),
+             "o3_sig": dict(order=3, log_time_spacing=False), "o2_log_eps": dict(order=2, log_time_spacing=True, x0_pred=False)}
+    cfg = A.config_c4_small()
+    net, _ = make(cfg)
+    net = net.cuda()
+    diff = A.EluDiffusion(sigma_data=0.5)
+    noise, sig = T(gold["adm_samp_noise"]), T(gold["unipc_sigmas"])
+    for use_graph in (False, True):
+        smp = A.UniPCSampler(num_steps=10, use_graph=use_graph, **cases[tag])
+        y = smp(noise.cuda(), fn=diff.denoise_fn, net=net, sigmas=sig).cpu()
+        assert rel(y, T(gold[f"unipc_{tag}_y"])) < 2e-4, (tag, use_graph, rel(y, T(gold[f"unipc_{tag}_y"])))
+
+
+@pytest.mark.gpu
+def test_unipc_sampler_on_a_1d_waveform_state_vs_oracle():
+    """The device UniPC is shape-agnostic (the reference's is not: its einsum wants [B, K, C, H, W]): the 1-D U-Net, 12 steps, order 3."""
+    from audiodiffuser_amd.weights import generate_weights as gw, generate_noise
+    from oracle import edm as E, samplers as S
+    cfg = A.config_tiny()
+    w = gw(cfg, seed=0)
+    net = A.UNet1dBase.from_config(cfg, compute_dtype="fp32")
+    net.load_state_dict(w)
+    noise = generate_noise(3, 2, 256)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 12)()
+    with torch.no_grad():
+        ref = S.unipc_sampler(noise, E.make_denoiser(w, cfg, 0.2), sig, 12, order=3, log_time_spacing=True)
+    y = A.UniPCSampler(num_steps=12, order=3)(noise.cuda(), fn=A.EluDiffusion(sigma_data=0.2).denoise_fn, net=net.cuda(), sigmas=sig).cpu()
+    assert rel(y, ref) < 2e-4, rel(y, ref)

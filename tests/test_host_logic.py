@@ -59,6 +59,9 @@ def test_sampler_nfe_via_abi():
     bad = A.DPMSampler(1.0, order=4, num_steps=50, multisteps=True, x0_pred=True, log_time_spacing=False)._desc(0.2)
     assert nfe(bad, 50) == -1
     assert nfe(A.DPM2Sampler(num_steps=50, s_churn=0.0)._desc(0.2), 50) == 2 * 49      # no sigma_next == 0 inside the schedule
+    assert nfe(A.UniPCSampler(num_steps=20, order=2)._desc(0.2), 20) == 20            # "NFE = num_steps" (sampler_edm.py:813)
+    assert nfe(A.UniPCSampler(num_steps=20, order=3, log_time_spacing=False)._desc(0.2), 20) == 19
+    assert nfe(A.UniPCSampler(num_steps=20, order=4)._desc(0.2), 20) == -1
     assert nfe(A.ADPM2Sampler(num_steps=50)._desc(0.2), 50) == 2 * 49
 
 

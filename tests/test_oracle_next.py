@@ -129,6 +129,38 @@ def test_adm_bf16_storage_mode_and_teacher_forcing():
     assert bad == {"middle_block.0.h1", "middle_block.0"}, bad      # the forced tensor and its one consumer
 
 
+UNIPC_CASES = {"o2_log": dict(order=2, log_time_spacing=True), "o3_log": dict(order=3, log_time_spacing=True),
+               "o1_log": dict(order=1, log_time_spacing=True), "o2_sig": dict(order=2, log_time_spacing=False),
+               "o3_sig": dict(order=3, log_time_spacing=False), "o2_log_eps": dict(order=2, log_time_spacing=True, x0_pred=False)}
+
+
+@pytest.mark.parametrize("tag", sorted(UNIPC_CASES))
+def test_unipc_sampler_vs_reference_golden(gold, tag):
+    """UniPCSampler (sampler_edm.py:807-1053) only runs on 4-D states in the reference: pinned on the small ADM net, 10 steps, orders 1-3,
+    both spacings, x0 and noise prediction.  Also: the evaluation count equals the step count, and the plugin's compatibility branch
+    (tensor ops around a foreign fn) computes the same."""
+    import audiodiffuser_amd as P
+    cfg = A.config_c4_small()
+    w = A.generate_weights(cfg, seed=3)
+    calls = {"n": 0}
+
+    def net(xi, ti, **_kw):
+        calls["n"] += 1
+        return A.unet2d_forward(w, cfg, xi, ti)
+
+    fn = lambda x, sigma=None, sigmas=None: E.denoise(net, x, 0.5, sigma=sigma, sigmas=sigmas)
+    noise, sig = T(gold["adm_samp_noise"]), T(gold["unipc_sigmas"])
+    kw = UNIPC_CASES[tag]
+    with torch.no_grad():
+        y = S.unipc_sampler(noise, fn, sig, 10, **kw)
+    assert calls["n"] == (10 if kw["log_time_spacing"] else 9)
+    assert rel(y, T(gold[f"unipc_{tag}_y"])) < 2e-5
+    compat = P.UniPCSampler(num_steps=10, **kw)
+    with torch.no_grad():
+        yc = compat(noise, fn=lambda x, net=None, sigma=None, inference=True, cond_scale=1.0, **k: fn(x, sigma=sigma), net=None, sigmas=sig)
+    assert rel(yc, y) < 2e-5
+
+
 def test_timestep_embedding_layout():
     e = A.timestep_embedding(torch.tensor([0.0, 2.0]), 8)
     assert torch.equal(e[0], torch.tensor([1.0, 1, 1, 1, 0, 0, 0, 0]))       # cosines first (:46)
