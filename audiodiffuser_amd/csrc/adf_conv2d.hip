@@ -379,17 +379,25 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
         const char* const aRow = ldsA + ((wm * WR + dy) * (TW + 2) + r + dx) * kC2Pitch;      // tile row wm * WR (+ i): one halo row further
         const char* const wRow = ldsW + (it & 1) * WSTAGE + (wn * 64 + r) * kC2Pitch;
         if constexpr (kBf16) {
+            // fragments of K step ks + 1 are read while the MFMAs of step ks issue (the LDS latency would otherwise sit between every read
+            // and its MFMAs: with 4 - 8 MFMAs per step nothing else covers it)
+            c2_bf16x8_t fa[2][WR], fb[2][2];
+            auto frags = [&](int ks, c2_bf16x8_t (&xa)[WR], c2_bf16x8_t (&xb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < WR; ++i) xa[i] = *(const c2_bf16x8_t*)(aRow + i * (TW + 2) * kC2Pitch + (ks * 2 + h) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xb[j] = *(const c2_bf16x8_t*)(wRow + j * 32 * kC2Pitch + (ks * 2 + h) * 16);
+            };
+            frags(0, fa[0], fb[0]);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                c2_bf16x8_t fa[WR], fb[2];
-#pragma unroll
-                for (int i = 0; i < WR; ++i) fa[i] = *(const c2_bf16x8_t*)(aRow + i * (TW + 2) * kC2Pitch + (ks * 2 + h) * 16);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = *(const c2_bf16x8_t*)(wRow + j * 32 * kC2Pitch + (ks * 2 + h) * 16);
+                if (ks + 1 < 4) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < WR; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
@@ -491,6 +499,8 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
         // the L2 -> CU rate and bounds the kernel; 256 pixels per workgroup halve it
         static const int big = adf_route_switch("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
         if (big && a.H % 8 == 0 && px / 256 * ny >= 512) return bf16 ? launch_conv2d_tile<bf16_t, 8, 2>(a, s) : launch_conv2d_tile<float, 8, 2>(a, s);
+        static const int wr2 = adf_route_switch("ADF_CONV2D_WR2", 0);     // 64 x 64 wave tiles on four waves (A/B runs)
+        if (wr2 && a.H % 4 == 0 && px / 128 * ny >= 128) return bf16 ? launch_conv2d_tile<bf16_t, 4, 2>(a, s) : launch_conv2d_tile<float, 4, 2>(a, s);
         if (a.H % 4 == 0 && px / 128 * ny >= 128) return bf16 ? launch_conv2d_tile<bf16_t, 4, 1>(a, s) : launch_conv2d_tile<float, 4, 1>(a, s);
         if (a.H % 2 == 0) return bf16 ? launch_conv2d_tile<bf16_t, 2, 1>(a, s) : launch_conv2d_tile<float, 2, 1>(a, s);
     }
