@@ -36,8 +36,25 @@ constexpr int kC2Pitch = 144;       // LDS row pitch: 128 bytes of K + 16 (confl
 // (NT is a multiple of the pieces per row), adds the residual, stores, and -- if asked -- reduces the GroupNorm statistics of what it
 // stored: per-thread partial sums -> lanes of a wave that share the piece column (shuffles) -> per-channel sums in LDS -> per-group fp64
 // atomics.  pix(row) maps a tile row to its pixel's element offset / cout inside the image.
+// The residual pieces a thread adds in c2_store_tile, loaded ahead of the accumulator -> LDS phase so that their latency hides behind it.
+template <typename T, int TM, int TN, int NT>
+struct C2Res { u32x4_t v[TM * (TN / Elem<T>::kPerChunk) / NT]; };
 template <typename T, int TM, int TN, int NT, typename FP>
-__device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, int PO, int tid, int n0, int b, T* og, const T* rg, FP pix) {
+__device__ __forceinline__ void c2_res_prefetch(const Conv2dArgs& a, int tid, int n0, const T* rg, FP pix, C2Res<T, TM, TN, NT>& r) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int PPR = TN / EPC;
+    const int pc = tid % PPR;
+    const int col = n0 + pc * EPC;
+#pragma unroll
+    for (int k = 0; k < TM * PPR / NT; ++k) {
+        const int row = tid / PPR + k * (NT / PPR);
+        r.v[k] = (rg && col < a.cout) ? *(const u32x4_t*)(rg + pix(row) * a.cout + col) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+}
+
+template <typename T, int TM, int TN, int NT, typename FP>
+__device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, int PO, int tid, int n0, int b, T* og, const T* rg, FP pix,
+                                              const C2Res<T, TM, TN, NT>& pre) {
     constexpr int EPC = Elem<T>::kPerChunk;
     constexpr int PPR = TN / EPC;
     static_assert(NT % PPR == 0 && PPR <= 64 && 64 % PPR == 0, "a thread keeps one piece column");
@@ -47,14 +64,16 @@ __device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, in
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     if (col < a.cout) {
-        for (int row = tid / PPR; row < TM; row += NT / PPR) {
+#pragma unroll
+        for (int k = 0; k < TM * PPR / NT; ++k) {
+            const int row = tid / PPR + k * (NT / PPR);
             u32x4_t v = *(const u32x4_t*)(lds + row * PO + pc * 16);
             const size_t o = pix(row) * a.cout + col;
             float f[EPC];
             unpack16<T>(v, f);
             if (rg) {
                 float g[EPC];
-                unpack16<T>(*(const u32x4_t*)(rg + o), g);
+                unpack16<T>(pre.v[k], g);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) f[e] += g[e];
             }
@@ -235,6 +254,9 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
 
     // ---- epilogue: accumulators (+ bias) -> LDS tile -> 16-byte pieces (+ residual) -> global ---------------------------------
     // (accumulator layout: column r, rows (q & 3) + 8 (q >> 2) + 4 h)
+    auto pixg = [&](int row) { return (size_t)(m0 + row); };
+    C2Res<T, TM, TN, NT> pre;
+    c2_res_prefetch<T, TM, TN, NT>(a, tid, n0, (const T*)a.res, pixg, pre);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lc = wn * 64 + j * 32 + r;
@@ -247,7 +269,7 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
         }
     }
     __syncthreads();
-    c2_store_tile<T, TM, TN, NT>(a, lds, PO, tid, n0, (int)(m0 / HW), (T*)a.out, (const T*)a.res, [&](int row) { return (size_t)(m0 + row); });
+    c2_store_tile<T, TM, TN, NT>(a, lds, PO, tid, n0, (int)(m0 / HW), (T*)a.out, (const T*)a.res, pixg, pre);
 }
 
 // The same-size 3x3 convs (the two convs of every ResBlock: > 90 % of the network's flops) on SPATIAL tiles: TH x 32 output pixels
@@ -438,6 +460,11 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
     C2_STAMP(6);
 
     // ---- epilogue through LDS (as conv2d_gemm_kernel): tile rows wm * WR + i, pixel = accumulator row -------------------------------
+    T* const og = (T*)a.out + (size_t)b * a.H * a.W * a.cout;
+    const T* const rg = a.res ? (const T*)a.res + (size_t)b * a.H * a.W * a.cout : nullptr;
+    auto pixt = [&](int row) { return (size_t)(ty0 + row / TW) * a.W + tx0 + (row % TW); };
+    C2Res<T, TM, TN, NT> pre;
+    c2_res_prefetch<T, TM, TN, NT>(a, tid, n0, rg, pixt, pre);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lc = wn * 64 + j * 32 + r;
@@ -452,10 +479,8 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
             }
     }
     __syncthreads();
-    T* const og = (T*)a.out + (size_t)b * a.H * a.W * a.cout;
-    const T* const rg = a.res ? (const T*)a.res + (size_t)b * a.H * a.W * a.cout : nullptr;
     C2_STAMP(7);
-    c2_store_tile<T, TM, TN, NT>(a, lds, PO, tid, n0, b, og, rg, [&](int row) { return (size_t)(ty0 + row / TW) * a.W + tx0 + (row % TW); });
+    c2_store_tile<T, TM, TN, NT>(a, lds, PO, tid, n0, b, og, rg, pixt, pre);
     C2_STAMP(8);
 }
 
