@@ -242,3 +242,21 @@ def test_dpm2_family_compat_branch_matches_oracle():
     assert torch.equal(y, S.dpm2_sampler(noise, fn_o, sig, 9, s_tmin=0.05, s_tmax=50.0, s_churn=20.0, s_noise=1.01, injected_noise=inj))
     y = A.ADPM2Sampler(rho=7.0, num_steps=9, eta=0.8)(noise, fn=mock, net=None, sigmas=sig, injected_noise=inj)
     assert torch.equal(y, S.adpm2_sampler(noise, fn_o, sig, 9, rho=7.0, eta=0.8, injected_noise=inj))
+
+
+def test_bench_defaults_per_config():
+    """bench.py --config picks the BASELINE workload sizes: configs[1] 64 x 16384 / N = 50 Heun; configs[2] DPM; configs[3] 80 x 256 mel blocks,
+    35-step churn sampler; configs[4] 22050 samples, 6 steps, batch 128 (1024 over 8 GPUs)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.parse([])
+    assert (a.config, a.batch, a.length, a.num_steps, a.sampler, a.gpus) == ("c2", 64, 16384, 50, "heun", 1)
+    a = bench.parse(["--config", "c3"])
+    assert (a.batch, a.length, a.num_steps, a.sampler) == (64, 16384, 50, "dpm")
+    a = bench.parse(["--config", "c4"])
+    assert (a.batch, a.length, a.num_steps, a.sampler) == (64, 80 * 256, 35, "churn")
+    a = bench.parse(["--config", "c5", "--batch", "32"])
+    assert (a.batch, a.length, a.num_steps, a.sampler) == (32, 22050, 6, "heun")
+    assert bench.adm_conv_flops(A.config_c4(), 1, 80, 256) > 2.0e11          # ~0.25 TFLOP per 1 x 80 x 256 block and evaluation

@@ -198,3 +198,33 @@ def test_bf16_sampler_against_fp32_device_run_and_weight_reload():
     with torch.no_grad():
         ref = W.wavenet_forward(w2, cfg, a, st)
     assert rel(n32(a.cuda(), st.cuda()).cpu(), ref) < FP32_TIGHT
+
+
+@pytest.mark.gpu
+def test_plan_cache_bounds_and_weight_update_on_the_second_network_kind():
+    """The workspace cap (4 (B, L) plans per handle) and the rebuilt weight-normed weights also hold for a WaveNetNoise handle: six shapes in a
+    row, the first one again, then an in-place parameter update."""
+    cfg = A.config_c5_small()
+    net, w = make(cfg)
+    net = net.cuda()
+    g = torch.Generator().manual_seed(21)
+    first = None
+    for i, (b, t) in enumerate([(2, 100), (1, 300), (3, 64), (2, 257), (1, 1000), (4, 33), (2, 100)]):
+        a, st = torch.randn(b, t, generator=g), torch.linspace(-0.5, 0.5, b)
+        if i in (0, 6):
+            gg = torch.Generator().manual_seed(99)
+            a = torch.randn(b, t, generator=gg)
+        y = net(a.cuda(), st.cuda()).cpu()
+        with torch.no_grad():
+            ref = W.wavenet_forward(w, cfg, a, st)
+        assert rel(y, ref) < FP32_TIGHT, (i, rel(y, ref))
+        if i == 0:
+            first = y
+    assert torch.equal(first, y)                      # the evicted and rebuilt workspace computes the same
+    with torch.no_grad():                             # an in-place update of g bumps the tensor version: the effective weights are rebuilt
+        net.get_parameter("skip_projection.conv.module.weight_g").mul_(1.5)
+    w2 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    a, st = torch.randn(2, 100, generator=g), torch.tensor([0.1, -0.2])
+    with torch.no_grad():
+        ref = W.wavenet_forward(w2, cfg, a, st)
+    assert rel(net(a.cuda(), st.cuda()).cpu(), ref) < FP32_TIGHT
