@@ -3,8 +3,9 @@ row 3).
 
 Contract kept (reference: src/models/backbones/unet2d_oai.py:382-635): the constructor kwargs, ``state_dict()`` keys / shapes
 (reference checkpoints strict-load), ``forward(x[B, C, H, W], time[B], classes=None, cond_drop_prob=None) -> [B, out_channels, H, W]``.
-On the device: the configuration BASELINE config 4 uses -- ``use_scale_shift_norm=True``, conv resampling, no resblock up/down,
-unconditional, either attention order.  Other constructor variants raise (their oracle and fixtures exist: oracle/unet2d_oai.py).
+On the device: ``use_scale_shift_norm=True``, conv resampling, no resblock up/down, either attention order, unconditional (BASELINE
+config 4) or class-conditional with classifier-free guidance (``num_classes``; the shipped ``diffunet_complex_oai_sc09_cfg.yaml`` setting).
+Other constructor variants raise (their oracle and fixtures exist: oracle/unet2d_oai.py).
 """
 from __future__ import annotations
 
@@ -44,15 +45,15 @@ class UNetModel(HipNet):
         super().__init__()
         if compute_dtype not in _DTYPES:
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
-        if num_classes is not None or class_embed_dim is not None:
-            raise NotImplementedError("class-conditional UNetModel is not on the device yet (oracle: oracle/unet2d_oai.py)")
+        if class_embed_dim is not None:
+            raise NotImplementedError("class_embed_dim (embedding inputs instead of labels) is outside the hot path")
         if not use_scale_shift_norm or resblock_updown or not conv_resample:
             raise NotImplementedError("on the device: use_scale_shift_norm=True, conv_resample=True, resblock_updown=False (BASELINE config 4)")
         self.compute_dtype = compute_dtype
         self.cond_drop_prob = cond_drop_prob
         self.cfg = ADMConfig(image_size=image_size, in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,
                              num_res_blocks=num_res_blocks, attention_resolutions=attention_resolutions, channel_mult=tuple(channel_mult),
-                             conv_resample=conv_resample, num_classes=None, num_heads=num_heads, num_head_channels=num_head_channels,
+                             conv_resample=conv_resample, num_classes=num_classes, num_heads=num_heads, num_head_channels=num_head_channels,
                              use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
                              use_new_attention_order=use_new_attention_order)
         for name, (shape, kind) in param_specs(self.cfg).items():
@@ -63,13 +64,20 @@ class UNetModel(HipNet):
         return cls(compute_dtype=compute_dtype, **cfg.to_kwargs())
 
     def forward(self, x: torch.Tensor, time: torch.Tensor, classes: Optional[torch.Tensor] = None, cond_drop_prob=None, **_ignored) -> torch.Tensor:
-        if classes is not None:
-            raise AssertionError("must specify y if and only if the model is class-conditional")     # unet2d_oai.py:614-616
+        assert (classes is not None) == (self.cfg.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"                           # unet2d_oai.py:614-616
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("the HIP UNetModel is an inference path (no backward); call it under torch.no_grad()")
         if x.ndim != 4:
             raise ValueError("x must be shaped [B, C, H, W]")
         hd = self.native(x.device)
+        if classes is not None:
+            # LabelEmbedder(classes, cond_drop_prob): the label mask is deterministic only at cond_drop_prob 0 (keep all) and 1 (null embedding
+            # for all), the two values inference uses (diffusion.py:50, :53)
+            cdp = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+            if cdp not in (0, 0.0, 1, 1.0):
+                raise NotImplementedError("cond_drop_prob other than 0 or 1 draws a random label mask (training only)")
+            hd.set_condition(classes, x.device, null_labels=bool(cdp), cond_scale=1.0)
         xin = x.detach().to(torch.float32).contiguous()
         tin = time.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         if tin.numel() != xin.shape[0]:

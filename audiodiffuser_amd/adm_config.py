@@ -37,8 +37,8 @@ class ADMConfig:
 
     @property
     def class_cond(self) -> bool:
-        """What the shared denoise / sampler host code asks of a network config (class-conditional nets are not on the device)."""
-        return False
+        """What the shared denoise / sampler host code asks of a network config."""
+        return self.num_classes is not None
 
     @property
     def attention_ds(self) -> Tuple[int, ...]:

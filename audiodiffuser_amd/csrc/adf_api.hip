@@ -647,6 +647,8 @@ struct FwdIO {
     const float* coef = nullptr; int coef_bstride = 0; int mode = 0; const float* x_noisy = nullptr;
     const float* film2 = nullptr; int film2_bstride = 0;   // class part of the FiLM projections (rows of adf_handle::cond_film)
     const float* film_pre = nullptr;                       // this evaluation's row of Plan::film_all: sigma embedding + FiLM already computed
+    const float* temb_pre = nullptr;                       // this evaluation's row of Plan::temb_all (class-conditional ADM net: the FiLM rows are per sample)
+    bool null_cond = false;                                // class-conditional ADM net: every sample takes the null class embedding (guidance branch)
 };
 
 int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
@@ -967,6 +969,17 @@ int adm_build_weights(adf_handle* h) {
     a.t_b1 = R.reg_f32("time_embed.0.bias", ted);
     a.t_w2 = R.reg_f32("time_embed.2.weight", (int64_t)ted * ted);
     a.t_b2 = R.reg_f32("time_embed.2.bias", ted);
+    if (c.num_classes > 0) {             // LabelEmbedder(num_classes, None, model_channels, 4 * model_channels), conditioner.py:64-90; unet2d_oai.py:461-468
+        h->cdim = ted;
+        h->lab_null = R.reg_f32("label_conditioner.null_classes_emb", mc);
+        h->lab_emb = R.reg_f32("label_conditioner.label_emb.weight", (int64_t)c.num_classes * mc);
+        h->lab_lnw = R.reg_f32("label_conditioner.class_to_cond.0.weight", mc);
+        h->lab_lnb = R.reg_f32("label_conditioner.class_to_cond.0.bias", mc);
+        h->lab_w1 = R.reg_f32("label_conditioner.class_to_cond.1.weight", (int64_t)ted * mc);
+        h->lab_b1 = R.reg_f32("label_conditioner.class_to_cond.1.bias", ted);
+        h->lab_w2 = R.reg_f32("label_conditioner.class_to_cond.3.weight", (int64_t)ted * ted);
+        h->lab_b2 = R.reg_f32("label_conditioner.class_to_cond.3.bias", ted);
+    }
     auto reg_layer = [&](const AdmLayer& l, const std::string& pre) {
         if (l.kind == 0) {
             a.in_w = R.reg_f32(pre + ".weight", (int64_t)a.input_ch * c.in_channels * 9);
@@ -1023,8 +1036,23 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     const int B = p->B, ted = 4 * c.model_channels;
     if (!p->dry && p->stats_bytes && hipMemsetAsync(p->stats, 0, p->stats_bytes, s) != hipSuccess) return fail(h, "hipMemsetAsync(stats) failed");
     const float* film = io.film_pre ? io.film_pre : p->film;
-    const int film_bs = io.nb > 1 ? h->film_total : 0;
-    if (W.live() && !io.film_pre) {
+    int film_bs = io.nb > 1 ? h->film_total : 0;
+    if (h->cdim > 0) {
+        // class-conditional: emb[b] = time_embed(t) + label_conditioner(classes[b]) (unet2d_oai.py:619-623), so every sample has its own FiLM rows
+        float* emb_b = (float*)W.alloc((size_t)B * ted * 4);
+        film = p->film; film_bs = h->film_total;
+        if (W.live()) {
+            const float* te = io.temb_pre;
+            int te_bs = 0;
+            if (!te) {
+                W.check(launch_adm_time_embed(io.t, io.t_stride, io.nb, c.model_channels, a.t_w1, a.t_b1, a.t_w2, a.t_b2, ted, p->temb, s));
+                te = p->temb; te_bs = io.nb > 1 ? ted : 0;
+            }
+            const float* ce = io.null_cond ? h->cond_emb + (size_t)B * ted : h->cond_emb;       // last row = the null embedding
+            W.check(launch_add_rows(emb_b, te, te_bs, ce, io.null_cond ? 0 : ted, B, ted, s));
+            W.check(launch_film(emb_b, ted, h->film_w, ted, 0, h->film_b, p->film, B, h->film_total, s));
+        }
+    } else if (W.live() && !io.film_pre) {
         W.check(launch_adm_time_embed(io.t, io.t_stride, io.nb, c.model_channels, a.t_w1, a.t_b1, a.t_w2, a.t_b2, ted, p->temb, s));
         W.check(launch_film(p->temb, ted, h->film_w, ted, 0, h->film_b, p->film, io.nb, h->film_total, s));
     }
@@ -1132,6 +1160,8 @@ int cond_rows(adf_handle* h, int B, bool null_branch, FwdIO& io) {
     if (h->cdim == 0) return 0;
     if (!h->cond_on || h->cond_B != B)
         return fail(h, "class-conditional network: call adf_set_condition with the labels of this batch first");
+    io.null_cond = null_branch;
+    if (h->adm) return 0;            // the ADM net adds the class embedding to the time embedding before the FiLM projections (adm_forward)
     if (null_branch) { io.film2 = h->cond_film + (size_t)B * h->film_total; io.film2_bstride = 0; }
     else { io.film2 = h->cond_film; io.film2_bstride = h->film_total; }
     return 0;
@@ -1191,7 +1221,8 @@ struct SamplerCtx {
             FwdIO io;
             io.x = x; io.t = p->coef_all + (size_t)k * 4 + 1; io.t_stride = 4; io.nb = 1;
             io.coef = p->coef_all + (size_t)k * 4; io.coef_bstride = 0; io.x_noisy = x;
-            io.film_pre = p->film_all + (size_t)k * h->film_total;
+            if (h->adm && h->cdim > 0) io.temb_pre = p->temb_all + (size_t)k * 4 * h->cfg.channels;
+            else io.film_pre = p->film_all + (size_t)k * h->film_total;
             return denoise_io(h, p, io, out, s);
         }
         return denoise_scalar(h, p, x, sigma, d->sigma_data, out, s);
@@ -1818,8 +1849,8 @@ int adf_adm_create(const adf_adm_config* cfg, adf_handle** out) {
     if (c.n_mult < 1 || c.n_mult > ADF_ADM_MAX_LEVELS || c.num_res_blocks < 1 || c.n_attention_ds < 0 || c.n_attention_ds > ADF_ADM_MAX_LEVELS) { g_create_error = "adf_adm_create: bad level / block counts"; return 1; }
     if (c.model_channels < 32 || c.model_channels % 32 || c.model_channels % kc || c.model_channels > 256) { g_create_error = "adf_adm_create: model_channels must be a multiple of 32 (fp32) / 64 (bf16), at most 256"; return 1; }
     if (c.in_channels < 1 || c.out_channels < 1 || c.out_channels > 4) { g_create_error = "adf_adm_create: in_channels >= 1, 1 <= out_channels <= 4"; return 1; }
-    if (!c.use_scale_shift_norm || c.resblock_updown || !c.conv_resample || c.num_classes > 0) {
-        g_create_error = "adf_adm_create: only the configuration of BASELINE config 4 is on the device (use_scale_shift_norm, conv resampling, no resblock up/down, unconditional)";
+    if (!c.use_scale_shift_norm || c.resblock_updown || !c.conv_resample || c.num_classes < 0) {
+        g_create_error = "adf_adm_create: on the device: use_scale_shift_norm, conv resampling, no resblock up/down (unconditional or class-conditional)";
         return 1;
     }
     for (int i = 0; i < c.n_mult; ++i) if (c.channel_mult[i] < 1) { g_create_error = "adf_adm_create: bad channel_mult"; return 1; }
@@ -1939,13 +1970,15 @@ int adf_set_condition(adf_handle* h, const int64_t* classes_dev, int B, int null
     }
     if (hipMemcpyAsync(h->cond_classes, classes_dev, (size_t)B * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "class label copy failed");
     const adf_net_config& c = h->cfg;
-    if (const char* e = launch_class_embed(h->cond_classes, c.num_classes, null_labels ? 1 : 0, h->lab_emb, h->lab_null, h->lab_lnw, h->lab_lnb,
+    if (const char* e = launch_class_embed(h->cond_classes, h->adm ? h->adm->cfg.num_classes : c.num_classes, null_labels ? 1 : 0, h->lab_emb, h->lab_null, h->lab_lnw, h->lab_lnb,
                                            h->lab_w1, h->lab_b1, h->lab_w2, h->lab_b2, c.channels, h->cdim, h->cond_emb, B + 1, s))
         return fail(h, e);
     // class part of every FiLM projection: columns [tdim, tdim + cdim) of the concatenated weight, no bias (it is in the time part)
-    if (const char* e = launch_film(h->cond_emb, h->cdim, h->film_w, 4 * c.channels + h->cdim, 4 * c.channels, nullptr, h->cond_film, B + 1,
-                                    h->film_total, s))
-        return fail(h, e);
+    // (not for the ADM net: its embeddings are ADDED before the SiLU of emb_layers, unet2d_oai.py:621-623, so nothing separates)
+    if (!h->adm)
+        if (const char* e = launch_film(h->cond_emb, h->cdim, h->film_w, 4 * c.channels + h->cdim, 4 * c.channels, nullptr, h->cond_film, B + 1,
+                                        h->film_total, s))
+            return fail(h, e);
     h->cond_on = true; h->cond_B = B; h->cond_scale = cond_scale;
     return 0;
 }
@@ -2058,6 +2091,7 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
             te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb_all;
             if (const char* e = launch_time_embed(te, st)) return fail(h, e);
         }
+        if (h->adm && h->cdim > 0) return 0;       // per-sample FiLM rows (time + class embedding): projected inside each pass
         if (const char* e = launch_film(p->temb_all, 4 * cfg.channels, h->film_w, 4 * cfg.channels + h->cdim, 0, h->film_b, p->film_all, n_eval,
                                         h->film_total, st))
             return fail(h, e);

@@ -45,6 +45,8 @@ const char* launch_gn_stats_any(const void* x, int bf16, int B, int L, int C, in
 // timestep_embedding (:31-49): cos | sin features of t[b * t_stride] -> Linear -> SiLU -> Linear (time_embed :455-459): emb[b][dim_out]
 const char* launch_adm_time_embed(const float* t, int t_stride, int nb, int mc, const float* w1, const float* b1, const float* w2,
                                   const float* b2, int dim_out, float* emb, hipStream_t s);
+// out[b][i] = a[b * a_bstride + i] + c[b * c_bstride + i]   (time embedding + class embedding rows, unet2d_oai.py:623)
+const char* launch_add_rows(float* out, const float* a, int a_bstride, const float* c, int c_bstride, int B, int n, hipStream_t s);
 // dst row (which * heads + h) * d + c  <-  src row (h * 3 + which) * d + c   (QKVAttentionLegacy :338-340 -> the q | k | v layout of
 // launch_attention); cols floats per row
 const char* launch_permute_qkv_rows(const float* src, float* dst, int heads, int d, int cols, hipStream_t s);

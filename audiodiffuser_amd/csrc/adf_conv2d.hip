@@ -774,6 +774,15 @@ const char* launch_adm_time_embed(const float* t, int t_stride, int nb, int mc, 
     return C2_LAUNCH_CHECK("adm_time_embed");
 }
 
+__global__ void __launch_bounds__(256) add_rows_kernel(float* __restrict__ out, const float* __restrict__ a, int a_bs, const float* __restrict__ c, int c_bs, int n) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[(size_t)b * n + i] = a[(size_t)b * a_bs + i] + c[(size_t)b * c_bs + i];
+}
+const char* launch_add_rows(float* out, const float* a, int a_bstride, const float* c, int c_bstride, int B, int n, hipStream_t s) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3(ceil_div(n, 256), B), dim3(256), 0, s, out, a, a_bstride, c, c_bstride, n);
+    return C2_LAUNCH_CHECK("add_rows");
+}
+
 __global__ void __launch_bounds__(256) permute_qkv_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int heads, int d, int cols) {
     const long long total = (long long)3 * heads * d * cols;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {

@@ -103,7 +103,7 @@ typedef struct adf_adm_config {
     int32_t n_mult; int32_t channel_mult[ADF_ADM_MAX_LEVELS];
     int32_t n_attention_ds; int32_t attention_ds[ADF_ADM_MAX_LEVELS];
     int32_t conv_resample, num_heads, num_head_channels, use_scale_shift_norm, resblock_updown, use_new_attention_order;
-    int32_t num_classes;                    /* 0 = unconditional (class-conditional nets are not on the device yet) */
+    int32_t num_classes;                    /* 0 = unconditional; > 0: LabelEmbedder + adf_set_condition (labels, guidance), as for adf_create */
     int32_t dtype;
 } adf_adm_config;
 
@@ -111,8 +111,8 @@ typedef struct adf_handle adf_handle;
 
 int adf_create(const adf_net_config* cfg, adf_handle** out);
 /* A UNetModel (ADM) handle: x / out of adf_net_forward, adf_denoise, adf_sampler_run are [B][C][H][W] fp32 with L = H * W, the
- * shape given by adf_set_image_shape before the call.  On the device: the configuration of BASELINE config 4 (scale-shift norm,
- * conv resampling, no resblock up/down, unconditional), either attention order.  Debug taps: "input_blocks.<i>", "middle_block",
+ * shape given by adf_set_image_shape before the call.  On the device: scale-shift norm, conv resampling, no resblock up/down, either
+ * attention order, unconditional (BASELINE config 4) or class-conditional.  Debug taps: "input_blocks.<i>", "middle_block",
  * "output_blocks.<i>" (the outputs of the reference's blocks). */
 int adf_adm_create(const adf_adm_config* cfg, adf_handle** out);
 int adf_set_image_shape(adf_handle* h, int H, int W);

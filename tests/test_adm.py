@@ -48,7 +48,7 @@ def test_plugin_state_dict_contract_and_refusals():
     assert float(sd["out.2.weight"].abs().max()) == 0.0 and float(sd["middle_block.1.proj_out.weight"].abs().max()) == 0.0   # zero_module
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 1, 16, 32), torch.zeros(1))
-    for kw in ({"num_classes": 4}, {"resblock_updown": True}, {"use_scale_shift_norm": False}, {"conv_resample": False}):
+    for kw in ({"class_embed_dim": 8}, {"resblock_updown": True}, {"use_scale_shift_norm": False}, {"conv_resample": False}):
         with pytest.raises(NotImplementedError):
             A.UNetModel(**kw)
     assert C.sizeof(_lib.AdfAdmConfig) == 4 * (4 + 1 + 8 + 1 + 8 + 8)
@@ -217,3 +217,75 @@ def test_unipc_sampler_on_a_1d_waveform_state_vs_oracle():
         ref = S.unipc_sampler(noise, E.make_denoiser(w, cfg, 0.2), sig, 12, order=3, log_time_spacing=True)
     y = A.UniPCSampler(num_steps=12, order=3)(noise.cuda(), fn=A.EluDiffusion(sigma_data=0.2).denoise_fn, net=net.cuda(), sigmas=sig).cpu()
     assert rel(y, ref) < 2e-4, rel(y, ref)
+
+
+def _cls_cfg():
+    return A.ADMConfig(**{**A.config_c4_small().to_kwargs(), "num_classes": 5, "use_new_attention_order": True, "num_head_channels": 16})
+
+
+@pytest.mark.gpu
+def test_class_conditional_forward_vs_reference_golden(gold):
+    """UNetModel(num_classes=...) (the shipped diffunet_complex_oai_sc09_cfg.yaml setting): labels kept (cond_drop_prob 0) and dropped (1) against
+    the REFERENCE's outputs (fixture 'cls_new': class-conditional + new attention order + per-head width 16)."""
+    cfg = _cls_cfg()
+    net, _ = make(cfg)
+    net = net.cuda()
+    x, t, cl = T(gold["adm_cls_new_x"]), T(gold["adm_cls_new_t"]), T(gold["adm_cls_new_classes"])
+    y = net(x.cuda(), t.cuda(), classes=cl.cuda(), cond_drop_prob=0.0).cpu()
+    assert rel(y, T(gold["adm_cls_new_y"])) < FP32_TIGHT
+    y0 = net(x.cuda(), t.cuda(), classes=cl.cuda(), cond_drop_prob=1.0).cpu()
+    assert rel(y0, T(gold["adm_cls_new_y_null"])) < FP32_TIGHT
+    with pytest.raises(AssertionError):
+        net(x.cuda(), t.cuda())
+    with pytest.raises(IndexError):
+        net(x.cuda(), t.cuda(), classes=torch.tensor([1, 9]).cuda())
+
+
+@pytest.mark.gpu
+def test_class_conditional_guidance_denoise_and_adpm2_sampler_vs_oracle():
+    """Classifier-free guidance (cond_scale 4, the shipped value) through denoise_fn and the module's default sampler (ADPM2, ancestral noise injected),
+    eager and graph-replayed, against the oracle's wrapper + loop."""
+    from oracle import edm as E, samplers as S
+    cfg = _cls_cfg()
+    net, w = make(cfg)
+    net = net.cuda()
+    diff = A.EluDiffusion(sigma_data=0.2)
+    g = torch.Generator().manual_seed(31)
+    x, cl = torch.randn(2, 1, 16, 32, generator=g), torch.tensor([3, 0])
+
+    def net_o(xi, ti, cond_drop_prob=0.0):
+        return O.unet2d_forward(w, cfg, xi, ti, classes=cl, cond_drop_prob=cond_drop_prob)
+
+    fn_o = lambda xx, sigma=None, sigmas=None: E.denoise(net_o, xx, 0.2, sigma=sigma, sigmas=sigmas, cond_scale=4.0)
+    with torch.no_grad():
+        d = diff.denoise_fn(x.cuda() * 2.0, net=net, inference=True, cond_scale=4.0, sigma=2.0, classes=cl.cuda()).cpu()
+        assert rel(d, fn_o(x * 2.0, sigma=2.0)) < FP32_TIGHT
+        sig = A.KarrasSchedule(0.001, 30.0, 9.0, 8)()
+        draws = torch.randn(7, 2, 1, 16, 32, generator=g)
+        ref = S.adpm2_sampler(x, fn_o, sig, 8, rho=1.0, injected_noise=draws)
+        for use_graph in (False, True):
+            smp = A.ADPM2Sampler(rho=1.0, num_steps=8, cond_scale=4.0, use_graph=use_graph)
+            y = smp(x.cuda(), fn=diff.denoise_fn, net=net, sigmas=sig, classes=cl.cuda(), injected_noise=draws.cuda()).cpu()
+            assert rel(y, ref) < 2e-4, (use_graph, rel(y, ref))
+
+
+@pytest.mark.gpu
+def test_two_channel_complex_stft_layout_vs_oracle():
+    """The shipped pipeline's tensor layout (diffunet_complex_oai_sc09_cfg.yaml: real / imaginary STFT planes = 2 input and 2 output channels, 10
+    classes, guidance) on the small net at 2 x 32 x 64: the first / last conv with more than one channel, labels, a guided denoise."""
+    from oracle import edm as E
+    cfg = A.ADMConfig(**{**A.config_c4_small().to_kwargs(), "in_channels": 2, "out_channels": 2, "num_classes": 10})
+    net, w = make(cfg, seed=13)
+    net = net.cuda()
+    g = torch.Generator().manual_seed(14)
+    x, t, cl = torch.randn(3, 2, 32, 64, generator=g), torch.tensor([0.4, -0.9, 0.0]), torch.tensor([9, 0, 4])
+    with torch.no_grad():
+        ref = O.unet2d_forward(w, cfg, x, t, classes=cl)
+    y = net(x.cuda(), t.cuda(), classes=cl.cuda()).cpu()
+    assert y.shape == x.shape and rel(y, ref) < FP32_TIGHT
+    diff = A.EluDiffusion(sigma_data=0.2)
+    net_o = lambda xi, ti, cond_drop_prob=0.0: O.unet2d_forward(w, cfg, xi, ti, classes=cl, cond_drop_prob=cond_drop_prob)
+    with torch.no_grad():
+        d = diff.denoise_fn(x.cuda(), net=net, inference=True, cond_scale=4.0, sigmas=torch.tensor([0.5, 3.0, 20.0]).cuda(), classes=cl.cuda()).cpu()
+        refd = E.denoise(net_o, x, 0.2, sigmas=torch.tensor([0.5, 3.0, 20.0]), cond_scale=4.0)
+    assert rel(d, refd) < FP32_TIGHT
