@@ -623,6 +623,7 @@ __global__ void __launch_bounds__(256) to_in_rows_kernel(const float* __restrict
         for (int e = 0; e < EPC; ++e) wr[k][e] = w[(size_t)(cc * EPC + e) * WL + k];
     __syncthreads();
     const int shift = 4 - pad;                      // x[m * STRIDE + k - pad] sits at xs[(m - m0) * STRIDE + k + shift]
+#pragma unroll 4
     for (int ml = rsub; ml < ROWS && m0 + ml < Lo; ml += rpi) {
         float acc[EPC];
 #pragma unroll
@@ -762,6 +763,11 @@ __global__ void __launch_bounds__(256) to_out_mfma_kernel(const bf16_t* __restri
     const int i0 = blockIdx.x * R - halo;
     const int nrows = R + 2 * halo;
     const int ntile = (nrows + 31) / 32;
+    // nf == 64 (the benched nets): the 32 rows of a tile are read as four fully coalesced 1 KB pieces (8 rows x 128 bytes per wave
+    // instruction) into a wave-private LDS tile and the A fragments come from there; the direct form below issues 64 separate 16-byte
+    // requests at a 128-byte stride per instruction (33 us per launch at B = 64)
+    const bool staged = nf == 64;
+    char* const tl = (char*)(P + (size_t)ntile * 32 * wl) + wave * (32 * 144);
     for (int t = wave; t < ntile; t += 4) {
         const int i = i0 + t * 32 + r;                       // this lane's feature row (A operand row)
         const int ic = i < 0 ? 0 : (i >= Lh ? Lh - 1 : i);   // clamped: out-of-range rows are masked below
@@ -769,11 +775,31 @@ __global__ void __launch_bounds__(256) to_out_mfma_kernel(const bf16_t* __restri
         to_f32x16_t acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if (staged) {
+            u32x4_t rv[4];
 #pragma unroll
-        for (int ks = 0; ks < MAXKS; ++ks) {
-            if (ks < ksteps) {
-                const to_bf16x8_t af = __builtin_bit_cast(to_bf16x8_t, *(const u32x4_t*)(row + ks * 16));
+            for (int q = 0; q < 4; ++q) {
+                const int rr = q * 8 + (lane >> 3);
+                const int ii = i0 + t * 32 + rr;
+                const int icc = ii < 0 ? 0 : (ii >= Lh ? Lh - 1 : ii);
+                rv[q] = *(const u32x4_t*)(h + ((size_t)b * Lh + icc) * nf + (lane & 7) * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(u32x4_t*)(tl + (q * 8 + (lane >> 3)) * 144 + (lane & 7) * 16) = rv[q];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const to_bf16x8_t af = *(const to_bf16x8_t*)(tl + r * 144 + (ks * 2 + hh) * 16);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[ks], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();                 // the tile is rewritten in the next trip
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < MAXKS; ++ks) {
+                if (ks < ksteps) {
+                    const to_bf16x8_t af = __builtin_bit_cast(to_bf16x8_t, *(const u32x4_t*)(row + ks * 16));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[ks], acc, 0, 0, 0);
+                }
             }
         }
         if (r < wl) {
@@ -818,7 +844,7 @@ const char* launch_to_out(const void* h, const float* w, float* out, int bf16, i
     const int halo = (wl + stride - 1) / stride;
     dim3 grid(ceil_div(Lh, 256), B, out_ch);
     if (bf16 && nf % 16 == 0 && nf <= 128) {
-        const size_t lds = (size_t)round_up(256 + 2 * halo, 32) * wl * sizeof(float);
+        const size_t lds = (size_t)round_up(256 + 2 * halo, 32) * wl * sizeof(float) + 4 * 32 * 144;      // P + one staging tile per wave
         hipLaunchKernelGGL(to_out_mfma_kernel, grid, dim3(256), lds, s, (const bf16_t*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
         return ADF_LAUNCH_CHECK("to_out_mfma");
     }
