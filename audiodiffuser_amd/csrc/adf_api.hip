@@ -85,6 +85,7 @@ struct AdmW {
     float *in_w = nullptr, *in_b = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
     float *out_gw = nullptr, *out_gb = nullptr, *out_w = nullptr, *out_b = nullptr;
     int input_ch = 0, final_ch = 0;
+    int fg = 4;                          // channels per fine statistics group: gcd of every GroupNorm group size of the net (incl. the skip concats)
 };
 
 struct WnW {
@@ -960,6 +961,15 @@ int adm_build_weights(adf_handle* h) {
     }
     a.final_ch = ch;
     if (a.final_ch != a.input_ch) return fail(h, "UNetModel: the last level's width must equal the first's (out conv, unet2d_oai.py:599)");
+    {
+        auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+        int g = a.final_ch / 32;
+        for (const AdmRes& r : a.res) { g = gcd(g, r.cin / 32); g = gcd(g, r.cout / 32); }
+        for (const AdmAttn& t : a.attn) g = gcd(g, t.c / 32);
+        for (int sc : a.skip_ch) g = gcd(g, sc);       // a concat splits at the skip's width
+        a.fg = g < 1 ? 1 : (g > 4 ? 4 : g);
+        while (128 % a.fg) --a.fg;
+    }
     // pass 2: registry, in the module's registration order
     Registrar R{h};
     h->film_w = (float*)dalloc(h, (size_t)h->film_total * ted * 4);
@@ -1056,40 +1066,55 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         W.check(launch_adm_time_embed(io.t, io.t_stride, io.nb, c.model_channels, a.t_w1, a.t_b1, a.t_w2, a.t_b2, ted, p->temb, s));
         W.check(launch_film(p->temb, ted, h->film_w, ted, 0, h->film_b, p->film, io.nb, h->film_total, s));
     }
-    struct T2 { Act t; int H, W; double* st = nullptr; };     // st: GroupNorm statistics of the tensor, when its producer reduced them
-    // GroupNorm32 (:10-21) (+ scale-shift, :262-267) of a tensor folded to the per-(sample, channel) table a conv prologue reads
-    auto gn_table = [&](const T2& x, const float* gamma, const float* beta, const float* fl) -> float* {
-        double* st = x.st ? x.st : W.alloc_stats();
-        float* ab = (float*)W.alloc((size_t)B * x.t.C * 2 * 4);
+    // st: FINE GroupNorm statistics of the tensor ([B][C / fg][2]), when its producer reduced them; t1 / st1: the second source of a virtual
+    // concat (the skip of an output block, unet2d_oai.py:629: never materialised -- convs and the GroupNorm table read both sources)
+    struct T2 { Act t; int H, W; double* st = nullptr; Act t1; double* st1 = nullptr; };
+    const int fg = a.fg;
+    auto alloc_fine = [&](int C) -> double* {
+        const size_t bytes = ((size_t)B * (C / fg) * 2 * sizeof(double) + 255) & ~(size_t)255;
+        const size_t off = p->stats_off;
+        p->stats_off += bytes;
+        if (p->dry) return (double*)(uintptr_t)(off + 256);
+        if (p->stats_off > p->stats_bytes) { W.check("stats arena overflow"); return nullptr; }
+        return (double*)(p->stats + off);
+    };
+    auto ensure_stats = [&](const Act& t, double*& st) {
+        if (st) return;
+        st = alloc_fine(t.C);
+        if (W.live()) W.check(launch_gn_stats_any(t.p, h->bf16, B, t.L, t.C, t.C / fg, st, s));
+    };
+    // GroupNorm32 (:10-21) (+ scale-shift, :262-267) of a tensor (or a virtual concat) folded to the per-(sample, channel) table a conv prologue reads
+    auto gn_table = [&](T2& x, const float* gamma, const float* beta, const float* fl) -> float* {
+        ensure_stats(x.t, x.st);
+        if (x.t1.p || x.t1.C) ensure_stats(x.t1, x.st1);
+        const int ctot = x.t.C + x.t1.C;
+        float* ab = (float*)W.alloc((size_t)B * ctot * 2 * 4);
         if (W.live()) {
-            if (!x.st) W.check(launch_gn_stats_any(x.t.p, h->bf16, B, x.t.L, x.t.C, 32, st, s));
-            GnFinalizeArgs g;
+            GnFineArgs g;
             memset(&g, 0, sizeof(g));
-            g.stats0 = st; g.c0 = x.t.C; g.c1 = 0; g.L = x.t.L; g.G = 32; g.B = B; g.scale1 = 1.f; g.eps = 1e-5f;
+            g.stats0 = x.st; g.stats1 = x.st1; g.c0 = x.t.C; g.c1 = x.t1.C; g.L = x.t.L; g.G = 32; g.B = B; g.fg = fg; g.eps = 1e-5f;
             g.gamma = gamma; g.beta = beta; g.film = fl; g.film_bstride = film_bs; g.ab = ab;
-            W.check(launch_gn_finalize(g, s));
+            W.check(launch_gn_finalize_fine(g, s));
         }
         return ab;
     };
-    // stats: also reduce the GroupNorm statistics of the output in the epilogue (where a GroupNorm reads this tensor next)
+    // stats: also reduce the (fine) GroupNorm statistics of the output in the epilogue (where a GroupNorm reads this tensor next)
     auto conv = [&](const T2& x, const ConvW& w, const float* ab, int act, int mode, const void* res, bool stats) -> T2 {
         T2 y;
-        const int gsz = w.cout / 32;
-        if (stats && w.cout % 32 == 0 && gsz >= 1 && 128 % gsz == 0 && (w.cout <= 128 || w.cout % 128 == 0)) y.st = W.alloc_stats();
+        if (stats && w.cout % fg == 0 && (w.cout <= 128 || w.cout % 128 == 0)) y.st = alloc_fine(w.cout);
         y.H = mode == 1 ? x.H * 2 : (mode == 2 ? x.H / 2 : x.H);
         y.W = mode == 1 ? x.W * 2 : (mode == 2 ? x.W / 2 : x.W);
         y.t = W.new_act(w.cout, y.H * y.W);
         if (W.live()) {
             Conv2dArgs g;
-            g.x = x.t.p; g.ab = ab; g.act = act; g.B = B; g.H = y.H; g.W = y.W; g.cin = x.t.C; g.cout = w.cout; g.n_pad = w.n_pad;
+            g.x = x.t.p; g.x1 = x.t1.C ? x.t1.p : nullptr; g.c0 = x.t.C;
+            g.ab = ab; g.act = act; g.B = B; g.H = y.H; g.W = y.W; g.cin = x.t.C + x.t1.C; g.cout = w.cout; g.n_pad = w.n_pad;
             g.taps = w.taps; g.mode = mode; g.w = w.w; g.nchunk = w.nchunk; g.bias = w.bias; g.res = res; g.out = y.t.p;
-            g.stats = y.st; g.stats_groups = 32;
+            g.stats = y.st; g.stats_groups = w.cout / fg;
             W.check(launch_conv2d(g, h->bf16, s));
         }
         return y;
     };
-    // every stored tensor is recorded for the parity tests: "<block>.<j>" = output of the block's layer j, "<block>.<j>.h1" = a ResBlock's
-    // first conv, "<block>.<j>.skip" its 1x1 skip conv, "<block>.<j>.xn / .qkv / .att" the attention block's internals
     auto run = [&](const std::vector<AdmLayer>& ls, T2 x, const std::string& bname) -> T2 {
         int lj = -1;
         for (const AdmLayer& l : ls) {
@@ -1125,7 +1150,7 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
                 x = conv(att, t.proj, nullptr, 0, 0, xn.t.p, true);    // the residual is the NORMALISED input (:318-322)
                 W.tap(ln, x.t);
             } else {
-                x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr, l.kind == 3);
+                x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr, true);
                 W.tap(ln, x.t);
             }
         }
@@ -1142,9 +1167,9 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     W.tap("middle_block", x.t);
     for (size_t i = 0; i < a.output_blocks.size() && !W.bad; ++i) {
         const T2 sk = hs.back(); hs.pop_back();
-        T2 cat; cat.H = x.H; cat.W = x.W; cat.t = W.new_act(x.t.C + sk.t.C, x.t.L);
         if (sk.H != x.H || sk.W != x.W) { W.check("UNetModel: skip shape mismatch"); break; }
-        if (W.live()) W.check(launch_concat2(x.t.p, sk.t.p, x.t.C, sk.t.C, (long long)B * x.t.L, cat.t.p, h->bf16, s));
+        T2 cat = x;                                                    // [x ; skip] along channels, by reference
+        cat.t1 = sk.t; cat.st1 = sk.st;
         x = run(a.output_blocks[i], cat, "output_blocks." + std::to_string(i));
         W.tap("output_blocks." + std::to_string(i), x.t);
     }

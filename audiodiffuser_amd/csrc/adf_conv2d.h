@@ -15,8 +15,10 @@ namespace adf {
 //       zero padding is applied AFTER f (the reference pads the activated tensor); ab null = raw input
 //   src: mode 0 same size (pad 1 for 3x3); mode 1 nearest x2 upsampling of the input fused (Upsample :122-127: the conv reads pixel
 //        ((y + dy - 1) >> 1, (x + dx - 1) >> 1) of an (H/2) x (W/2) input); mode 2 stride 2 (Downsample :146-158: input is 2H x 2W)
+//   two sources: x holds channels [0, c0), x1 (optional) channels [c0, cin) of the same pixels -- the skip concat of the output blocks (:629) is
+//   never materialised (c0 a multiple of the 128-byte K chunk); the prologue table covers the concatenated channels
 struct Conv2dArgs {
-    const void* x; const float* ab; int act;
+    const void* x; const void* x1; int c0; const float* ab; int act;
     int B, H, W;            // OUTPUT height / width
     int cin, cout, n_pad;
     int taps;               // 9 (3x3) or 1
@@ -42,6 +44,15 @@ const char* launch_conv2d_out(const void* h, const float* ab, const float* w, co
 const char* launch_concat2(const void* s0, const void* s1, int c0, int c1, long long rows, void* out, int bf16, hipStream_t s);
 // GroupNorm statistics of a channels-last tensor for any C that is a multiple of a 16-byte chunk: stats[b][g][2] += (sum, sumsq)
 const char* launch_gn_stats_any(const void* x, int bf16, int B, int L, int C, int G, double* stats, hipStream_t s);
+// GroupNorm32 (+ scale-shift) of the (virtual) concat [x0 (c0) ; x1 (c1)] folded to the per-(sample, channel) table ab[b][c0 + c1][2], from
+// FINE statistics of each source: stats[b][c / fg][2] = (sum, sumsq) over fg consecutive channels (what the conv epilogues emit; fg = the greatest
+// common divisor of every group size of the net: 4 for the config-4 net).  A group of the concat may straddle the two sources (768 / 32 = 24 channels
+// per group against c0 = 512): any range that is a multiple of fg channels can be summed.
+struct GnFineArgs {
+    const double* stats0; const double* stats1; int c0, c1, L, G, B, fg; float eps;      // fg = channels per fine statistics group
+    const float* gamma; const float* beta; const float* film; int film_bstride; float* ab;
+};
+const char* launch_gn_finalize_fine(const GnFineArgs& a, hipStream_t s);
 // timestep_embedding (:31-49): cos | sin features of t[b * t_stride] -> Linear -> SiLU -> Linear (time_embed :455-459): emb[b][dim_out]
 const char* launch_adm_time_embed(const float* t, int t_stride, int nb, int mc, const float* w1, const float* b1, const float* w2,
                                   const float* b2, int dim_out, float* emb, hipStream_t s);

@@ -169,8 +169,10 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
                 sy = a.mode == 1 ? oy >> 1 : oy; sx = a.mode == 1 ? ox >> 1 : ox;
             }
             va[k] = ok;
-            const size_t off = ok ? (((size_t)pb[k] * Hin + sy) * Win + sx) * a.cin + (size_t)ck * KC + c16 * EPC : 0;
-            ra[k] = *(const u32x4_t*)(xg + off);
+            const bool s1 = ck * KC >= a.c0;                              // uniform: this chunk comes from the second source
+            const int cs = s1 ? a.cin - a.c0 : a.c0, cb = s1 ? ck * KC - a.c0 : ck * KC;
+            const size_t off = ok ? (((size_t)pb[k] * Hin + sy) * Win + sx) * cs + (size_t)cb + c16 * EPC : 0;
+            ra[k] = *(const u32x4_t*)((s1 ? (const T*)a.x1 : xg) + off);
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
@@ -305,7 +307,8 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
     const int ty0 = (bid % tiles_y) * TH;
     const int b = bid / tiles_y;
     const int n0 = blockIdx.y * TN;
-    const T* const xg = (const T*)a.x + (size_t)b * a.H * a.W * a.cin;
+    const T* const xg = (const T*)a.x + (size_t)b * a.H * a.W * a.c0;
+    const T* const xg1 = a.x1 ? (const T*)a.x1 + (size_t)b * a.H * a.W * (a.cin - a.c0) : nullptr;
     const char* const wg = (const char*)a.w;
 #ifdef ADF_C2_STAMP
     const bool stamped = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
@@ -318,19 +321,22 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
 
     // halo pieces of this thread: piece ids tid + k NT over HR * 8 pieces; (pixel offset, validity) are fixed for the whole kernel
     constexpr int NHP = (HR * 8 + NT - 1) / NT;
-    int hoff[NHP];                                     // element offset of the halo pixel's channel 0, or -1 = outside the image / no piece
+    int hoff[NHP];                                     // pixel index of the halo piece inside the image, or -1 = outside the image / no piece
 #pragma unroll
     for (int k = 0; k < NHP; ++k) {
         const int id = tid + k * NT;
         const int row = id >> 3;
         const int hy = row / (TW + 2), hx = row - hy * (TW + 2);
         const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-        hoff[k] = (id < HR * 8 && y >= 0 && y < a.H && x >= 0 && x < a.W) ? (y * a.W + x) * a.cin + (id & 7) * EPC : -1;
+        hoff[k] = (id < HR * 8 && y >= 0 && y < a.H && x >= 0 && x < a.W) ? y * a.W + x : -1;        // pixel index; the channel stride depends on the source
     }
     u32x4_t ra[NHP], rw[2];
     auto load_a = [&](int ck) __attribute__((always_inline)) {
+        const bool s1 = ck * KC >= a.c0;                                  // uniform
+        const int cs = s1 ? a.cin - a.c0 : a.c0, cb = (s1 ? ck * KC - a.c0 : ck * KC) + (tid & 7) * EPC;
+        const T* const src = s1 ? xg1 : xg;
 #pragma unroll
-        for (int k = 0; k < NHP; ++k) ra[k] = *(const u32x4_t*)(xg + (hoff[k] >= 0 ? hoff[k] + ck * KC : 0));
+        for (int k = 0; k < NHP; ++k) ra[k] = *(const u32x4_t*)(src + (hoff[k] >= 0 ? hoff[k] * cs + cb : 0));
     };
     auto store_a = [&](int ck) __attribute__((always_inline)) {
         char* const st = ldsA;
@@ -502,11 +508,14 @@ static const char* launch_conv2d_tile(const Conv2dArgs& a, hipStream_t s) {
     return C2_LAUNCH_CHECK("conv2d_tile");
 }
 
+static inline bool NT_OK(const Conv2dArgs&) { return true; }
+
 const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     const int kc = bf16 ? 64 : 32;
     if (a.taps != 9 && a.taps != 1) return "conv2d: taps must be 9 or 1";
     if (a.taps == 1 && a.mode != 0) return "conv2d: a 1x1 conv has no resampling mode";
     if (a.cin % kc || a.cin > 1024) return "conv2d: input channels must be a multiple of the 128-byte K chunk, at most 1024";
+    if (a.c0 < 1 || a.c0 > a.cin || a.c0 % kc || (a.c0 < a.cin) != (a.x1 != nullptr)) return "conv2d: bad source split";
     if (a.nchunk * kc != a.cin) return "conv2d: packed weight chunk count does not match the input channels";
     if (a.cout % (bf16 ? 8 : 4)) return "conv2d: output channels must be a multiple of a 16-byte piece";
     if (a.stats) {
@@ -519,7 +528,7 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     const unsigned ny = (unsigned)ceil_div(a.cout, 128);
     // same-size 3x3: spatial tiles (the halo staged once per chunk serves all nine taps); route switch for the parity tests
     static const int tile_route = adf_route_switch("ADF_CONV2D_TILE", 1);
-    if (tile_route && a.taps == 9 && a.mode == 0 && a.W % 32 == 0 && (long long)a.H * a.W * a.cin < (1ll << 31)) {
+    if (tile_route && a.taps == 9 && a.mode == 0 && a.W % 32 == 0 && (long long)a.H * a.W * a.cin < (1ll << 31) && NT_OK(a)) {
         // a workgroup re-reads every weight slab from L2: at 128 pixels per workgroup that stream (16 KB per iteration against 64 MFMAs) runs at
         // the L2 -> CU rate and bounds the kernel; 256 pixels per workgroup halve it
         static const int big = adf_route_switch("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
@@ -738,6 +747,38 @@ const char* launch_gn_stats_any(const void* x, int bf16, int B, int L, int C, in
     if (bf16) hipLaunchKernelGGL(gn_stats_any_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, L, C, G, rows_per_block, stats);
     else hipLaunchKernelGGL(gn_stats_any_kernel<float>, grid, dim3(256), lds, s, (const float*)x, L, C, G, rows_per_block, stats);
     return C2_LAUNCH_CHECK("gn_stats_any");
+}
+
+__global__ void __launch_bounds__(256) gn_finalize_fine_kernel(const GnFineArgs a) {
+    const int b = blockIdx.x, ctot = a.c0 + a.c1, gs = ctot / a.G;
+    for (int c = threadIdx.x; c < ctot; c += 256) {
+        const int g = c / gs;
+        double sum = 0.0, sq = 0.0;
+        for (int k = g * gs / a.fg; k < (g + 1) * gs / a.fg; ++k) {     // fine groups of fg channels; a group may straddle the two sources
+            const double* st = k * a.fg < a.c0 ? a.stats0 + ((size_t)b * (a.c0 / a.fg) + k) * 2 : a.stats1 + ((size_t)b * (a.c1 / a.fg) + (k - a.c0 / a.fg)) * 2;
+            sum += st[0]; sq += st[1];
+        }
+        const double cnt = (double)a.L * (double)gs;
+        const double mean = sum / cnt;
+        double var = sq / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        float A = rstd * a.gamma[c];
+        float Bc = a.beta[c] - (float)mean * A;
+        if (a.film) {
+            const float fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f, fh = a.film[(size_t)b * a.film_bstride + ctot + c];
+            A *= fs;
+            Bc = fmaf(Bc, fs, fh);
+        }
+        float* o = a.ab + ((size_t)b * ctot + c) * 2;
+        o[0] = A; o[1] = Bc;
+    }
+}
+const char* launch_gn_finalize_fine(const GnFineArgs& a, hipStream_t s) {
+    const int ctot = a.c0 + a.c1;
+    if (a.fg < 1 || ctot % a.G || (ctot / a.G) % a.fg || a.c0 % a.fg || a.c1 % a.fg) return "gn_finalize_fine: group size and source widths must be multiples of the fine group";
+    hipLaunchKernelGGL(gn_finalize_fine_kernel, dim3(a.B), dim3(256), 0, s, a);
+    return C2_LAUNCH_CHECK("gn_finalize_fine");
 }
 
 __global__ void __launch_bounds__(256) adm_time_embed_kernel(const float* __restrict__ t, int t_stride, int mc, const float* __restrict__ w1,
