@@ -19,7 +19,7 @@ ADF_MAX_LAYERS = 12
 DTYPE_F32, DTYPE_BF16 = 0, 1
 FLAG_SEPARATE_GN_STATS = 1
 SAMPLER_EDM, SAMPLER_EDM_ALPHA, SAMPLER_DPM_MULTISTEP, SAMPLER_DPM2, SAMPLER_ADPM2 = 0, 1, 2, 3, 4
-SAMPLER_LMS, SAMPLER_DPM_SINGLESTEP, SAMPLER_DPM2M, SAMPLER_UNIPC = 5, 6, 7, 8
+SAMPLER_LMS, SAMPLER_DPM_SINGLESTEP, SAMPLER_DPM2M, SAMPLER_UNIPC, SAMPLER_ADPMPP2S = 5, 6, 7, 8, 9
 
 
 class AdfNetConfig(C.Structure):
@@ -44,6 +44,7 @@ class AdfSamplerDesc(C.Structure):
         ("s_tmin", C.c_float), ("s_tmax", C.c_float), ("s_churn", C.c_float), ("s_noise", C.c_float),
         ("use_heun", C.c_int32), ("alpha", C.c_float), ("order", C.c_int32), ("sigma_data", C.c_float),
         ("use_graph", C.c_int32), ("rho", C.c_float), ("eta", C.c_float), ("log_time_spacing", C.c_int32), ("eps_pred", C.c_int32),
+        ("reflow", C.c_int32),
     ]
 
 

@@ -1532,6 +1532,7 @@ int run_dpm2m(SamplerCtx& c, float** result) {
         float* den = D[i & 1];
         const float* old = i > 0 ? D[(i + 1) & 1] : nullptr;
         if (c.den(X, sg, den)) return 1;
+        if (d.reflow && !c.count_only && c.ck(launch_reflow(den, X, sg, c.n, c.s))) return 1;     // stochastic_sampler_edm.py:214-215
         const float t = -logf(sg), tn = -logf(sn);
         const float h = tn - t;
         const float ratio = fminf(expf(-tn), expf(-t)) / fmaxf(expf(-tn), expf(-t));
@@ -1677,6 +1678,54 @@ int run_adpm2(SamplerCtx& c, float** result) {
     return 0;
 }
 
+// ADPMPP2SSampler: stochastic_sampler_edm.py:162-178 (loop, final clamp), :117-160 (step), :29-32 (get_sigmas); fp32 scalars.  A draw is
+// consumed only by a step whose sigma_next is positive (:158): adpmpp2s_draws() counts them for the injected-noise check.
+static int adpmpp2s_draws(const float* sig, int nsig, int N) {
+    int k = 0;
+    for (int i = 0; i + 1 < N && i + 1 < nsig; ++i) k += sig[i + 1] > 0.0f;
+    return k;
+}
+int run_adpmpp2s(SamplerCtx& c, float** result) {
+    const adf_sampler_desc& d = *c.d;
+    const int N = d.num_steps;
+    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "ADPMPP2SSampler: need at least num_steps (>= 2) sigmas");
+    Plan* p = c.p;
+    float* X = c.count_only ? nullptr : p->sb[0];
+    float* XN = c.count_only ? nullptr : p->sb[1];
+    float* X2 = c.count_only ? nullptr : p->sb[3];
+    float* DEN = c.count_only ? nullptr : p->sb[5];
+    if (!c.count_only && !p->inj_stage && adpmpp2s_draws(c.sig, c.nsig, N) > 0) return fail(c.h, "ADPMPP2SSampler needs injected_noise (one draw per step with sigma_next > 0)");
+    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
+    int k = 0;
+    for (int i = 0; i + 1 < N; ++i) {
+        const float sg = c.sig[i], sn = c.sig[i + 1];
+        const float up_raw = d.eta * sqrtf(sn * sn * (sg * sg - sn * sn) / (sg * sg));
+        const float s_up = sn < up_raw ? sn : up_raw;                          // python min(sigma_next, ...)
+        const float s_down = sqrtf(sn * sn - s_up * s_up);
+        if (c.den(X, sg, DEN)) return 1;
+        if (s_down == 0.0f) {                                                  // Euler step to sigma_down (:136-140)
+            if (!c.count_only && c.ck(launch_dstep(XN, X, X, DEN, sg, s_down - sg, c.n, c.s))) return 1;
+        } else {
+            const float t = -logf(sg), tn = -logf(s_down);
+            const float h = tn - t;
+            const float sm = t + 0.5f * h;
+            const float sig_mid = expf(-sm);
+            if (!c.count_only && c.ck(launch_dpm2m(X2, X, DEN, nullptr, sig_mid / expf(-t), expm1f(-h * 0.5f), 1.f, 0.f, c.n, c.s))) return 1;
+            if (c.den(X2, sig_mid, DEN)) return 1;
+            if (!c.count_only && c.ck(launch_dpm2m(XN, X, DEN, nullptr, expf(-tn) / expf(-t), expm1f(-h), 1.f, 0.f, c.n, c.s))) return 1;
+        }
+        if (sn > 0.0f) {
+            if (!c.count_only && c.ck(launch_churn(X, XN, p->inj_stage + (size_t)k * c.n, s_up, 1.0f, c.n, c.s))) return 1;   // x + sigma_up * randn
+            ++k;
+        } else {
+            std::swap(X, XN);
+        }
+    }
+    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
+    *result = X;
+    return 0;
+}
+
 // UniPCSampler.forward (sampler_edm.py:996-1053, variant 'bh2').  Every coefficient depends on the grid only: computed on the host
 // in fp32 in the reference's order of operations (the small solves of :934, :942 by Gaussian elimination with partial pivoting, as
 // LAPACK's gesv does); one launch per predictor / corrector formula.
@@ -1803,6 +1852,7 @@ int run_sampler(SamplerCtx& c, float** result) {
         case ADF_SAMPLER_LMS: return run_lms(c, result);
         case ADF_SAMPLER_DPM2M: return run_dpm2m(c, result);
         case ADF_SAMPLER_UNIPC: return run_unipc(c, result);
+        case ADF_SAMPLER_ADPMPP2S: return run_adpmpp2s(c, result);
         default: return c.count_only ? 1 : fail(c.h, "unknown sampler kind");
     }
 }
@@ -2046,7 +2096,8 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     if (hipMemcpyAsync(p->noise_stage, noise, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "noise copy failed");
     if (injected_noise) {
         // one draw per step: the EDM sampler steps num_steps times, the DPM2 family num_steps - 1 times
-        const int ndraws = (desc->kind == ADF_SAMPLER_DPM2 || desc->kind == ADF_SAMPLER_ADPM2) ? desc->num_steps - 1 : desc->num_steps;
+        const int ndraws = desc->kind == ADF_SAMPLER_ADPMPP2S ? adpmpp2s_draws(sigmas_host, n_sigmas, desc->num_steps)
+                           : (desc->kind == ADF_SAMPLER_DPM2 || desc->kind == ADF_SAMPLER_ADPM2) ? desc->num_steps - 1 : desc->num_steps;
         const size_t need = (size_t)(ndraws > 0 ? ndraws : 0) * n;
         // the ABI carries the number of [B][C][L] draws behind the pointer: a short buffer is an error, not an over-read
         if (n_injected < ndraws)
@@ -2067,6 +2118,8 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
         return fail(h, "a sampler with s_churn > 0 needs injected_noise (pre-drawn randn_like tensors)");
     } else if (desc->kind == ADF_SAMPLER_ADPM2) {
         return fail(h, "ADPM2Sampler needs injected_noise (one pre-drawn randn_like tensor per step)");
+    } else if (desc->kind == ADF_SAMPLER_ADPMPP2S && adpmpp2s_draws(sigmas_host, n_sigmas, desc->num_steps) > 0) {
+        return fail(h, "ADPMPP2SSampler needs injected_noise (one pre-drawn randn_like tensor per step with sigma_next > 0)");
     }
     // the sigma of every denoiser evaluation of this run (host logic only), then the buffers of the per-run table -- sized
     // before any capture starts

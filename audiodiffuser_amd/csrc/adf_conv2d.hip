@@ -509,6 +509,12 @@ static const char* launch_conv2d_tile(const Conv2dArgs& a, hipStream_t s) {
 }
 
 static inline bool NT_OK(const Conv2dArgs&) { return true; }
+// ADF_C2_TRACE=1: one stderr line per conv2d launch (tools/adm_layer_table.py matches them with a kernel trace)
+static void c2_trace(const char* route, const Conv2dArgs& a) {
+    static const int on = adf_route_switch("ADF_C2_TRACE", 0);
+    if (on) fprintf(stderr, "[adf conv2d] %-6s B=%d H=%d W=%d cin=%d c0=%d cout=%d taps=%d mode=%d ab=%d act=%d res=%d stats=%d\n", route, a.B, a.H, a.W, a.cin, a.c0,
+                    a.cout, a.taps, a.mode, a.ab != nullptr, a.act, a.res != nullptr, a.stats != nullptr);
+}
 
 const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     const int kc = bf16 ? 64 : 32;
@@ -532,19 +538,21 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
         // a workgroup re-reads every weight slab from L2: at 128 pixels per workgroup that stream (16 KB per iteration against 64 MFMAs) runs at
         // the L2 -> CU rate and bounds the kernel; 256 pixels per workgroup halve it
         static const int big = adf_route_switch("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
-        if (big && a.H % 8 == 0 && px / 256 * ny >= 512) return bf16 ? launch_conv2d_tile<bf16_t, 8, 2>(a, s) : launch_conv2d_tile<float, 8, 2>(a, s);
+        if (big && a.H % 8 == 0 && px / 256 * ny >= 512) return c2_trace("t8x2", a), bf16 ? launch_conv2d_tile<bf16_t, 8, 2>(a, s) : launch_conv2d_tile<float, 8, 2>(a, s);
         static const int wr2 = adf_route_switch("ADF_CONV2D_WR2", 0);     // 64 x 64 wave tiles on four waves (A/B runs)
-        if (wr2 && a.H % 4 == 0 && px / 128 * ny >= 128) return bf16 ? launch_conv2d_tile<bf16_t, 4, 2>(a, s) : launch_conv2d_tile<float, 4, 2>(a, s);
-        if (a.H % 4 == 0 && px / 128 * ny >= 128) return bf16 ? launch_conv2d_tile<bf16_t, 4, 1>(a, s) : launch_conv2d_tile<float, 4, 1>(a, s);
-        if (a.H % 2 == 0) return bf16 ? launch_conv2d_tile<bf16_t, 2, 1>(a, s) : launch_conv2d_tile<float, 2, 1>(a, s);
+        if (wr2 && a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4x2", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 2>(a, s) : launch_conv2d_tile<float, 4, 2>(a, s);
+        if (a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 1>(a, s) : launch_conv2d_tile<float, 4, 1>(a, s);
+        if (a.H % 2 == 0) return c2_trace("t2", a), bf16 ? launch_conv2d_tile<bf16_t, 2, 1>(a, s) : launch_conv2d_tile<float, 2, 1>(a, s);
     }
     // 128-pixel tiles (each weight piece staged once per 128 pixels) when the image divides and the grid still fills the chip
     if (((long long)a.H * a.W) % 128 == 0 && px / 128 * ny >= 512) {
         const dim3 grid((unsigned)(px / 128), ny), blk(512);
+        c2_trace("g128", a);
         if (bf16) hipLaunchKernelGGL((conv2d_gemm_kernel<bf16_t, 128>), grid, blk, 0, s, a);
         else hipLaunchKernelGGL((conv2d_gemm_kernel<float, 128>), grid, blk, 0, s, a);
     } else {
         const dim3 grid((unsigned)(px / 64), ny), blk(256);
+        c2_trace("g64", a);
         if (bf16) hipLaunchKernelGGL((conv2d_gemm_kernel<bf16_t, 64>), grid, blk, 0, s, a);
         else hipLaunchKernelGGL((conv2d_gemm_kernel<float, 64>), grid, blk, 0, s, a);
     }

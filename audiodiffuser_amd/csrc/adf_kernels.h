@@ -82,6 +82,8 @@ const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, in
 // x_next = x_base + ((x_eval - den) / sigma) * dt  (DPM2 / ancestral DPM2 steps)
 // m = (x - m) / sigma in place: the noise-prediction model value of DPMSampler(x0_pred=False)
 const char* launch_eps(float* m, const float* x, float sigma, long long n, hipStream_t s);
+// m = x - m * sigma (the reflow reading of DPM2MSampler, stochastic_sampler_edm.py:214-215)
+const char* launch_reflow(float* m, const float* x, float sigma, long long n, hipStream_t s);
 // DPM2MSampler update: out = ratio*x - coef*(c1*d - c2*d_old) (d_old may be null: out = ratio*x - coef*d)
 const char* launch_dpm2m(float* out, const float* x, const float* d, const float* d_old, float ratio, float coef, float c1, float c2, long long n,
                          hipStream_t s);

@@ -1084,6 +1084,7 @@ __global__ void __launch_bounds__(256) lincomb_kernel(float* out, const float* x
 }
 // noise prediction from the denoised estimate, in place: m = (x - m) / sigma (DPMSampler.model_fn, sampler_edm.py:700-706)
 __global__ void __launch_bounds__(256) eps_kernel(float* m, const float* x, float sigma, long long n) { ADF_EW_LOOP m[i] = (x[i] - m[i]) / sigma; }
+__global__ void __launch_bounds__(256) reflow_kernel(float* m, const float* x, float sigma, long long n) { ADF_EW_LOOP m[i] = x[i] - m[i] * sigma; }
 // DPM-Solver++(2M) update (sampler_edm.py:1096-1107): out = ratio*x - coef*(c1*d - c2*d_old); first step / final sigma 0: d_old null
 __global__ void __launch_bounds__(256) dpm2m_kernel(float* out, const float* x, const float* d, const float* d_old, float ratio, float coef,
                                                     float c1, float c2, long long n) {
@@ -1138,6 +1139,10 @@ const char* launch_rk2(float* x_next, const float* x, const float* d, const floa
 const char* launch_dpm_update(float* x_out, const float* x, const DpmArgs& a, int clamp, long long n, hipStream_t st) {
     hipLaunchKernelGGL(dpm_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x_out, x, a, clamp, n);
     return ADF_LAUNCH_CHECK("dpm_update");
+}
+const char* launch_reflow(float* m, const float* x, float sigma, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(reflow_kernel, dim3(ew_grid(n)), dim3(256), 0, st, m, x, sigma, n);
+    return ADF_LAUNCH_CHECK("reflow");
 }
 const char* launch_eps(float* m, const float* x, float sigma, long long n, hipStream_t st) {
     hipLaunchKernelGGL(eps_kernel, dim3(ew_grid(n)), dim3(256), 0, st, m, x, sigma, n);

@@ -276,17 +276,20 @@ class DPMSampler(nn.Module):
 class DPM2MSampler(nn.Module):
     """'DPM-Solver++(2M) Karras' (sampler_edm.py:1056-1131).  The loop reads ``sigmas[i + 1]`` for ``i < num_steps``: the schedule
     must hold ``num_steps + 1`` entries (a final 0 returns the last denoised estimate); with the module's own N-entry schedule the
-    reference raises IndexError on its last step, and so does this class."""
+    reference raises IndexError on its last step, and so does this class.  ``reflow`` is the constructor flag of the class of the same
+    name in stochastic_sampler_edm.py:180-259 (otherwise the same recurrence): the network output is read as a velocity,
+    ``denoised = x - output * sigma`` (:214-215)."""
 
-    def __init__(self, num_steps: int = 50, cond_scale: float = 1.0, use_graph: bool = True):
+    def __init__(self, num_steps: int = 50, cond_scale: float = 1.0, reflow: bool = False, use_graph: bool = True):
         super().__init__()
-        self.num_steps, self.cond_scale, self.use_graph = num_steps, cond_scale, use_graph
+        self.num_steps, self.cond_scale, self.reflow, self.use_graph = num_steps, cond_scale, reflow, use_graph
 
     def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
         d = _lib.AdfSamplerDesc()
         d.kind, d.num_steps = _lib.SAMPLER_DPM2M, int(self.num_steps)
         d.s_tmin = d.s_tmax = d.s_churn = 0.0
         d.s_noise = 1.0
+        d.reflow = int(bool(self.reflow))
         d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, 2, sigma_data, int(self.use_graph)
         return d
 
@@ -306,6 +309,8 @@ class DPM2MSampler(nn.Module):
         for i in range(self.num_steps):
             s_last, s, s_next = sigmas[i - 1], sigmas[i], sigmas[i + 1]
             den = fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)
+            if self.reflow:
+                den = x - den * s
             t, t_next = s.log().neg(), s_next.log().neg()
             h = t_next - t
             t_min, t_max = min(t_next.neg().exp(), t.neg().exp()), max(t_next.neg().exp(), t.neg().exp())
@@ -462,6 +467,58 @@ class ADPM2Sampler(nn.Module):
             d_mid = (x_mid - fn(x_mid, net=net, sigma=s_mid, inference=True, cond_scale=self.cond_scale, **kwargs)) / s_mid
             x = x + d_mid * (s_down - s)
             x = x + (injected_noise[i] if injected_noise is not None else torch.randn_like(x)) * s_up
+        return x.clamp(-1.0, 1.0)
+
+
+class ADPMPP2SSampler(nn.Module):
+    """'DPM++ 2S a Karras', ancestral DPM-Solver++(2S) (reference: src/models/components/stochastic_sampler_edm.py:102-178):
+    ``num_steps - 1`` steps of two evaluations (one when sigma_down is 0), fresh noise of scale sigma_up after every step whose
+    sigma_next is positive -- ``injected_noise`` ([that many, B, C, L]) replaces those ``randn_like`` draws.  ``rho`` is accepted and,
+    as in the reference, never read."""
+
+    def __init__(self, rho: float = 1.0, num_steps: int = 50, cond_scale: float = 1.0, eta: float = 1.0, use_graph: bool = True):
+        super().__init__()
+        self.rho, self.num_steps, self.cond_scale, self.eta, self.use_graph = rho, num_steps, cond_scale, eta, use_graph
+
+    def _desc(self, sigma_data: float) -> "_lib.AdfSamplerDesc":
+        d = _lib.AdfSamplerDesc()
+        d.kind, d.num_steps = _lib.SAMPLER_ADPMPP2S, self.num_steps
+        d.s_tmin, d.s_tmax, d.s_churn, d.s_noise = 0.0, 3.0e38, 0.0, 1.0
+        d.use_heun, d.alpha, d.order, d.sigma_data, d.use_graph = 0, 1.0, 0, sigma_data, int(self.use_graph)
+        d.rho, d.eta = float(self.rho), float(self.eta)
+        return d
+
+    @torch.no_grad()
+    def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
+                **kwargs) -> Tensor:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs)
+        if diff is not None and noise.is_cuda:
+            x = _prep(noise)
+            hd = net.native(x.device)
+            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            n_draws = int((sigmas[1:self.num_steps].detach().cpu() > 0).sum())                 # one per step with sigma_next > 0 (:158)
+            inj = _draws(x, n_draws, injected_noise, True)
+            return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
+        # ---- interface-compatibility branch (stochastic_sampler_edm.py:29-32, :117-178) ----------------
+        x = sigmas[0] * noise
+        k = 0
+        for i in range(self.num_steps - 1):
+            s, s_next = sigmas[i], sigmas[i + 1]
+            den = fn(x, net=net, sigma=s, inference=True, cond_scale=self.cond_scale, **kwargs)
+            s_up = min(s_next, self.eta * (s_next ** 2 * (s ** 2 - s_next ** 2) / s ** 2) ** 0.5)
+            s_down = (s_next ** 2 - s_up ** 2) ** 0.5
+            if s_down == 0:
+                x = x + (x - den) / s * (s_down - s)
+            else:
+                t, t_next = s.log().neg(), s_down.log().neg()
+                h = t_next - t
+                sm = t + 0.5 * h
+                x_2 = (sm.neg().exp() / t.neg().exp()) * x - (-h * 0.5).expm1() * den
+                den_2 = fn(x_2, net=net, sigma=sm.neg().exp(), inference=True, cond_scale=self.cond_scale, **kwargs)
+                x = (t_next.neg().exp() / t.neg().exp()) * x - (-h).expm1() * den_2
+            if s_next > 0:
+                x = x + (injected_noise[k] if injected_noise is not None else torch.randn_like(x)) * s_up
+                k += 1
         return x.clamp(-1.0, 1.0)
 
 

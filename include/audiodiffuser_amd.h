@@ -69,9 +69,11 @@ typedef struct adf_net_config {
 #define ADF_SAMPLER_DPM2 3      /* DPM2Sampler ("DPM2 Karras", optional churn)   sampler_edm.py:401-493 */
 #define ADF_SAMPLER_ADPM2 4     /* ADPM2Sampler ("DPM2 a Karras", ancestral)     stochastic_sampler_edm.py:35-100 */
 #define ADF_SAMPLER_LMS 5       /* LMSSampler ("LMS Karras"), order 1..4         sampler_edm.py:1134-1190 */
-#define ADF_SAMPLER_DPM2M 7     /* DPM2MSampler ("DPM-Solver++(2M) Karras"); needs num_steps + 1 sigmas   sampler_edm.py:1056-1131 */
+#define ADF_SAMPLER_DPM2M 7     /* DPM2MSampler ("DPM-Solver++(2M) Karras"); needs num_steps + 1 sigmas   sampler_edm.py:1056-1131;
+                                   with `reflow` the class of the same name in stochastic_sampler_edm.py:180-259 */
 #define ADF_SAMPLER_UNIPC 8     /* UniPCSampler (variant bh2), order 1..3, x0 or noise prediction, both spacings   sampler_edm.py:807-1053 */
 #define ADF_SAMPLER_DPM_SINGLESTEP 6 /* DPMSampler(multisteps=False, x0_pred=True) sampler_edm.py:568-622, :769-805 */
+#define ADF_SAMPLER_ADPMPP2S 9  /* ADPMPP2SSampler ("DPM++ 2S a Karras", ancestral; one draw per step with sigma_next > 0)   stochastic_sampler_edm.py:102-178 */
 
 typedef struct adf_sampler_desc {
     int32_t kind;
@@ -85,6 +87,7 @@ typedef struct adf_sampler_desc {
     float rho, eta;      /* ADPM2 */
     int32_t log_time_spacing;  /* DPM (both kinds), UniPC: the reference's log_time_spacing flag (sampler_edm.py:518, :546-556, :824) */
     int32_t eps_pred;          /* DPM (both kinds), UniPC: 1 = the reference's x0_pred=False (noise prediction, :700-706, :841-846) */
+    int32_t reflow;            /* DPM2M: 1 = read the denoiser output as a velocity, denoised = x - output * sigma (stochastic_sampler_edm.py:214-215) */
 } adf_sampler_desc;
 
 /* Hyper-parameters of WaveNetNoise (wavenet.py:154-157) and of the ResidualGroup it builds (:120: dim_in 128, dim_mid 512,

@@ -215,15 +215,19 @@ def dpm_singlestep_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tens
     return x.clamp(-1.0, 1.0)
 
 
-def dpm2m_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int) -> torch.Tensor:
+def dpm2m_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int, reflow: bool = False) -> torch.Tensor:
     """DPM2MSampler ('DPM-Solver++(2M) Karras', sampler_edm.py:1056-1131): num_steps updates, each reading sigmas[i + 1] -- the
     schedule must hold num_steps + 1 entries (with the module's own N-entry schedule the reference raises IndexError on its last
-    step; kept).  A final sigma of 0 returns the last denoised estimate (:1098); final clamp."""
+    step; kept).  A final sigma of 0 returns the last denoised estimate (:1098); final clamp.  The class of the same name in
+    stochastic_sampler_edm.py:180-259 is the same recurrence plus ``reflow`` (:214-215: the network output read as a velocity,
+    denoised = x - output * sigma)."""
     x = sigmas[0] * noise
     old = None
     for i in range(num_steps):
         s_last, s, s_next = sigmas[i - 1], sigmas[i], sigmas[i + 1]
         den = fn(x, sigma=s)
+        if reflow:
+            den = x - den * s
         t, t_next = s.log().neg(), s_next.log().neg()
         h = t_next - t
         t_min, t_max = min(t_next.neg().exp(), t.neg().exp()), max(t_next.neg().exp(), t.neg().exp())
@@ -312,6 +316,34 @@ def adpm2_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_s
         d_mid = (x_mid - fn(x_mid, sigma=s_mid)) / s_mid
         x = x + d_mid * (s_down - s)
         x = x + (injected_noise[i] if injected_noise is not None else torch.randn_like(x)) * s_up
+    return x.clamp(-1.0, 1.0)
+
+
+def adpmpp2s_sampler(noise: torch.Tensor, fn: Callable, sigmas: torch.Tensor, num_steps: int, eta: float = 1.0,
+                      injected_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ADPMPP2SSampler ('DPM++ 2S a Karras', stochastic_sampler_edm.py:162-178 loop and final clamp, :117-160 step, :29-32
+    get_sigmas): num_steps - 1 steps of two evaluations (one when sigma_down is 0: the Euler branch :136-140), fresh noise of
+    scale sigma_up after every step whose sigma_next is positive (:158-159).  The constructor's rho is never read.
+    ``injected_noise[k]`` replaces the k-th randn_like draw (draws are only consumed by steps with sigma_next > 0)."""
+    x = sigmas[0] * noise
+    k = 0
+    for i in range(num_steps - 1):
+        s, s_next = sigmas[i], sigmas[i + 1]
+        den = fn(x, sigma=s)
+        s_up = min(s_next, eta * (s_next ** 2 * (s ** 2 - s_next ** 2) / s ** 2) ** 0.5)
+        s_down = (s_next ** 2 - s_up ** 2) ** 0.5
+        if s_down == 0:
+            x = x + (x - den) / s * (s_down - s)
+        else:
+            t, t_next = s.log().neg(), s_down.log().neg()
+            h = t_next - t
+            sm = t + 0.5 * h
+            x_2 = (sm.neg().exp() / t.neg().exp()) * x - (-h * 0.5).expm1() * den
+            den_2 = fn(x_2, sigma=sm.neg().exp())
+            x = (t_next.neg().exp() / t.neg().exp()) * x - (-h).expm1() * den_2
+        if s_next > 0:
+            x = x + (injected_noise[k] if injected_noise is not None else torch.randn_like(x)) * s_up
+            k += 1
     return x.clamp(-1.0, 1.0)
 
 

@@ -606,6 +606,35 @@ def test_dpm2_family_vs_reference_golden(golden, graph):
 
 
 @pytest.mark.parametrize("graph", [False, True])
+def test_rest_of_stochastic_sampler_file_vs_reference_golden(graph):
+    """ADPMPP2SSampler (two eta settings; a schedule ending in 0: Euler last step, one draw fewer) and DPM2MSampler(reflow=True) of
+    stochastic_sampler_edm.py against the reference's own results (oracle/gen_golden_stoch.py)."""
+    from test_oracle_golden import recorded_draws
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stoch_golden.npz"))
+    net, _ = make_net(A.config_tiny(), "fp32")
+    d = A.EluDiffusion(sigma_data=0.2)
+    noise = generate_noise(70, 2, 256).cuda()
+    sched = lambda n: A.KarrasSchedule(0.002, 80.0, 7.0, n)()
+    sig0 = torch.cat([sched(9), torch.zeros(1)])
+    for tag, eta, sg, nd in (("e1", 1.0, sched(10), 9), ("e06", 0.6, sched(10), 9), ("e1_zero", 1.0, sig0, 8)):
+        inj = recorded_draws(9400, nd, (2, 1, 256)).cuda()
+        smp = A.ADPMPP2SSampler(num_steps=10, eta=eta, use_graph=graph)
+        for _ in range(2):
+            y = smp(noise, fn=d.denoise_fn, net=net, sigmas=sg, injected_noise=inj)
+            assert rel_err(y.cpu(), T(g[f"smp_adpmpp2s_{tag}_final"])) < FP32_TOL, tag
+    with pytest.raises(_lib.AdfError):          # a short draw buffer is an error, not an over-read
+        net.native(noise.device).sampler_run(A.ADPMPP2SSampler(num_steps=10)._desc(0.2), sched(10), noise,
+                                             recorded_draws(9400, 3, (2, 1, 256)).cuda())
+    for tag, sg in (("k11", sched(11)), ("k10_zero", torch.cat([sched(10), torch.zeros(1)]))):
+        smp = A.DPM2MSampler(num_steps=10, reflow=True, use_graph=graph)
+        for _ in range(2):
+            y = smp(noise, fn=d.denoise_fn, net=net, sigmas=sg)
+            assert rel_err(y.cpu(), T(g[f"smp_dpm2m_reflow_{tag}_final"])) < FP32_TOL, tag
+    y = A.ADPMPP2SSampler(num_steps=6)(noise, fn=d.denoise_fn, net=net, sigmas=sched(6))     # draws its own noise
+    assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("graph", [False, True])
 def test_lms_and_dpm_variants_vs_reference_golden(golden, graph):
     """LMSSampler (orders 4 and 2), single-step DPM-Solver (both spacings, every order pattern, including the early stop of
     the sigma-grid mode) and the log-spaced multistep solver, against the reference's own results."""

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AdfNetConfig) == 4 * (9 + 13 + 12 * 3 + 4 + 2 + 1)
-    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 15
+    assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 16
 
 
 def test_sampler_nfe_via_abi():
@@ -63,6 +63,8 @@ def test_sampler_nfe_via_abi():
     assert nfe(A.UniPCSampler(num_steps=20, order=3, log_time_spacing=False)._desc(0.2), 20) == 19
     assert nfe(A.UniPCSampler(num_steps=20, order=4)._desc(0.2), 20) == -1
     assert nfe(A.ADPM2Sampler(num_steps=50)._desc(0.2), 50) == 2 * 49
+    assert nfe(A.ADPMPP2SSampler(num_steps=50)._desc(0.2), 50) == 2 * 49            # sigma_down > 0 on a Karras schedule: two evaluations per step
+    assert nfe(A.DPM2MSampler(num_steps=50, reflow=True)._desc(0.2), 51) == 50
 
 
 # ---- plugin surface -------------------------------------------------------------------------------
@@ -242,6 +244,14 @@ def test_dpm2_family_compat_branch_matches_oracle():
     assert torch.equal(y, S.dpm2_sampler(noise, fn_o, sig, 9, s_tmin=0.05, s_tmax=50.0, s_churn=20.0, s_noise=1.01, injected_noise=inj))
     y = A.ADPM2Sampler(rho=7.0, num_steps=9, eta=0.8)(noise, fn=mock, net=None, sigmas=sig, injected_noise=inj)
     assert torch.equal(y, S.adpm2_sampler(noise, fn_o, sig, 9, rho=7.0, eta=0.8, injected_noise=inj))
+    # the rest of stochastic_sampler_edm.py: DPM++ 2S a (also on a schedule ending in 0: Euler last step, no last draw) and DPM2M with reflow
+    for sg, nd in ((sig, 8), (torch.cat([sig[:8], torch.zeros(1)]), 7)):
+        y = A.ADPMPP2SSampler(num_steps=9, eta=0.8)(noise, fn=mock, net=None, sigmas=sg, injected_noise=inj[:nd])
+        assert torch.equal(y, S.adpmpp2s_sampler(noise, fn_o, sg, 9, eta=0.8, injected_noise=inj[:nd]))
+    sg10 = A.KarrasSchedule(0.002, 80.0, 7.0, 10)()
+    for reflow in (False, True):
+        y = A.DPM2MSampler(num_steps=9, reflow=reflow)(noise, fn=mock, net=None, sigmas=sg10)
+        assert torch.equal(y, S.dpm2m_sampler(noise, fn_o, sg10, 9, reflow=reflow))
 
 
 def test_bench_defaults_per_config():

@@ -273,6 +273,24 @@ def test_dpm2_family_with_tiny_net(golden):
             assert rel(y, T(golden[f"smp_adpm2_{tag}_final"])) < 5e-4, tag
 
 
+def test_rest_of_stochastic_sampler_file_with_tiny_net():
+    """ADPMPP2SSampler and the reflow flag of stochastic_sampler_edm.py's DPM2MSampler against the reference's results
+    (fixtures of oracle/gen_golden_stoch.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stoch_golden.npz"))
+    cfg = config_tiny()
+    fn = E.make_denoiser(generate_weights(cfg, seed=0), cfg, 0.2)
+    noise = generate_noise(70, 2, 256)
+    sig = E.karras_sigmas(0.002, 80.0, 7.0, 10)
+    sig0 = torch.cat([E.karras_sigmas(0.002, 80.0, 7.0, 9), torch.zeros(1)])
+    with torch.no_grad():
+        for tag, eta, sg, nd in (("e1", 1.0, sig, 9), ("e06", 0.6, sig, 9), ("e1_zero", 1.0, sig0, 8)):
+            y = S.adpmpp2s_sampler(noise, fn, sg, 10, eta=eta, injected_noise=recorded_draws(9400, nd, noise.shape))
+            assert rel(y, T(g[f"smp_adpmpp2s_{tag}_final"])) < 5e-4, tag
+        for tag, sg in (("k11", E.karras_sigmas(0.002, 80.0, 7.0, 11)), ("k10_zero", torch.cat([sig, torch.zeros(1)]))):
+            y = S.dpm2m_sampler(noise, fn, sg, 10, reflow=True)
+            assert rel(y, T(g[f"smp_dpm2m_reflow_{tag}_final"])) < 5e-4, tag
+
+
 LMS_DPM_CASES = [(3, True, 10), (3, True, 9), (2, True, 7), (1, True, 4), (3, False, 10), (2, False, 10)]
 
 
