@@ -116,6 +116,21 @@ def test_both_conv_routes_in_a_child_process(tile):
 
 
 @pytest.mark.gpu
+def test_ten_row_images_take_the_160_pixel_tiles():
+    """H = 10 (the 80-row mel block three levels down) at a batch that fills the chip: the 5 x 32-pixel spatial tiles, fp32 against the oracle and
+    bf16 teacher-forced against the bf16-storage oracle; the launcher's route lines prove the kernel."""
+    import json, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "gpu_adm_t5_report.py")], capture_output=True, text=True,
+                       env=dict(os.environ, ADF_C2_TRACE="1"), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sum(1 for l in r.stderr.splitlines() if l.startswith("[adf conv2d] t5 ")) >= 6, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["fp32_max_rel"] < FP32_TIGHT, rep
+    assert rep["bf16_taps"] > 15 and not rep["bf16_missing"], rep
+    assert rep["bf16_worst_conv"] < BF16_CONV_TOL and rep["bf16_worst_att"] < BF16_ATT_TOL, rep
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_config4_full_size_fp32_and_bf16(gold):
     """The BASELINE config-4 network itself (default constructor, 1 x 80 x 256): fp32 against the reference's output; bf16 against
