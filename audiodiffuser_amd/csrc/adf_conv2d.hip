@@ -153,7 +153,14 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
     }
 
     u32x4_t ra[NA], rw[NW];
-    bool va[NA];
+    bool va[NA], wok[NW];                              // weight rows past n_pad are zeroed when the slab is stored (a select behind a load is a wait behind it)
+    unsigned woff[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int row = srow + RPT * k;
+        wok[k] = n0 + row < a.n_pad;
+        woff[k] = (unsigned)((wok[k] ? n0 + row : 0) * 128 + c16 * 16);
+    }
     auto load_regs = [&](int it) __attribute__((always_inline)) {
         const int ck = it / a.taps, tap = it - ck * a.taps;
         const int dy = a.taps == 9 ? tap / 3 : 1, dx = a.taps == 9 ? tap - (tap / 3) * 3 : 1;
@@ -175,13 +182,9 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
             const size_t off = ok ? (((size_t)pb[k] * Hin + sy) * Win + sx) * cs + (size_t)cb + c16 * EPC : 0;
             ra[k] = *(const u32x4_t*)((s1 ? (const T*)a.x1 : xg) + off);
         }
+        const char* const wbase = wg + (size_t)it * a.n_pad * 128;          // packed order [chunk][tap]
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int row = srow + RPT * k;
-            const bool ok = n0 + row < a.n_pad;
-            rw[k] = *(const u32x4_t*)(wg + (((size_t)ck * a.taps + tap) * a.n_pad + (ok ? n0 + row : 0)) * 128 + c16 * 16);
-            if (!ok) rw[k] = u32x4_t{0u, 0u, 0u, 0u};
-        }
+        for (int k = 0; k < NW; ++k) rw[k] = *(const u32x4_t*)(wbase + woff[k]);
     };
     auto store_lds = [&](int it) __attribute__((always_inline)) {
         const int ck = it / a.taps;
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
             *(u32x4_t*)(st + (srow + RPT * k) * kC2Pitch + c16 * 16) = v;
         }
 #pragma unroll
-        for (int k = 0; k < NW; ++k) *(u32x4_t*)(st + (TM + srow + RPT * k) * kC2Pitch + c16 * 16) = rw[k];
+        for (int k = 0; k < NW; ++k) *(u32x4_t*)(st + (TM + srow + RPT * k) * kC2Pitch + c16 * 16) = wok[k] ? rw[k] : u32x4_t{0u, 0u, 0u, 0u};
     };
 
     c2_f32x16_t acc[2];
@@ -214,13 +217,14 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
     // one barrier per iteration: while iteration `it` computes from stage it & 1, the registers of iteration it + 1 (loaded before
-    // the MFMAs) are written to the other stage afterwards
+    // the MFMAs) are written to the other stage afterwards.  The loads are issued on every path (the last iteration fetches its own operands
+    // again into the stage nobody reads): under a condition the compiler waits for them where they are issued (see conv2d_tile_kernel)
     load_regs(0);
     __syncthreads();                                   // the prologue table is in LDS
     store_lds(0);
     __syncthreads();
     for (int it = 0; it < nit; ++it) {
-        if (it + 1 < nit) load_regs(it + 1);
+        load_regs(it + 1 < nit ? it + 1 : it);
         const char* const aRow = lds + (it & 1) * STAGE + (wm * 32 + r) * kC2Pitch;
         const char* const wRow = lds + (it & 1) * STAGE + (TM + wn * 64 + r) * kC2Pitch;
         if constexpr (kBf16) {
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
                         for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][e], fb[j][u][e], acc[j], 0, 0, 0);
             }
         }
-        if (it + 1 < nit) store_lds(it + 1);
+        store_lds(it + 1 < nit ? it + 1 : it);
         __syncthreads();
     }
 
@@ -322,8 +326,11 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
     const int ty0 = (bid % tiles_y) * TH;
     const int b = bid / tiles_y;
     const int n0 = blockIdx.y * TN;
-    const T* const xg = (const T*)a.x + (size_t)b * a.H * a.W * a.c0;
-    const T* const xg1 = a.x1 ? (const T*)a.x1 + (size_t)b * a.H * a.W * (a.cin - a.c0) : nullptr;
+    // mode 1 (nearest x2 upsampling fused): the halo keeps its OUTPUT geometry in LDS, each of its pixels is fetched from input pixel (y >> 1, x >> 1)
+    // (four halo pixels share a source pixel: the repeats are cache hits), so the taps stay row offsets into the halo
+    const int Hin = a.mode == 1 ? a.H >> 1 : a.H, Win = a.mode == 1 ? a.W >> 1 : a.W;
+    const T* const xg = (const T*)a.x + (size_t)b * Hin * Win * a.c0;
+    const T* const xg1 = a.x1 ? (const T*)a.x1 + (size_t)b * Hin * Win * (a.cin - a.c0) : nullptr;
     const char* const wg = (const char*)a.w;
 #ifdef ADF_C2_STAMP
     const bool stamped = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
@@ -343,7 +350,7 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
         const int row = id >> 3;
         const int hy = row / (TW + 2), hx = row - hy * (TW + 2);
         const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-        hoff[k] = (id < HR * 8 && y >= 0 && y < a.H && x >= 0 && x < a.W) ? y * a.W + x : -1;        // pixel index; the channel stride depends on the source
+        hoff[k] = (id < HR * 8 && y >= 0 && y < a.H && x >= 0 && x < a.W) ? (a.mode == 1 ? (y >> 1) * Win + (x >> 1) : y * a.W + x) : -1;   // source pixel index; the channel stride depends on the source
     }
     u32x4_t ra[NHP], rw[2];
     auto load_a = [&](int ck) __attribute__((always_inline)) {
@@ -572,9 +579,9 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     if (((long long)a.H * a.W) % 64) return "conv2d: H*W must be a multiple of 64";
     if (a.mode == 1 && ((a.H | a.W) & 1)) return "conv2d: upsampled output must have even height and width";
     const unsigned ny = (unsigned)ceil_div(a.cout, 128);
-    // same-size 3x3: spatial tiles (the halo staged once per chunk serves all nine taps); route switch for the parity tests
+    // same-size and upsampling 3x3: spatial tiles (the halo staged once per chunk serves all nine taps); route switch for the parity tests
     static const int tile_route = adf_route_switch("ADF_CONV2D_TILE", 1);
-    if (tile_route && a.taps == 9 && a.mode == 0 && a.W % 32 == 0 && (long long)a.H * a.W * a.cin < (1ll << 31) && NT_OK(a)) {
+    if (tile_route && a.taps == 9 && a.mode != 2 && a.W % 32 == 0 && (long long)a.H * a.W * a.cin < (1ll << 31) && NT_OK(a)) {
         // a workgroup re-reads every weight slab from L2: at 128 pixels per workgroup that stream (16 KB per iteration against 64 MFMAs) runs at
         // the L2 -> CU rate and bounds the kernel; 256 pixels per workgroup halve it
         static const int big = adf_route_switch("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
