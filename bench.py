@@ -249,12 +249,12 @@ def adm_pass_row(net, cfg, x, device, iters):
 
 
 def adm_roofline(net, cfg, x, device, dtype):
-    """First-path figure for this row: the GEMM flops of one network pass (3x3 / 1x1 convs, attention) over the pass time."""
+    """The GEMM flops of one network pass (3x3 / 1x1 convs, attention) over the pass time (per-layer figures: tools/adm_layer_table.py)."""
     row = adm_pass_row(net, cfg, x, device, 5)
     tfs = row["flops"] / (row["pass_ms"] * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv2d_gemm_kernel (implicit GEMM over channels-last pixels), whole network pass",
+    return {"bound": "mfma", "kernel": "conv2d_tile_kernel / conv2d_gemm_kernel (implicit GEMM over channels-last pixels), whole network pass",
             "definition": "multiply-add flops x 2 of every conv / projection / attention contraction of one UNetModel pass / the eager pass time (events on the launch "
-                          "stream): a per-pass figure, not a single launch; the kernel is a first correct path, not tuned yet",
+                          "stream): a per-pass figure, not a single launch (per-layer table: profiles/r02_adm_layer_table.txt)",
             "level": -1, "conv": 0, "pass_ms": row["pass_ms"], "algorithmic_flops": row["flops"], "mfma_TFLOPs": tfs, "achieved": tfs,
             "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS[dtype], "traffic": None}
 

@@ -65,4 +65,7 @@ timeout -k 10 600 python bench.py --config c4 --steps 1 --warmup 1 2>/dev/null |
 rm -rf /tmp/p6
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 bench.py --config c4 --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-precision-check > /tmp/p6.log 2>&1 || { tail -5 /tmp/p6.log; exit 1; }
 cp $(ls /tmp/p6/*/*kernel_stats.csv | head -1) $out/${tag}_bench_c4_kernel_stats.csv
+rm -rf /tmp/p7
+( cd /tmp && ADF_C2_TRACE=1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/p7 -- python3 $OLDPWD/tools/adm_pass.py 64 2> /tmp/p7.err > /dev/null ) || { tail -5 /tmp/p7.err; exit 1; }
+python3 tools/adm_layer_table.py /tmp/p7 /tmp/p7.err > $out/${tag}_adm_layer_table.txt
 ls -la $out
