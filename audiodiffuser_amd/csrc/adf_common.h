@@ -97,29 +97,48 @@ struct GnRaw {
     double sum, sq;          // statistics of the (coarse) group, summed over its stored fine groups
     float gamma, beta, fs, fh;
 };
+// EVERY load below is unconditional and independent of the others (optional tensors are read through a valid dummy pointer and discarded): a load
+// under a condition, or a select on a loaded value, makes the compiler wait `vmcnt(0)` on the spot, and the statistics -> gamma / beta -> FiLM ->
+// class FiLM chain was four to five serialised memory round trips at the head of every kernel that derives its table (ISA of conv_gemm_rb_kernel,
+// round 2).  The statistics pointer is formed as stats0 + a selected byte distance: a per-lane select between two kernel-argument pointers is
+// otherwise compiled to a load of the pointer itself from the kernarg segment -- one more dependent round trip.
+__device__ __forceinline__ const double* gn_select_ptr(bool second, const double* p0, const double* p1) {
+    // p0 + (second ? p1 - p0 : 0): arithmetic on p0 keeps the global address space (a select of two integers cast back would make flat loads)
+    long long d = (const char*)p1 - (const char*)p0;
+    asm volatile("" : "+s"(d));
+    return (const double*)((const char*)p0 + (second ? d : 0ll));
+}
 __device__ __forceinline__ GnRaw gn_affine_load(const GnFinalizeArgs& a, int b, int c) {
     const int ctot = a.c0 + a.c1;
     const int gs = ctot / a.G;
     const int cstart = (c / gs) * gs;
     const bool s1 = cstart >= a.c0;
-    const double* st = s1 ? a.stats1 : a.stats0;
+    const double* st = gn_select_ptr(s1, a.stats0, a.stats1);
     const int csrc = s1 ? a.c1 : a.c0;
     const int lc = s1 ? cstart - a.c0 : cstart;
     const int fg = csrc / a.G;                // channels per stored (fine) group
     const int g0 = lc / fg, g1 = (lc + gs + fg - 1) / fg;
     GnRaw r;
-    r.sum = 0.0; r.sq = 0.0;
-    for (int g = g0; g < g1; ++g) { r.sum += st[((size_t)b * a.G + g) * 2]; r.sq += st[((size_t)b * a.G + g) * 2 + 1]; }
-    r.gamma = a.gamma[c];
-    r.beta = a.beta[c];
+    // one or two fine groups per coarse group in every shape served (one source, or two equal ones): both loads go out together; more in a loop
+    const double* p0 = st + ((size_t)b * a.G + g0) * 2;
+    const double* p1 = g0 + 1 < g1 ? p0 + 2 : p0;
+    const double s0 = p0[0], q0 = p0[1], s1v = p1[0], q1v = p1[1];
+    const float gamma = a.gamma[c], beta = a.beta[c];
+    const bool hf = a.film != nullptr, hf2 = hf && a.film2 != nullptr;                 // uniform
+    int cd = c;                                        // opaque copy of the index: gamma[cd] through the dummy pointer must not be folded into the gamma load
+    asm volatile("" : "+v"(cd));                       // above (a copy of that register is a wait for it, and the optional loads end up behind a branch again)
+    const float* const f1 = hf ? a.film + (size_t)b * a.film_bstride : a.gamma;
+    const float* const f2 = hf2 ? a.film2 + (size_t)b * a.film2_bstride : a.gamma;
+    const float f1s = f1[cd], f1h = f1[hf ? ctot + cd : cd], f2s = f2[cd], f2h = f2[hf2 ? ctot + cd : cd];
+    r.sum = s0 + (g0 + 1 < g1 ? s1v : 0.0); r.sq = q0 + (g0 + 1 < g1 ? q1v : 0.0);
+    for (int g = g0 + 2; g < g1; ++g) { r.sum += st[((size_t)b * a.G + g) * 2]; r.sq += st[((size_t)b * a.G + g) * 2 + 1]; }
+    r.gamma = gamma;
+    r.beta = beta;
     r.fs = 1.0f; r.fh = 0.0f;
-    if (a.film) {
-        r.fs = a.film[(size_t)b * a.film_bstride + c] + 1.0f;
-        r.fh = a.film[(size_t)b * a.film_bstride + ctot + c];
-        if (a.film2) {      // class-embedding part of the FiLM projection (precomputed per sampler run)
-            r.fs += a.film2[(size_t)b * a.film2_bstride + c];
-            r.fh += a.film2[(size_t)b * a.film2_bstride + ctot + c];
-        }
+    if (hf) {
+        r.fs = f1s + 1.0f;
+        r.fh = f1h;
+        if (hf2) { r.fs += f2s; r.fh += f2h; }   // class-embedding part of the FiLM projection (precomputed per sampler run)
     }
     return r;
 }

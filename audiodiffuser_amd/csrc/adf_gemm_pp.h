@@ -128,10 +128,13 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     { int m0_, n0_; geom(0, b_first, m0_, n0_); }
     // (a, b) of one sample's input channels -> table slot: two channels per thread, the arithmetic of gn_finalize_kernel
     auto fill_table = [&](int b, int slot) __attribute__((always_inline)) {
+        // both channels' loads go out together, unconditionally (lanes past the end on a clamped index): see gn_affine_load
+        const int c_ = tid * 2 < ctot0 ? tid * 2 : 0;
+        const GnRaw r0 = gn_affine_load(a.seg[0].gn, b, c_), r1 = gn_affine_load(a.seg[0].gn, b, c_ + 1);
         if (tid * 2 < ctot0) {
             float A0, B0, A1, B1;
-            gn_affine<true>(a.seg[0].gn, b, tid * 2, A0, B0);
-            gn_affine<true>(a.seg[0].gn, b, tid * 2 + 1, A1, B1);
+            gn_affine_finish<true>(a.seg[0].gn, c_, r0, A0, B0);
+            gn_affine_finish<true>(a.seg[0].gn, c_ + 1, r1, A1, B1);
             *(f32x4_t*)(ldsTab + slot * kPpTab + tid * 16) = f32x4_t{A0, B0, A1, B1};
         }
     };
@@ -532,22 +535,28 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     };
     // bias vector and the first tile's affine table: their global loads go out first (one HBM round trip, ~3 us on a cold
     // line, that gates the block's first barrier), then the descriptors and the first DMAs, then the LDS stores
+    // (every one of them unconditional -- absent tensors through a dummy pointer, lanes past the end on a clamped index -- and the selects after
+    //  the last load: loads under conditions are waited for one by one, see gn_affine_load)
     float bias_v[(kPpMaxN + 511) / 512];
+    const bool hb0 = a.bias0 != nullptr, hb1 = a.bias1 != nullptr;                   // uniform
+    const float* const dummy_f = (const float*)a.seg[0].w;                           // always there, >= 16 KB
+    const float* const pb0 = hb0 ? a.bias0 : dummy_f;
+    const float* const pb1 = hb1 ? a.bias1 : dummy_f;
+    float b0v[(kPpMaxN + 511) / 512], b1v[(kPpMaxN + 511) / 512];
 #pragma unroll
     for (int q = 0; q < (kPpMaxN + 511) / 512; ++q) {
         const int n = tid + q * 512;
-        float bv = 0.f;
-        if (n < a.n) {
-            const int bi = n % a.bias_mod;
-            if (a.bias0) bv += a.bias0[bi];
-            if (a.bias1) bv += a.bias1[bi];
-        }
-        bias_v[q] = bv;
+        const int bi = n < a.n ? n % a.bias_mod : 0;
+        b0v[q] = pb0[hb0 ? bi : 0]; b1v[q] = pb1[hb1 ? bi : 0];
     }
-    f32x4_t tab_v = {0.f, 0.f, 0.f, 0.f};
-    if (use_tab && !gn_in && tid * 2 < ctot0) tab_v = *(const f32x4_t*)(a.seg[0].ab + ((size_t)b_first * ctot0 + tid * 2) * 2);
+    const bool tab_in = use_tab && !gn_in;                                            // uniform
+    const int c_tab = tid * 2 < ctot0 ? tid * 2 : 0;
+    const f32x4_t tab_l = *(const f32x4_t*)(tab_in ? (const float*)(a.seg[0].ab + ((size_t)b_first * ctot0 + c_tab) * 2) : dummy_f);
     GnRaw gr0 = {}, gr1 = {};                                                // statistics / gamma / beta / FiLM of this thread's two channels
-    if (gn_in && tid * 2 < ctot0) { gr0 = gn_affine_load(a.seg[0].gn, b_first, tid * 2); gr1 = gn_affine_load(a.seg[0].gn, b_first, tid * 2 + 1); }
+    if (gn_in) { gr0 = gn_affine_load(a.seg[0].gn, b_first, c_tab); gr1 = gn_affine_load(a.seg[0].gn, b_first, c_tab + 1); }
+#pragma unroll
+    for (int q = 0; q < (kPpMaxN + 511) / 512; ++q) bias_v[q] = tid + q * 512 < a.n ? (hb0 ? b0v[q] : 0.f) + (hb1 ? b1v[q] : 0.f) : 0.f;
+    const f32x4_t tab_v = tab_l;
     PpBlk dc = desc(0, 0);
     (void)issue_a(dc, 0, -1);
     issue_w(dc.w, 0);

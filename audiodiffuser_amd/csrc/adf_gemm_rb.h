@@ -211,14 +211,20 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     // (the arithmetic of gn_finalize_kernel / gn_affine<true>.  Per-wave stamps showed the two-channels-per-thread form on waves
     //  0-1 -- four dependent memory round trips -- holding the block's first barrier until 12.6 K cycles after entry, three times
     //  the landing time of the first DMAs.)
-    struct GnLoaded { double s0, q0, s1, q1; float gamma, beta, fs, fh; };
+    struct GnLoaded { double s0, q0, s1, q1; float gamma, beta, f1s, f1h, f2s, f2h; };     // raw loads: nothing is computed from them before gn_store
+    auto gn_two = [&](int c) __attribute__((always_inline)) -> bool {
+        const GnFinalizeArgs& g = a.gn;
+        const int ctot = g.c0 + g.c1, gs = ctot / g.G;
+        const bool from1 = (c / gs) * gs >= g.c0;
+        return gs > (from1 ? g.c1 : g.c0) / g.G;          // two stored (fine) groups per coarse group: two equal sources
+    };
     auto gn_load = [&](int b, int c) __attribute__((always_inline)) -> GnLoaded {
         const GnFinalizeArgs& g = a.gn;
         const int ctot = g.c0 + g.c1;
         const int gs = ctot / g.G;                         // channels per (coarse) group
         const int cstart = (c / gs) * gs;
         const bool from1 = cstart >= g.c0;
-        const double* st = from1 ? g.stats1 : g.stats0;
+        const double* st = gn_select_ptr(from1, g.stats0, g.stats1);
         const int csrc = from1 ? g.c1 : g.c0;
         const int lc = from1 ? cstart - g.c0 : cstart;
         const int fg = csrc / g.G;                         // channels per stored (fine) group: gs = fg (one source) or 2 fg (two equal sources)
@@ -226,25 +232,28 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         const bool two = gs > fg;
         const double* p0 = st + ((size_t)b * g.G + g0) * 2;
         const double* p1 = two ? p0 + 2 : p0;
+        // every load unconditional and independent (optional FiLM tensors through a valid dummy pointer), no arithmetic on a loaded value here: see
+        // gn_affine_load in adf_common.h -- the conditional form was five serialised round trips before this kernel's first DMA, and three to four
+        // in the middle of the pipeline at every change of sample
+        const bool hf = g.film != nullptr, hf2 = hf && g.film2 != nullptr;                 // uniform
+        int cd = c;                                        // opaque copy of the index, so that gamma[cd] through the dummy pointer is not folded into the
+        asm volatile("" : "+v"(cd));                       // gamma load (a wait for it)
+        const float* const f1 = hf ? g.film + (size_t)b * g.film_bstride : g.gamma;
+        const float* const f2 = hf2 ? g.film2 + (size_t)b * g.film2_bstride : g.gamma;
         GnLoaded r;
         r.s0 = p0[0]; r.q0 = p0[1]; r.s1 = p1[0]; r.q1 = p1[1];
-        if (!two) { r.s1 = 0.0; r.q1 = 0.0; }
         r.gamma = g.gamma[c]; r.beta = g.beta[c];
-        r.fs = 1.0f; r.fh = 0.0f;
-        if (g.film) {
-            r.fs = g.film[(size_t)b * g.film_bstride + c] + 1.0f;
-            r.fh = g.film[(size_t)b * g.film_bstride + ctot + c];
-            if (g.film2) {
-                r.fs += g.film2[(size_t)b * g.film2_bstride + c];
-                r.fh += g.film2[(size_t)b * g.film2_bstride + ctot + c];
-            }
-        }
+        r.f1s = f1[cd]; r.f1h = f1[hf ? ctot + cd : cd]; r.f2s = f2[cd]; r.f2h = f2[hf2 ? ctot + cd : cd];
         return r;
     };
     auto gn_store = [&](int c, const GnLoaded& v, int slot) __attribute__((always_inline)) {
+        const bool two = gn_two(c);
+        const bool hf = a.gn.film != nullptr, hf2 = hf && a.gn.film2 != nullptr;           // uniform
         GnRaw r;
-        r.sum = v.s0 + v.s1; r.sq = v.q0 + v.q1;
-        r.gamma = v.gamma; r.beta = v.beta; r.fs = v.fs; r.fh = v.fh;
+        r.sum = v.s0 + (two ? v.s1 : 0.0); r.sq = v.q0 + (two ? v.q1 : 0.0);
+        r.gamma = v.gamma; r.beta = v.beta;
+        r.fs = hf ? v.f1s + 1.0f + (hf2 ? v.f2s : 0.f) : 1.0f;
+        r.fh = hf ? v.f1h + (hf2 ? v.f2h : 0.f) : 0.0f;
         float A, Bc;
         gn_affine_finish<true>(a.gn, c, r, A, Bc);
         *(f32x2_t*)(ldsTab + slot * kPpTab + c * 8) = f32x2_t{A, Bc};
@@ -254,7 +263,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         //  are computed at kernel entry and kept -- spilled -- across the whole tile loop)
         int t1 = tid;
         asm volatile("" : "+v"(t1));
-        if (t1 < ctot0) gn_store(t1, gn_load(b, t1), slot);
+        const GnLoaded v = gn_load(b, t1 < ctot0 ? t1 : ctot0 - 1);
+        if (t1 < ctot0) gn_store(t1, v, slot);
     };
 
     // ---- prologue arithmetic on one 8-byte half (4 elements) of a chunk this lane fetched ----------------------------
@@ -568,13 +578,14 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #endif
     kstamp(11);
     // ---- start-up: bias vector, the first sample's table, first DMAs -------------------------------------------------
-    float bias_v = 0.f;
-    if (tid < a.n) {
-        if (a.bias0) bias_v += a.bias0[tid];
-        if (a.bias1) bias_v += a.bias1[tid];
-    }
+    // (all start-up loads unconditional -- absent tensors through a dummy pointer, lanes past the end on a clamped index: two bias loads and the
+    //  table loads under conditions were seven serialised round trips ahead of the first DMA)
+    const bool hb0 = a.bias0 != nullptr, hb1 = a.bias1 != nullptr;                    // uniform
+    const float* const dummy_f = (const float*)a.blk[0].w;                            // always there, >= 1 KB
+    const int bidx_l = tid < a.n ? tid : 0;
+    const float b0v = (hb0 ? a.bias0 : dummy_f)[bidx_l], b1v = (hb1 ? a.bias1 : dummy_f)[bidx_l];
     GnLoaded gl = {};
-    if (!RAW && tid < ctot0) gl = gn_load(b_first, tid);
+    if constexpr (!RAW) gl = gn_load(b_first, tid < ctot0 ? tid : ctot0 - 1);
     Blk dc = make_desc();
     advance();
     issue_a01(dc, 0u); issue_a23(dc, 0u); issue_halo(dc, 0u);
@@ -584,7 +595,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage);
     Blk d2 = make_desc();
     advance();
-    if (tid < a.n) ldsBias[tid] = bias_v;
+    if (tid < a.n) ldsBias[tid] = (hb0 ? b0v : 0.f) + (hb1 ? b1v : 0.f);
     if (!RAW && tid < ctot0) gn_store(tid, gl, 0);
     kstamp(12);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -133,24 +133,33 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
 
     prefetch(a.wr ? a.wr : a.w1, wave * 32);
     // ---- R0: parameters and the GroupNorm-1 table -> LDS; raw input rows -> bufX (for the 1x1 residual conv) ---------------
-    for (int i = tid; i < 6 * 256; i += 512) {
-        const int k = i >> 8, c = i & 255;
-        float v;
-        if (k == 0) v = a.b1[c];
-        else if (k == 1) v = a.b2[c] + (a.wr && a.br ? a.br[c] : 0.f);
-        else if (k == 2) v = a.gamma2[c];
-        else if (k == 3) v = a.beta2[c];
-        else {
-            float f = a.film ? a.film[(size_t)b * a.film_bstride + (k == 5 ? 256 : 0) + c] : 0.f;
-            if (a.film && a.film2) f += a.film2[(size_t)b * a.film2_bstride + (k == 5 ? 256 : 0) + c];
-            v = k == 4 ? f + 1.0f : f;
+    // (every parameter load unconditional and independent -- absent tensors through a dummy pointer, the half of the block that takes which vector
+    //  chosen by a wave-uniform select: as a loop with a branch per vector these were five serialised memory round trips, see gn_affine_load)
+    {
+        const bool lo = wave < 4;                                                     // uniform: threads 0..255 / 256..511
+        const int c = tid & 255;
+        const bool hbr = a.wr && a.br, hf = a.film != nullptr, hf2 = hf && a.film2 != nullptr;
+        const float* const dummy = a.b1;
+        int cd = c;                                                                   // opaque index for the dummy reads (see gn_affine_load)
+        asm volatile("" : "+v"(cd));
+        const float* const p0 = lo ? a.b1 : a.b2;
+        const float* const pbr = hbr ? a.br : dummy;
+        const float* const p1 = lo ? a.gamma2 : a.beta2;
+        const float* const pf = hf ? a.film + (size_t)b * a.film_bstride + (lo ? 0 : 256) : dummy;
+        const float* const pf2 = hf2 ? a.film2 + (size_t)b * a.film2_bstride + (lo ? 0 : 256) : dummy;
+        float v0 = p0[c], vbr = pbr[cd], v1 = p1[c], vf = pf[cd], vf2 = pf2[cd];
+        GnRaw gr = gn_affine_load(a.gn1, b, tid < CIN ? tid : 0);
+        // everything is loaded HERE, in one round trip (the compiler otherwise sinks loads towards their uses, behind other loads' waits)
+        asm volatile("" : "+v"(v0), "+v"(vbr), "+v"(v1), "+v"(vf), "+v"(vf2), "+v"(gr.gamma), "+v"(gr.beta), "+v"(gr.fs), "+v"(gr.fh), "+v"(gr.sum), "+v"(gr.sq));
+        prm[(lo ? 0 : 1) * 256 + c] = v0 + (!lo && hbr ? vbr : 0.f);                  // b1 | b2 (+ br)
+        prm[(lo ? 2 : 3) * 256 + c] = v1;                                             // gamma2 | beta2
+        const float f = (hf ? vf : 0.f) + (hf2 ? vf2 : 0.f);
+        prm[(lo ? 4 : 5) * 256 + c] = lo ? f + 1.0f : f;                              // film scale + 1 | film shift
+        if (tid < CIN) {
+            float A, Bc;
+            gn_affine_finish<true>(a.gn1, tid, gr, A, Bc);
+            tab[2 * tid] = A; tab[2 * tid + 1] = Bc;
         }
-        prm[i] = v;
-    }
-    if (tid < CIN) {
-        float A, Bc;
-        gn_affine<true>(a.gn1, b, tid, A, Bc);
-        tab[2 * tid] = A; tab[2 * tid + 1] = Bc;
     }
     constexpr int CPR = CIN / 8;                          // 16-byte chunks per input row
     auto src_chunk = [&](int row, int cc) __attribute__((always_inline)) -> u32x4_t {

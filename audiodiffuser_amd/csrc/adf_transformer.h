@@ -209,8 +209,16 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     if constexpr (MODE != 2) prefetch(nt3, a.wqkv, a.npad_qkv, wave * 96);
     else prefetch(nt1, a.wproj, a.npad_proj, wave * 32);
     // LayerNorm parameters -> LDS, their loads in flight together with the input rows' (one round trip instead of three)
-    for (int i = tid; i < 1280; i += 512)
-        prm[i] = i < 256 ? a.ln_w[i] : (i < 512 ? a.ln_b[i - 256] : (i < 768 ? a.g0[i - 512] : a.g3[i - 768]));
+    // (three unconditional loads per thread, the vector chosen by a wave-uniform select: the loop with a branch per vector was waited for trip by trip)
+    {
+        const bool lo = wave < 4;                                                     // uniform: threads 0..255 / 256..511
+        const int c = tid & 255;
+        float v0 = (lo ? a.ln_w : a.ln_b)[c], v1 = (lo ? a.g0 : a.g3)[c], v2 = a.g3[256 + c];
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2));       // all three are loaded HERE (the compiler otherwise sinks v2's load into the `if (lo)` below)
+        prm[tid] = v0;                    // ln_w | ln_b
+        prm[512 + tid] = v1;              // g0 | g3[0..255]
+        if (lo) prm[1024 + c] = v2;       // g3[256..511]
+    }
     if constexpr (MODE != 2) {
     // ---- S0: LayerNorm of the input rows -> bufA ------------------------------------------------------------------
     layer_norm(std::integral_constant<int, C>{}, (const char*)xb, C * 2, true, bufA, PA, prm, prm + 256, true);
