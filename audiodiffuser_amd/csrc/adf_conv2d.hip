@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
     const int nit = a.nchunk * a.taps;
     if (a.ab) {
         const float* const abg = a.ab + (size_t)(m0 / HW) * a.cin * 2;
-        for (int i = tid; i < 2 * a.cin; i += NT) abs_[i] = abg[i];
+        // 16-byte pieces: 1024 channels are one trip of the workgroup (float by float they were four load -> store trips, each a memory round trip)
+        for (int i = tid; i < a.cin / 2; i += NT) ((u32x4_t*)abs_)[i] = ((const u32x4_t*)abg)[i];
     }
 
     u32x4_t ra[NA], rw[NW];
@@ -338,7 +339,8 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
     C2_STAMP(0);
     if (a.ab) {
         const float* const abg = a.ab + (size_t)b * a.cin * 2;
-        for (int i = tid; i < 2 * a.cin; i += NT) abs_[i] = abg[i];
+        // 16-byte pieces: 1024 channels are one trip of the workgroup (float by float they were four load -> store trips, each a memory round trip)
+        for (int i = tid; i < a.cin / 2; i += NT) ((u32x4_t*)abs_)[i] = ((const u32x4_t*)abg)[i];
     }
 
     // halo pieces of this thread: piece ids tid + k NT over HR * 8 pieces; (pixel offset, validity) are fixed for the whole kernel
