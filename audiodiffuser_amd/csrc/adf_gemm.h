@@ -66,6 +66,25 @@ struct GemmArgs {
     int stats_groups;
 };
 
+// out[k] = bias0[bi[k]] + bias1[bi[k]] (absent vectors = 0) for ok[k], else 0 -- with EVERY load issued unconditionally and before the first use (absent
+// vectors through a valid dummy pointer): as `if (a.bias0) b += a.bias0[bi]; if (a.bias1) ...` per element each load was waited for on the spot, 2 N
+// serialised memory round trips (16 in the split-K epilogue).  See "Waits the compiler adds" in DESIGN.md.
+template <int N>
+__device__ __forceinline__ void gemm_bias_load(const GemmArgs& a, const int (&bi)[N], const bool (&ok)[N], float (&out)[N]) {
+    const bool h0 = a.bias0 != nullptr, h1 = a.bias1 != nullptr;                      // uniform
+    const float* const dmy = (const float*)a.seg[0].w;
+    const float* const p0 = h0 ? a.bias0 : dmy;
+    const float* const p1 = h1 ? a.bias1 : dmy;
+    float v0[N], v1[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int idx = ok[k] ? bi[k] : 0;
+        v0[k] = p0[h0 ? idx : 0]; v1[k] = p1[h1 ? idx : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = ok[k] ? (h0 ? v0[k] : 0.f) + (h1 ? v1[k] : 0.f) : 0.f;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -397,16 +416,17 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     // ---- epilogue phase 1: accumulators (+bias) -> LDS fp32 image [TM][TN] -----------------------
     __syncthreads();
     float* tile = (float*)smem;
+    float bias_c[NT];
+    {
+        int bi[NT]; bool okb[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { const int n = n0 + (wn * NT + j) * 32 + r; okb[j] = n < a.n; bi[j] = n % a.bias_mod; }
+        gemm_bias_load<NT>(a, bi, okb, bias_c);
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int col = (wn * NT + j) * 32 + r;
-        const int n = n0 + col;
-        float bias = 0.f;
-        if (n < a.n) {
-            const int bi = n % a.bias_mod;
-            if (a.bias0) bias += a.bias0[bi];
-            if (a.bias1) bias += a.bias1[bi];
-        }
+        const float bias = bias_c[j];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -734,15 +754,11 @@ __global__ void __launch_bounds__(512) conv_gemm_ws_kernel(const GemmArgs a, int
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     float bias_r[NT];        // bias of this lane's output column(s): the block's N tile never changes
+    {
+        int bi[NT]; bool okb[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int nb = n0 + (wn * NT + j) * 32 + r;
-        bias_r[j] = 0.f;
-        if (nb < a.n) {
-            const int bi = nb % a.bias_mod;
-            if (a.bias0) bias_r[j] += a.bias0[bi];
-            if (a.bias1) bias_r[j] += a.bias1[bi];
-        }
+        for (int j = 0; j < NT; ++j) { const int nb = n0 + (wn * NT + j) * 32 + r; okb[j] = nb < a.n; bi[j] = nb % a.bias_mod; }
+        gemm_bias_load<NT>(a, bi, okb, bias_r);
     }
     f32x16_t acc[MT][NT];
 #pragma unroll
@@ -1241,14 +1257,12 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
                     v[e] += q.x; v[e + 1] += q.y; v[e + 2] += q.z; v[e + 3] += q.w;
                 }
             if (ok) {
+                int bi[EPC]; bool okb[EPC]; float bsum[EPC];
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const int bi = (n + e) % a.bias_mod;
-                    float bsum = 0.f;
-                    if (a.bias0) bsum += a.bias0[bi];
-                    if (a.bias1) bsum += a.bias1[bi];
-                    v[e] += bsum;
-                }
+                for (int e = 0; e < EPC; ++e) { bi[e] = (n + e) % a.bias_mod; okb[e] = true; }
+                gemm_bias_load<EPC>(a, bi, okb, bsum);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += bsum[e];
                 const unsigned off = (unsigned)((bb * a.out_rows + m) * a.out_c + n);
                 if (res) {
                     float rr[EPC];
