@@ -54,12 +54,29 @@ __global__ void __launch_bounds__(512) conv_gemm_up_kernel(const GemmArgs a, int
         const int b = t / tiles_per_sample, m0 = (t - b * tiles_per_sample) * TM;
         __syncthreads();                                   // the previous tile is out of bufX / bufO
         constexpr int CPR = CIN / 8;
-        for (int idx = tid; idx < (TM + 1) * CPR; idx += 512) {
-            const int row = idx / CPR, cc = idx % CPR;
-            const int p = m0 - 1 + row;
-            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-            if (p >= 0 && p < L) v = *(const u32x4_t*)(src + ((size_t)b * L + p) * CIN + cc * 8);
-            *(u32x4_t*)(bufX + row * PX + cc * 16) = v;
+        // the pieces of a thread are loaded four at a time (unconditionally, rows outside the sample on a clamped address) before their LDS stores:
+        // as load -> store per trip under a condition these were (TM + 1) CPR / 512 serialised memory round trips per tile (four at a time: the
+        // weight-fragment ring is live here, eight would spill)
+        constexpr int XS = ((TM + 1) * CPR + 511) / 512, XG = 4;
+#pragma unroll
+        for (int g0 = 0; g0 < XS; g0 += XG) {
+            u32x4_t xs[XG];
+#pragma unroll
+            for (int k = 0; k < XG; ++k) {
+                const int idx = tid + (g0 + k) * 512;
+                const int row = idx < (TM + 1) * CPR ? idx / CPR : 0, cc = idx % CPR;
+                const int p = m0 - 1 + row;
+                const int pc = p < 0 ? 0 : (p < L ? p : L - 1);
+                xs[k] = *(const u32x4_t*)(src + ((size_t)b * L + pc) * CIN + cc * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < XG; ++k) {
+                const int idx = tid + (g0 + k) * 512;
+                if (g0 + k >= XS || idx >= (TM + 1) * CPR) continue;
+                const int row = idx / CPR, cc = idx % CPR;
+                const int p = m0 - 1 + row;
+                *(u32x4_t*)(bufX + row * PX + cc * 16) = (p >= 0 && p < L) ? xs[k] : u32x4_t{0u, 0u, 0u, 0u};
+            }
         }
         __syncthreads();
         {

@@ -162,13 +162,30 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
         }
     }
     constexpr int CPR = CIN / 8;                          // 16-byte chunks per input row
-    auto src_chunk = [&](int row, int cc) __attribute__((always_inline)) -> u32x4_t {
-        return cc < 32 ? *(const u32x4_t*)(xb + (size_t)row * 256 + cc * 8) : *(const u32x4_t*)(sb + (size_t)row * 256 + (cc - 32) * 8);
-    };
-    if (a.wr) {
-        for (int idx = tid; idx < NTOK * CPR; idx += 512) {
+    // The input rows are read ONCE, all pieces of a thread in flight together with the parameter loads above, and kept in registers for both uses
+    // (raw rows for the 1x1 residual conv, activated rows for conv1).  As two loops of load -> use -> store per piece they were 2 x NTOK * CPR / 512
+    // (16 at 64 tokens x 512 channels) serialised memory round trips.
+    constexpr int XT = NTOK * CPR / 512 > 0 ? NTOK * CPR / 512 : 1;
+    static_assert(NTOK * CPR % 512 == 0 || NTOK * CPR < 512, "whole sweeps of the workgroup");
+    u32x4_t xv[XT];
+    {
+        const long long dskip = sb ? (const char*)sb - (const char*)xb : 0ll;        // x and skip rows through ONE base pointer (no per-lane pointer select)
+#pragma unroll
+        for (int k = 0; k < XT; ++k) {
+            const int idx = tid + k * 512;
             const int row = idx / CPR, cc = idx % CPR;
-            u32x4_t v = src_chunk(row, cc);
+            const bool live = idx < NTOK * CPR;
+            const long long off = ((long long)(live ? row : 0) * 256 + (cc < 32 ? cc : cc - 32) * 8) * 2 + (cc < 32 ? 0ll : dskip);
+            xv[k] = *(const u32x4_t*)((const char*)xb + off);
+        }
+    }
+    if (a.wr) {
+#pragma unroll
+        for (int k = 0; k < XT; ++k) {
+            const int idx = tid + k * 512;
+            if (idx >= NTOK * CPR) continue;
+            const int row = idx / CPR, cc = idx % CPR;
+            u32x4_t v = xv[k];
             if (cc >= 32 && a.skip_scale != 1.0f) {        // the residual conv reads the raw concat [x ; skip_scale * skip]
                 float f[8];
                 unpack16<bf16_t>(v, f);
@@ -201,10 +218,13 @@ __global__ void __launch_bounds__(512) resblock_small_kernel(const RbFusedArgs a
             }
     }
     // ---- R2: silu(GroupNorm1(input)) -> bufX rows 1 .. NTOK, zero halo rows ---------------------------------------------
-    for (int idx = tid; idx < NTOK * CPR; idx += 512) {
+#pragma unroll
+    for (int k = 0; k < XT; ++k) {
+        const int idx = tid + k * 512;
+        if (idx >= NTOK * CPR) continue;
         const int row = idx / CPR, cc = idx % CPR;
         float f[8];
-        unpack16<bf16_t>(src_chunk(row, cc), f);
+        unpack16<bf16_t>(xv[k], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = silu_f(fmaf(f[e], tab[2 * (cc * 8 + e)], tab[2 * (cc * 8 + e) + 1]));
         *(u32x4_t*)(bufX + (row + 1) * PX + cc * 16) = pack16<bf16_t>(f);

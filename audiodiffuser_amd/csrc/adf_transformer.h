@@ -249,9 +249,19 @@ __global__ void __launch_bounds__(512) transformer_small_kernel(const TrFusedArg
     }
     if constexpr (MODE == 2) {                          // attention output rows -> bufA
         const bf16_t* const ab = a.att + (size_t)b * NTOK * C;
-        for (int idx = tid; idx < NTOK * (C / 8); idx += 512) {
-            const int row = idx / (C / 8), cc = idx % (C / 8);
-            *(u32x4_t*)(bufA + row * PA + cc * 16) = *(const u32x4_t*)(ab + (size_t)row * C + cc * 8);
+        // (every load of a thread before its first store: as load -> store per trip these were NTOK * C / 8 / 512 serialised round trips)
+        constexpr int AT = NTOK * (C / 8) / 512 > 0 ? NTOK * (C / 8) / 512 : 1;
+        u32x4_t av[AT];
+#pragma unroll
+        for (int k = 0; k < AT; ++k) {
+            const int idx = tid + k * 512;
+            const int row = idx < NTOK * (C / 8) ? idx / (C / 8) : 0, cc = idx % (C / 8);
+            av[k] = *(const u32x4_t*)(ab + (size_t)row * C + cc * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < AT; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < NTOK * (C / 8)) *(u32x4_t*)(bufA + (idx / (C / 8)) * PA + (idx % (C / 8)) * 16) = av[k];
         }
         __syncthreads();
     }

@@ -330,13 +330,21 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
             *(u32x4_t*)(bufA + ((size_t)tap * TM + i) * PA + cc * 16) = sv[k];
         }
     }
-    for (int i = tid; i < 6 * C; i += 512) {
-        float v;
-        if (i < 2 * C) v = b1[i];
-        else if (i < 4 * C) v = b2[i - 2 * C];
-        else if (i < 5 * C) v = e[(size_t)b * e_bstride + (size_t)n * C + (i - 4 * C)];
-        else v = y_next ? e[(size_t)b * e_bstride + (size_t)(n + 1) * C + (i - 5 * C)] : 0.0f;
-        prm[i] = v;
+    {   // every parameter load of a thread before its first LDS store (as load -> store per trip: 6 C / 512 serialised memory round trips per tile)
+        constexpr int PT = (6 * C + 511) / 512;
+        float pv[PT];
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int i = tid + k * 512;
+            float v = 0.0f;
+            if (i < 2 * C) v = b1[i];
+            else if (i < 4 * C) v = b2[i - 2 * C];
+            else if (i < 5 * C) v = e[(size_t)b * e_bstride + (size_t)n * C + (i - 4 * C)];
+            else if (i < 6 * C && y_next) v = e[(size_t)b * e_bstride + (size_t)(n + 1) * C + (i - 5 * C)];
+            pv[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < PT; ++k) if (tid + k * 512 < 6 * C) prm[tid + k * 512] = pv[k];
     }
     WN_STAMP(1);
     __syncthreads();
@@ -492,14 +500,21 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_wide_kernel(const bf16_t* _
                 for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
     };
     auto ldprm = [&]() __attribute__((always_inline)) {
-        for (int i = tid; i < 6 * C; i += NT) {
-            float v;
+        // every parameter load of a thread before its first LDS store (as load -> store per trip: 6 C / NT serialised memory round trips per tile)
+        constexpr int PT = (6 * C + NT - 1) / NT;
+        float pv[PT];
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int i = tid + k * NT;
+            float v = 0.0f;
             if (i < 2 * C) v = b1[i];
             else if (i < 4 * C) v = b2[i - 2 * C];
             else if (i < 5 * C) v = e[(size_t)b * e_bstride + (size_t)n * C + (i - 4 * C)];
-            else v = y_next ? e[(size_t)b * e_bstride + (size_t)(n + 1) * C + (i - 5 * C)] : 0.0f;
-            prm[i] = v;
+            else if (i < 6 * C && y_next) v = e[(size_t)b * e_bstride + (size_t)(n + 1) * C + (i - 5 * C)];
+            pv[k] = v;
         }
+#pragma unroll
+        for (int k = 0; k < PT; ++k) if (tid + k * NT < 6 * C) prm[tid + k * NT] = pv[k];
     };
     zero();
     if (2 * dil <= TM) {
