@@ -72,6 +72,7 @@ EXPORTS = {
     "adf_wavenet_create": (C.c_int, [C.POINTER(AdfWaveNetConfig), C.POINTER(C.c_void_p)]),
     "adf_adm_create": (C.c_int, [C.POINTER(AdfAdmConfig), C.POINTER(C.c_void_p)]),
     "adf_set_image_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "adf_set_dynamic_threshold": (C.c_int, [C.c_void_p, C.c_float]),
     "adf_destroy": (None, [C.c_void_p]),
     "adf_last_error": (C.c_char_p, [C.c_void_p]),
     "adf_num_weights": (C.c_int, [C.c_void_p]),
@@ -87,6 +88,7 @@ EXPORTS = {
     "adf_sampler_nfe": (C.c_int, [C.POINTER(AdfSamplerDesc), C.POINTER(C.c_float), C.c_int]),
     "adf_debug_tap_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adf_debug_tap_copy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "adf_debug_dyn_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
     "adf_debug_tap_count": (C.c_int, [C.c_void_p]),
     "adf_debug_tap_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "adf_device_bytes": (C.c_int64, [C.c_void_p]),

@@ -115,6 +115,7 @@ struct Plan {
     float* sb[10] = {nullptr};
     float* noise_stage = nullptr; float* out_stage = nullptr; float* inj_stage = nullptr; size_t inj_cap = 0;
     float* cfg_c = nullptr; float* cfg_n = nullptr;      // raw network outputs of the two CFG branches
+    float* dyn_scale = nullptr;                          // [B] per-sample scales of the dynamic threshold
     // captured sampler loops, most recently used first; at most kMaxGraphsPerPlan are kept (the oldest is destroyed)
     std::vector<std::pair<std::string, hipGraphExec_t>> graphs;
     std::vector<void*> allocs;                            // device memory owned by this plan (released when the plan is evicted)
@@ -151,6 +152,7 @@ struct adf_handle {
     bool cond_on = false;
     int cond_B = 0;
     float cond_scale = 1.0f;
+    float dyn_q = 0.0f;                                  // > 0: dynamic thresholding at this quantile instead of clamp(-1, 1) (adf_set_dynamic_threshold)
     long long* cond_classes = nullptr;  // [cond_B]
     float* cond_emb = nullptr;          // [cond_B + 1][cdim], last row = null embedding
     float* cond_film = nullptr;         // [cond_B + 1][film_total]: class part of every FiLM projection
@@ -1204,23 +1206,35 @@ int ensure_cfg_buffers(adf_handle* h, Plan* p) {
 
 // One denoiser evaluation.  io carries x / t / coef (preconditioning scalars already in p->coef); with classifier-free
 // guidance the network runs twice (labels, null labels) in raw mode and cfg_combine applies guidance + preconditioning.
+// Dynamic thresholding (EluDiffusion(dynamic_threshold = q), components/utils.py:23-33): the estimate leaves the combine kernel unclipped and is
+// rescaled in place by its per-sample quantile.
 int denoise_io(adf_handle* h, Plan* p, FwdIO io, float* out, hipStream_t s) {
     const bool cfg = h->cdim > 0 && h->cond_on && h->cond_scale != 1.0f;
-    if (!cfg) {
+    const bool dyn = h->dyn_q > 0.0f;
+    if (!cfg && !dyn) {
         if (cond_rows(h, p->B, false, io)) return 1;
         io.out = out; io.mode = 1;
         return forward(h, p, io, s);
     }
-    const size_t wave = (size_t)p->B * h->cfg.out_channels * p->L;
+    const long long per_sample = (long long)h->cfg.out_channels * p->L;
+    const size_t wave = (size_t)p->B * per_sample;
     if (ensure_cfg_buffers(h, p)) return 1;
+    if (dyn && !p->dyn_scale) {
+        p->dyn_scale = (float*)dalloc(h, (size_t)p->B * 4, p);
+        if (!p->dyn_scale) return fail(h, "device allocation failed for the dynamic-threshold scales");
+    }
     io.mode = 0;                                     // raw network output; c_in is still applied by to_in
     io.out = p->cfg_c;
     if (cond_rows(h, p->B, false, io) || forward(h, p, io, s)) return 1;
-    io.out = p->cfg_n;
-    if (cond_rows(h, p->B, true, io) || forward(h, p, io, s)) return 1;
-    if (const char* e = launch_cfg_combine(out, io.x_noisy, p->cfg_c, p->cfg_n, io.coef, io.coef_bstride, h->cond_scale,
-                                           (long long)h->cfg.out_channels * p->L, (long long)wave, s))
+    if (cfg) {
+        io.out = p->cfg_n;
+        if (cond_rows(h, p->B, true, io) || forward(h, p, io, s)) return 1;
+    }
+    if (const char* e = launch_cfg_combine(out, io.x_noisy, p->cfg_c, cfg ? p->cfg_n : p->cfg_c, io.coef, io.coef_bstride, cfg ? h->cond_scale : 1.0f,
+                                           per_sample, (long long)wave, dyn ? 0 : 1, s))
         return fail(h, e);
+    if (dyn)
+        if (const char* e = launch_dyn_threshold(out, p->B, per_sample, h->dyn_q, p->dyn_scale, s)) return fail(h, e);
     return 0;
 }
 
@@ -2058,6 +2072,13 @@ int adf_set_condition(adf_handle* h, const int64_t* classes_dev, int B, int null
     return 0;
 }
 
+int adf_set_dynamic_threshold(adf_handle* h, float quantile) {
+    if (!h) return 1;
+    if (!(quantile >= 0.0f) || quantile > 1.0f) return fail(h, "adf_set_dynamic_threshold: the quantile must be in [0, 1] (0 = clamp to [-1, 1])");
+    h->dyn_q = quantile;
+    return 0;
+}
+
 int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, float sigma, float sigma_data, float* out, int B,
                 int L, void* stream) {
     ADF_ON_DEVICE(h);
@@ -2092,6 +2113,13 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     if (h->cdim > 0) {
         if (!h->cond_on || h->cond_B != B) return fail(h, "class-conditional network: call adf_set_condition with the labels of this batch first");
         if (h->cond_scale != 1.0f && ensure_cfg_buffers(h, p)) return 1;
+    }
+    if (h->dyn_q > 0.0f) {                               // buffers of the dynamic threshold: allocated before any capture starts
+        if (ensure_cfg_buffers(h, p)) return 1;
+        if (!p->dyn_scale) {
+            p->dyn_scale = (float*)dalloc(h, (size_t)B * 4, p);
+            if (!p->dyn_scale) return fail(h, "device allocation failed for the dynamic-threshold scales");
+        }
     }
     if (hipMemcpyAsync(p->noise_stage, noise, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "noise copy failed");
     if (injected_noise) {
@@ -2200,6 +2228,7 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
     key.push_back(injected_noise ? 'i' : 'n');
     key.push_back(h->cond_on ? 'c' : 'u');                   // the guidance branch structure is part of the captured graph
     key.append((const char*)&h->cond_scale, sizeof(float));
+    key.append((const char*)&h->dyn_q, sizeof(float));        // the clipping of every evaluation is part of the captured graph
     auto it = std::find_if(p->graphs.begin(), p->graphs.end(), [&](const std::pair<std::string, hipGraphExec_t>& g) { return g.first == key; });
     if (it != p->graphs.end() && it != p->graphs.begin()) {      // most recently used first
         std::rotate(p->graphs.begin(), it, it + 1);
@@ -2232,6 +2261,17 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
         return fail(h, "stream fence (out) failed");
     if (hipMemcpyAsync(out, p->out_stage, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
     return 0;
+}
+
+int adf_debug_dyn_threshold(adf_handle* h, float* x_dev, int B, long long per_sample, float quantile, void* stream) {
+    ADF_ON_DEVICE(h);
+    if (!x_dev || B < 1) return fail(h, "adf_debug_dyn_threshold: bad arguments");
+    float* sc = (float*)dalloc(h, (size_t)B * 4);
+    if (!sc) return fail(h, "device allocation failed");
+    const char* e = launch_dyn_threshold(x_dev, B, per_sample, quantile, sc, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    dfree(h, sc, (size_t)B * 4);
+    return e ? fail(h, e) : 0;
 }
 
 int adf_debug_tap_count(adf_handle* h) { return h->last_plan ? (int)h->last_plan->taps.size() : 0; }

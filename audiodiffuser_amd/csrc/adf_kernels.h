@@ -62,7 +62,10 @@ const char* launch_class_embed(const long long* classes, int num_classes, int nu
                                int ch, int cdim, float* out, int nrows, hipStream_t s);
 // out = clamp(c_skip x + c_out (fn + (fc - fn) scale), -1, 1); coef rows are (c_in, c_noise, c_skip, c_out).
 const char* launch_cfg_combine(float* out, const float* x, const float* fc, const float* fn, const float* coef, int coef_bstride,
-                               float scale, long long per_sample, long long n, hipStream_t s);
+                               float scale, long long per_sample, long long n, int clampit, hipStream_t s);
+// Dynamic thresholding of EluDiffusion (components/utils.py:23-33) in place on x [B][per_sample]: per sample scale = max(1, quantile(|x|, q)) (torch's
+// linear interpolation, exact order statistics by radix select), x = clamp(x, -scale, scale) / scale.  scale_scratch: B floats.
+const char* launch_dyn_threshold(float* x, int B, long long per_sample, float q, float* scale_scratch, hipStream_t s);
 
 // ---- sampler state updates (fp32, flat arrays of n elements) --------------------------------
 const char* launch_scale(float* out, const float* in, float s, long long n, hipStream_t st);

@@ -1013,25 +1013,109 @@ const char* launch_class_embed(const long long* classes, int num_classes, int nu
     return ADF_LAUNCH_CHECK("class_embed");
 }
 
-// Classifier-free guidance + EDM preconditioning (diffusion.py:52-59): out = clamp(c_skip x + c_out (n + (c - n) s), -1, 1)
+// Classifier-free guidance + EDM preconditioning (diffusion.py:52-59): out = clamp(c_skip x + c_out (n + (c - n) s), -1, 1); clampit = 0 leaves the
+// estimate unclipped for the dynamic threshold below (fc == fn, scale 1: the unguided estimate)
 __global__ void __launch_bounds__(256) cfg_combine_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ fc,
                                                           const float* __restrict__ fn, const float* __restrict__ coef, int coef_bstride,
-                                                          float scale, long long per_sample, long long n) {
+                                                          float scale, long long per_sample, long long n, int clampit) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long b = i / per_sample;
         const float c_skip = coef[b * coef_bstride + 2], c_out = coef[b * coef_bstride + 3];
         const float nl = fn[i];
         const float pred = nl + (fc[i] - nl) * scale;
-        out[i] = fminf(fmaxf(c_skip * x[i] + c_out * pred, -1.0f), 1.0f);
+        const float v = c_skip * x[i] + c_out * pred;
+        out[i] = clampit ? fminf(fmaxf(v, -1.0f), 1.0f) : v;
     }
 }
 
 const char* launch_cfg_combine(float* out, const float* x, const float* fc, const float* fn, const float* coef, int coef_bstride,
-                               float scale, long long per_sample, long long n, hipStream_t s) {
+                               float scale, long long per_sample, long long n, int clampit, hipStream_t s) {
     long long g = (n + 255) / 256;
     hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s, out, x, fc, fn, coef,
-                       coef_bstride, scale, per_sample, n);
+                       coef_bstride, scale, per_sample, n, clampit);
     return ADF_LAUNCH_CHECK("cfg_combine");
+}
+
+// Dynamic thresholding (components/utils.py:23-33): per sample, scale = max(1, quantile(|x|, q)) with torch.quantile's linear interpolation
+// between the two order statistics around rank q (n - 1) (ATen quantile_compute: ranks in fp32, lerp), then x = clamp(x, -scale, scale) / scale.
+// The order statistics are EXACT: a radix select over the bit patterns of |x| (monotonic for non-negative floats), four 8-bit passes with a
+// 256-bin LDS histogram each, one workgroup per sample; the upper neighbour is the same value when enough elements tie, else the minimum of the
+// larger ones (a fifth pass).  NaNs are not expected (torch.quantile would return NaN).
+__global__ void __launch_bounds__(1024) dyn_scale_kernel(const float* __restrict__ x, long long per_sample, float q, float* __restrict__ scale_out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_prefix, sh_k, sh_le, sh_min;
+    const int tid = threadIdx.x;
+    const float* const xb = x + (size_t)blockIdx.x * per_sample;
+    const float ranks = q * (float)(per_sample - 1);                      // fp32, as ATen computes it
+    const long long below = (long long)floorf(ranks), above = (long long)ceilf(ranks);
+    const float weight = ranks - (float)below;
+    unsigned prefix = 0u;                                                // the bytes of the answer found so far (high to low)
+    unsigned k = (unsigned)below;                                        // rank of the answer among the elements that match `prefix`
+    unsigned eq = 0u;                                                    // elements in the answer's bin (after the last pass: equal to it)
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned mask = pass == 0 ? 0u : 0xffffffffu << (shift + 8);
+        for (long long i = tid; i < per_sample; i += 1024) {
+            const unsigned u = __float_as_uint(xb[i]) & 0x7fffffffu;
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                                   // wave 0: lane l owns bins 4 l .. 4 l + 3
+            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned tot = h0 + h1 + h2 + h3;
+            unsigned inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (tid >= o) inc += t; }
+            const unsigned exc = inc - tot;                               // matching elements in the bins before this lane's
+            if (k >= exc && k < inc) {                                    // exactly one lane
+                unsigned c = exc; int bin = 4 * tid;
+                if (k >= c + h0) { c += h0; ++bin; if (k >= c + h1) { c += h1; ++bin; if (k >= c + h2) { c += h2; ++bin; } } }
+                sh_prefix = prefix | ((unsigned)bin << shift);
+                sh_k = k - c;                                             // the c elements of the smaller bins are smaller than the answer
+                sh_le = hist[bin];
+            }
+        }
+        __syncthreads();
+        prefix = sh_prefix; k = sh_k; eq = sh_le;
+        __syncthreads();
+    }
+    const float v_below = __uint_as_float(prefix);
+    float v_above = v_below;
+    // (below - k) elements are smaller than v_below, eq equal to it: the element of rank `above` is v_below itself unless above >= that count
+    if (above != below && (unsigned long long)above >= (unsigned long long)((unsigned)below - k) + eq) {
+        if (tid == 0) sh_min = 0x7f800000u;
+        __syncthreads();
+        unsigned m = 0x7f800000u;
+        for (long long i = tid; i < per_sample; i += 1024) {
+            const unsigned u = __float_as_uint(xb[i]) & 0x7fffffffu;
+            if (u > prefix && u < m) m = u;
+        }
+        atomicMin(&sh_min, m);
+        __syncthreads();
+        v_above = __uint_as_float(sh_min);
+    }
+    if (tid == 0) {
+        const float d = v_above - v_below;
+        const float r = fabsf(weight) < 0.5f ? v_below + weight * d : v_above - d * (1.0f - weight);    // at::lerp
+        scale_out[blockIdx.x] = fmaxf(r, 1.0f);
+    }
+}
+__global__ void __launch_bounds__(256) dyn_apply_kernel(float* __restrict__ x, const float* __restrict__ scale, long long per_sample, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float s = scale[i / per_sample];
+        x[i] = __fdiv_rn(fminf(fmaxf(x[i], -s), s), s);
+    }
+}
+const char* launch_dyn_threshold(float* x, int B, long long per_sample, float q, float* scale_scratch, hipStream_t s) {
+    if (per_sample < 1 || per_sample > 0x7fffffffll) return "dyn_threshold: bad sample size";
+    if (!(q > 0.0f) || q > 1.0f) return "dyn_threshold: the quantile must be in (0, 1]";
+    hipLaunchKernelGGL(dyn_scale_kernel, dim3((unsigned)B), dim3(1024), 0, s, x, per_sample, q, scale_scratch);
+    const long long n = (long long)B * per_sample;
+    long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(dyn_apply_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, x, scale_scratch, per_sample, n);
+    return ADF_LAUNCH_CHECK("dyn_threshold");
 }
 
 // =====================================================================================================

@@ -47,9 +47,9 @@ class EluDiffusion(nn.Module):
         return (sigmas ** 2 + self.sigma_data ** 2) * (sigmas * self.sigma_data) ** -2
 
     def _native_ok(self, net, inference: bool, cond_scale: float, kwargs: dict) -> bool:
-        """The HIP fast path covers inference with clamp clipping; the only conditioning kwarg it understands is
+        """The HIP fast path covers inference (clamp clipping or the dynamic threshold); the only conditioning kwarg it understands is
         ``classes`` (labels) on a class-conditional net, where ``cond_scale != 1`` is classifier-free guidance."""
-        if not (isinstance(net, HipNet) and inference and self.dynamic_threshold == 0.0):
+        if not (isinstance(net, HipNet) and inference and 0.0 <= self.dynamic_threshold <= 1.0):
             return False
         extra = {k: v for k, v in kwargs.items() if v is not None}
         if net.cfg.class_cond:
@@ -62,6 +62,7 @@ class EluDiffusion(nn.Module):
         assert (sigma is not None) ^ (sigmas is not None), "Either x or xs must be provided"   # components/utils.py:47
         if self._native_ok(net, inference, cond_scale, kwargs) and x_noisy.is_cuda:
             hd = net.native(x_noisy.device)
+            hd.set_dynamic_threshold(self.dynamic_threshold)
             x = x_noisy.detach().to(torch.float32).contiguous()
             if net.cfg.class_cond:      # labels + guidance scale for this call (diffusion.py:49-54)
                 hd.set_condition(kwargs["classes"], x.device, null_labels=False, cond_scale=float(cond_scale))

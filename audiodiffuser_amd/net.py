@@ -124,6 +124,10 @@ class NativeHandle:
                                             x.shape[0], self._length(x), C.c_void_p(_stream_ptr(x.device))), "adf_net_forward")
         return out
 
+    def set_dynamic_threshold(self, quantile: float) -> None:
+        """Clipping of every later denoiser evaluation: 0 = clamp(-1, 1), q = EluDiffusion(dynamic_threshold=q) (components/utils.py:19-33)."""
+        self.check(self.lib.adf_set_dynamic_threshold(self.h, float(quantile)), "adf_set_dynamic_threshold")
+
     def denoise(self, x: torch.Tensor, sigma_data: float, sigma: Optional[float] = None,
                 sigmas: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = torch.empty_like(x)

@@ -29,7 +29,7 @@ def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict) -> Optional
     ``cond_scale != 1`` is classifier-free guidance (two network passes per evaluation)."""
     owner = getattr(fn, "__self__", None)
     if not (isinstance(owner, EluDiffusion) and getattr(fn, "__func__", None) is EluDiffusion.denoise_fn
-            and isinstance(net, HipNet) and owner.dynamic_threshold == 0.0):
+            and isinstance(net, HipNet) and 0.0 <= owner.dynamic_threshold <= 1.0):
         return None
     extra = {k: v for k, v in kwargs.items() if v is not None}
     if net.cfg.class_cond:
@@ -37,9 +37,10 @@ def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict) -> Optional
     return owner if (not extra and cond_scale == 1.0) else None
 
 
-def _condition(net: UNet1dBase, hd, device, cond_scale: float, kwargs: dict) -> None:
+def _condition(net: UNet1dBase, hd, device, cond_scale: float, kwargs: dict, diff: Optional[EluDiffusion] = None) -> None:
     """Labels + guidance scale of this sampler run (the reference forwards them to every fn call, e.g.
-    sampler_edm.py:341-345)."""
+    sampler_edm.py:341-345), and the clipping of the owner of ``fn`` (clamp or dynamic threshold, diffusion.py:61)."""
+    hd.set_dynamic_threshold(diff.dynamic_threshold if diff is not None else 0.0)
     if net.cfg.class_cond:
         hd.set_condition(kwargs["classes"], device, null_labels=False, cond_scale=float(cond_scale))
 
@@ -88,7 +89,7 @@ class EDMSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             inj = _draws(x, self.num_steps, injected_noise, self.s_churn > 0)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
         # ---- interface-compatibility branch (sampler_edm.py:333-397) -----------------------------
@@ -134,7 +135,7 @@ class EDMAlphaSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         x = sigmas[0] * noise                                            # sampler_edm.py:284-300
         for i in range(self.num_steps - 1):
@@ -203,7 +204,7 @@ class DPMSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         # ---- interface-compatibility branch (sampler_edm.py:710-805, :568-690) --------------------
         if not self.x0_pred:
@@ -301,7 +302,7 @@ class DPM2MSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         # ---- interface-compatibility branch --------------------------------------------------------
         x = sigmas[0] * noise
@@ -366,7 +367,7 @@ class LMSSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         # ---- interface-compatibility branch --------------------------------------------------------
         t = sigmas.detach().cpu().numpy()
@@ -406,7 +407,7 @@ class DPM2Sampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             inj = _draws(x, self.num_steps - 1, injected_noise, self.s_churn > 0)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
         # ---- interface-compatibility branch (sampler_edm.py:428-493) ----------------------------------
@@ -452,7 +453,7 @@ class ADPM2Sampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             inj = _draws(x, self.num_steps - 1, injected_noise, True)                          # reference draw order (:82)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
         # ---- interface-compatibility branch (stochastic_sampler_edm.py:29-32, :53-100) -----------------
@@ -495,7 +496,7 @@ class ADPMPP2SSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             n_draws = int((sigmas[1:self.num_steps].detach().cpu() > 0).sum())                 # one per step with sigma_next > 0 (:158)
             inj = _draws(x, n_draws, injected_noise, True)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, inj).to(noise.dtype)
@@ -551,7 +552,7 @@ class UniPCSampler(nn.Module):
         if diff is not None and noise.is_cuda:
             x = _prep(noise)
             hd = net.native(x.device)
-            _condition(net, hd, x.device, self.cond_scale, kwargs)
+            _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
             return hd.sampler_run(self._desc(diff.sigma_data), sigmas, x, None).to(noise.dtype)
         # ---- interface-compatibility branch (same recurrences as tensor ops around a foreign fn / net) ----------------------------
         steps, order = self.num_steps, self.order

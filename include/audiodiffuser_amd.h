@@ -119,6 +119,11 @@ int adf_create(const adf_net_config* cfg, adf_handle** out);
  * "output_blocks.<i>" (the outputs of the reference's blocks). */
 int adf_adm_create(const adf_adm_config* cfg, adf_handle** out);
 int adf_set_image_shape(adf_handle* h, int H, int W);
+
+/* Clipping of every denoiser evaluation from here on (adf_denoise, adf_sampler_run): 0 = clamp to [-1, 1] (the default), q in (0, 1] = the dynamic
+ * thresholding of EluDiffusion(dynamic_threshold = q) -- per sample, scale = max(1, quantile(|x|, q)) (torch.quantile's linear interpolation),
+ * x = clamp(x, -scale, scale) / scale.  Replaces src/models/components/utils.py:19-33 (`clip`) as called from diffusion.py:61. */
+int adf_set_dynamic_threshold(adf_handle* h, float quantile);
 /* A WaveNetNoise handle.  x / out of adf_net_forward, adf_denoise, adf_sampler_run are [B][1][T] (the reference's forward takes
  * audio [B][T] and returns [B][1][T]: same memory); any T >= 1.  Debug taps: "y<n>" = input of residual layer n including its
  * diffusion-step addend (kept while all of them fit 256 MiB), "skip" = the normalised skip sum. */
@@ -161,6 +166,8 @@ int adf_sampler_nfe(const adf_sampler_desc* desc, const float* sigmas_host, int 
  * fp32 [B][C][L].  Names follow oracle/unet1d.py taps ("to_in", "down0.conv", "down0.block1", "mid.attn", ...). */
 int adf_debug_tap_shape(adf_handle* h, const char* name, int* C, int* L);
 int adf_debug_tap_copy(adf_handle* h, const char* name, float* out_fp32, void* stream);
+/* The dynamic threshold alone, in place on x_dev [B][per_sample] (tests: exactness of the order statistics against torch.quantile). */
+int adf_debug_dyn_threshold(adf_handle* h, float* x_dev, int B, long long per_sample, float quantile, void* stream);
 int adf_debug_tap_count(adf_handle* h);
 const char* adf_debug_tap_name(adf_handle* h, int index);
 

@@ -28,10 +28,22 @@ def edm_scale_weights(sigmas: torch.Tensor, sigma_data: float, ndim: int) -> Tup
     return c_skip, c_out, c_in, c_noise
 
 
+def clip(x: torch.Tensor, dynamic_threshold: float = 0.0) -> torch.Tensor:
+    """src/models/components/utils.py:19-33: clamp(-1, 1), or dynamic thresholding -- per sample scale = max(1, quantile(|x|, q)),
+    x = clamp(x, -scale, scale) / scale."""
+    if dynamic_threshold == 0.0:
+        return x.clamp(-1.0, 1.0)
+    flat = x.reshape(x.shape[0], -1)
+    scale = torch.quantile(flat.abs(), dynamic_threshold, dim=-1)
+    scale.clamp_(min=1.0)
+    scale = scale.view(*scale.shape, *((1,) * (x.ndim - scale.ndim)))
+    return x.clamp(-scale, scale) / scale
+
+
 def denoise(net: Callable[..., torch.Tensor], x_noisy: torch.Tensor,
-            sigma_data: float, sigma=None, sigmas: Optional[torch.Tensor] = None, cond_scale: float = 1.0) -> torch.Tensor:
-    """src/models/components/diffusion.py:32-63 at inference with dynamic_threshold == 0
-    (clip = clamp(-1, 1), components/utils.py:20-22).  Exactly one of sigma / sigmas.
+            sigma_data: float, sigma=None, sigmas: Optional[torch.Tensor] = None, cond_scale: float = 1.0,
+            dynamic_threshold: float = 0.0) -> torch.Tensor:
+    """src/models/components/diffusion.py:32-63 at inference (clip: components/utils.py:19-33).  Exactly one of sigma / sigmas.
     cond_scale != 1: classifier-free guidance (:52-54); ``net`` must then accept cond_drop_prob."""
     assert (sigma is None) ^ (sigmas is None), "Either sigma or sigmas must be provided"
     b = x_noisy.shape[0]
@@ -44,11 +56,11 @@ def denoise(net: Callable[..., torch.Tensor], x_noisy: torch.Tensor,
         pred = net(c_in * x_noisy, c_noise, cond_drop_prob=0.0)
         null = net(c_in * x_noisy, c_noise, cond_drop_prob=1.0)
         pred = null + (pred - null) * cond_scale
-    return (c_skip * x_noisy + c_out * pred).clamp(-1.0, 1.0)
+    return clip(c_skip * x_noisy + c_out * pred, dynamic_threshold)
 
 
 def make_denoiser(p: P, cfg: UNet1dConfig, sigma_data: float, classes: Optional[torch.Tensor] = None,
-                  cond_scale: float = 1.0, storage: str = "fp32") -> Callable:
+                  cond_scale: float = 1.0, storage: str = "fp32", dynamic_threshold: float = 0.0) -> Callable:
     """fn(x, sigma) -> denoised, the closure the samplers call (module call site:
     src/models/diffunet_complex_module.py:86-89); ``classes`` / ``cond_scale`` as the module forwards them.
     ``storage="bf16"``: the network in the bf16-storage arithmetic of oracle/unet1d.py (the preconditioning, the
@@ -57,5 +69,5 @@ def make_denoiser(p: P, cfg: UNet1dConfig, sigma_data: float, classes: Optional[
         return unet1d_forward(p, cfg, xi, t, classes=classes, cond_drop_prob=cond_drop_prob, storage=storage)
 
     def fn(x, sigma=None, sigmas=None):
-        return denoise(net, x, sigma_data, sigma=sigma, sigmas=sigmas, cond_scale=cond_scale)
+        return denoise(net, x, sigma_data, sigma=sigma, sigmas=sigmas, cond_scale=cond_scale, dynamic_threshold=dynamic_threshold)
     return fn

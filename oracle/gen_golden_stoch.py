@@ -5,6 +5,7 @@ restatements against it before writing tests/golden/stoch_golden.npz:
 
   * ADPMPP2SSampler ('DPM++ 2S a Karras', stochastic_sampler_edm.py:102-178) with recorded randn_like draws, eta 1.0 and 0.6,
     on a Karras schedule and on one that ends in 0 (the Euler branch :136-140 and the skipped last draw :158);
+  * the dynamic threshold of EluDiffusion (components/utils.py:19-33): denoise_fn at three noise levels and an 8-step Heun run, q = 0.95 / 0.5;
   * DPM2MSampler of the same file (:180-259) with reflow=True (its reflow=False path is sampler_edm.py's DPM2MSampler, pinned
     by oracle/gen_golden.py section 9).
 
@@ -82,6 +83,24 @@ def main():
         assert torch.equal(ya, yb)
         report[f"dpm2m_reflow_{tag}"] = rel_err(yo, y)
         out[f"smp_dpm2m_reflow_{tag}_final"] = y.numpy()
+    # ---- dynamic thresholding (components/utils.py:19-33 via diffusion.py:61): denoise_fn at three noise levels and an 8-step Heun run ----
+    for q in (0.95, 0.5):
+        diff_q = ref["EluDiffusion"](sigma_data=0.2, dynamic_threshold=q)
+        fn_q = E.make_denoiser(w, cfg, 0.2, dynamic_threshold=q)
+        x = 3.0 * generate_noise(71, 2, 256)
+        for sv in (2.5, 0.4, 0.02):
+            with torch.no_grad():
+                y = diff_q.denoise_fn(x, net=net, sigma=sv, inference=True)
+                yo = fn_q(x, sigma=sv)
+            report[f"dyn_q{q}_s{sv}"] = rel_err(yo, y)
+            out[f"dyn_q{q}_s{sv}"] = y.numpy()
+        sg8 = E.karras_sigmas(0.002, 80.0, 7.0, 8)
+        with torch.no_grad():
+            y = ref["EDMSampler"](s_churn=0.0, num_steps=8)(noise, fn=diff_q.denoise_fn, net=net, sigmas=sg8)
+            yo = S.edm_sampler(noise, fn_q, sg8, 8, s_churn=0.0)
+        report[f"dyn_q{q}_heun8"] = rel_err(yo, y)
+        out[f"dyn_q{q}_heun8"] = y.numpy()
+    out["dyn_x"] = (3.0 * generate_noise(71, 2, 256)).numpy()
     assert all(np.isfinite(v).all() for v in out.values())
     assert max(report.values()) < 5e-4, report
     print(json.dumps(report, indent=1))

@@ -605,6 +605,51 @@ def test_dpm2_family_vs_reference_golden(golden, graph):
     assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
 
 
+def test_dynamic_threshold_kernel_is_exact_against_torch_quantile():
+    """The radix select of dyn_scale_kernel returns the exact order statistics: the rescaled tensor equals torch's
+    clamp(x, -s, s) / s with s = max(1, torch.quantile(|x|, q)) bit for bit -- random data, heavy ties, tiny and odd sizes, q = 1, integer ranks."""
+    net, _ = make_net(A.config_tiny(), "fp32")
+    hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for n in (5, 64, 1000, 16384, 20480 + 7):
+        cases.append(3.0 * torch.randn(3, n, generator=g))
+        cases.append((3.0 * torch.randn(3, n, generator=g)).round())                 # many ties, zeros
+    cases.append(torch.full((2, 333), 0.25))                                         # all equal, scale clamps to 1
+    for x in cases:
+        for q in (0.95, 0.5, 1.0, 0.999, 1.0 / 3.0, 0.25):
+            s = torch.quantile(x.abs(), q, dim=-1, keepdim=True).clamp(min=1.0)
+            ref = x.clamp(-s, s) / s
+            xd = x.clone().cuda().contiguous()
+            hd.check(hd.lib.adf_debug_dyn_threshold(hd.h, C.c_void_p(xd.data_ptr()), x.shape[0], x.shape[1], q, C.c_void_p(0)), "adf_debug_dyn_threshold")
+            assert torch.equal(xd.cpu(), ref), (tuple(x.shape), q, float((xd.cpu() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_dynamic_threshold_denoise_and_sampler_vs_reference_golden(graph):
+    """EluDiffusion(dynamic_threshold=q) on the device: denoise_fn at three noise levels and an 8-step Heun run (eager and graph-replayed) against
+    the reference's own results; back to the plain clamp afterwards (the setting is per call)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stoch_golden.npz"))
+    net, _ = make_net(A.config_tiny(), "fp32")
+    x = T(g["dyn_x"]).cuda()
+    noise = generate_noise(70, 2, 256).cuda()
+    sg8 = A.KarrasSchedule(0.002, 80.0, 7.0, 8)()
+    for q in (0.95, 0.5):
+        d = A.EluDiffusion(sigma_data=0.2, dynamic_threshold=q)
+        for sv in (2.5, 0.4, 0.02):
+            y = d.denoise_fn(x, net=net, sigma=sv, inference=True)
+            assert rel_err(y.cpu(), T(g[f"dyn_q{q}_s{sv}"])) < FP32_TOL, (q, sv)
+            ys = d.denoise_fn(x, net=net, sigmas=torch.full((2,), sv), inference=True)
+            assert rel_err(ys.cpu(), T(g[f"dyn_q{q}_s{sv}"])) < FP32_TOL, (q, sv)
+        smp = A.EDMSampler(s_churn=0.0, num_steps=8, use_graph=graph)
+        for _ in range(2):
+            y = smp(noise, fn=d.denoise_fn, net=net, sigmas=sg8)
+            assert rel_err(y.cpu(), T(g[f"dyn_q{q}_heun8"])) < FP32_TOL, q
+    d0 = A.EluDiffusion(sigma_data=0.2)
+    y0 = d0.denoise_fn(x, net=net, sigma=0.02, inference=True)
+    assert float(y0.abs().max()) <= 1.0 and rel_err(y0.cpu(), T(g["dyn_q0.95_s0.02"])) > 1e-2
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_rest_of_stochastic_sampler_file_vs_reference_golden(graph):
     """ADPMPP2SSampler (two eta settings; a schedule ending in 0: Euler last step, one draw fewer) and DPM2MSampler(reflow=True) of

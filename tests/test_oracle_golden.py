@@ -291,6 +291,31 @@ def test_rest_of_stochastic_sampler_file_with_tiny_net():
             assert rel(y, T(g[f"smp_dpm2m_reflow_{tag}_final"])) < 5e-4, tag
 
 
+def test_dynamic_threshold_with_tiny_net():
+    """EluDiffusion(dynamic_threshold=q): the oracle's clip (components/utils.py:19-33) inside denoise_fn and an 8-step Heun run against the
+    reference's results (oracle/gen_golden_stoch.py); the thresholds are active (the scale exceeds 1) in every case."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stoch_golden.npz"))
+    cfg = config_tiny()
+    w = generate_weights(cfg, seed=0)
+    x = T(g["dyn_x"])
+    noise = generate_noise(70, 2, 256)
+    sg8 = E.karras_sigmas(0.002, 80.0, 7.0, 8)
+    with torch.no_grad():
+        for q in (0.95, 0.5):
+            fn = E.make_denoiser(w, cfg, 0.2, dynamic_threshold=q)
+            plain = E.make_denoiser(w, cfg, 0.2)
+            for sv in (2.5, 0.4, 0.02):
+                y = fn(x, sigma=sv)
+                assert rel(y, T(g[f"dyn_q{q}_s{sv}"])) < 5e-4, (q, sv)
+            assert rel(fn(x, sigma=0.02), plain(x, sigma=0.02)) > 1e-2           # not the plain clamp
+            assert rel(S.edm_sampler(noise, fn, sg8, 8, s_churn=0.0), T(g[f"dyn_q{q}_heun8"])) < 5e-4, q
+    # the clip itself against torch.quantile semantics on ties and integer ranks
+    t = torch.tensor([[0.5, -2.0, 2.0, 2.0, -3.0, 0.25, 4.0, -4.0, 1.5]])
+    for q in (0.5, 0.75, 1.0, 0.3):
+        s = torch.quantile(t.abs(), q, dim=-1).clamp(min=1.0)
+        assert torch.equal(E.clip(t, q), t.clamp(-s, s) / s)
+
+
 LMS_DPM_CASES = [(3, True, 10), (3, True, 9), (2, True, 7), (1, True, 4), (3, False, 10), (2, False, 10)]
 
 
