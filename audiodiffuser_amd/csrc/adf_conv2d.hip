@@ -362,8 +362,10 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
 #pragma unroll
         for (int k = 0; k < NHP; ++k) ra[k] = *(const u32x4_t*)(src + (hoff[k] >= 0 ? hoff[k] * cs + cb : 0));
     };
-    auto store_a = [&](int ck) __attribute__((always_inline)) {
-        char* const st = ldsA;
+    // the prologue (GroupNorm affine + SiLU) of a chunk's halo pieces, in place in their registers.  For the chunks after the first it runs in
+    // the MIDDLE of the previous chunk's nine taps, where the waves have drifted apart and its vector work overlaps other waves' MFMAs; done at the
+    // restage point (tap 8, between two barriers) every wave of the workgroup did it at the same time, with the matrix pipes idle
+    auto transform_a = [&](int ck) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NHP; ++k) {
             const int id = tid + k * NT;
@@ -381,7 +383,16 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
                 }
                 v = pack16<T>(f);
             }
-            *(u32x4_t*)(st + (id >> 3) * kC2Pitch + (id & 7) * 16) = v;
+            ra[k] = v;
+        }
+    };
+    auto store_a = [&]() __attribute__((always_inline)) {
+        char* const st = ldsA;
+#pragma unroll
+        for (int k = 0; k < NHP; ++k) {
+            const int id = tid + k * NT;
+            if (id >= HR * 8) continue;
+            *(u32x4_t*)(st + (id >> 3) * kC2Pitch + (id & 7) * 16) = ra[k];
         }
     };
     // weight slabs travel TWO iterations ahead (one iteration of 8 MFMAs per wave does not cover an L2 round trip), slab j in register set j % 3:
@@ -430,7 +441,8 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
     load_w(nit > 1 ? 1 : 0, rwv[1]);
     __syncthreads();                                   // the prologue table is in LDS
     C2_STAMP(1);
-    store_a(0);
+    transform_a(0);
+    store_a();
     store_w(0, rwv[0]);
     __syncthreads();
     C2_STAMP(2);
@@ -501,9 +513,10 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
             }
         }
         store_w(it + 1, rwv[(tap + 1) % 3]);                          // (after the last iteration: a stage nobody reads any more)
+        if (tap == 4 && ck + 1 < a.nchunk) transform_a(ck + 1);       // the halo loaded at tap 0 has landed; registers only
         if (tap == 8 && ck + 1 < a.nchunk) {                          // every wave must have left this chunk's halo before it is replaced
             __syncthreads();
-            store_a(ck + 1);
+            store_a();
         }
         if (!(ADF_C2_KNOCK & 8)) __syncthreads();
     };
