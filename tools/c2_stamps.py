@@ -20,7 +20,7 @@ buf = (C.c_ulonglong * 128)()
 fn = hd.lib.adf_debug_c2_stamps
 fn.restype = C.c_int
 print("copy rc", fn(buf))
-names = ["entry", "first loads issued + table barrier", "first stage stored", "iteration 0 done", "iteration 1 done", "iteration 9 done", "loop done", "tile in LDS", "end"]
+names = ["entry", "first loads issued + table barrier", "first stage stored", "chunk 0 done (9 taps)", "(unused)", "chunk 1 done", "loop done", "tile in LDS", "end"]
 t0 = min(buf[w * 16] for w in range(8) if buf[w * 16])
 print("%-36s" % "point" + "".join("%8s" % ("w%d" % w) for w in range(8)))
 for i, nm in enumerate(names):
