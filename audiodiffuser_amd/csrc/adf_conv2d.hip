@@ -601,6 +601,8 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
         // the L2 -> CU rate and bounds the kernel; 256 pixels per workgroup halve it
         static const int big = adf_route_switch("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
         if (big && a.H % 8 == 0 && px / 256 * ny >= 512) return c2_trace("t8x2", a), bf16 ? launch_conv2d_tile<bf16_t, 8, 2>(a, s) : launch_conv2d_tile<float, 8, 2>(a, s);
+        static const int th8w1 = adf_route_switch("ADF_CONV2D_TH8W1", 0); // 8 x 32 pixels on sixteen waves, one workgroup per CU (A/B runs)
+        if (th8w1 && a.H % 8 == 0 && px / 256 * ny >= 256) return c2_trace("t8", a), bf16 ? launch_conv2d_tile<bf16_t, 8, 1>(a, s) : launch_conv2d_tile<float, 8, 1>(a, s);
         static const int wr2 = adf_route_switch("ADF_CONV2D_WR2", 0);     // 64 x 64 wave tiles on four waves (A/B runs)
         if (wr2 && a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4x2", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 2>(a, s) : launch_conv2d_tile<float, 4, 2>(a, s);
         if (a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 1>(a, s) : launch_conv2d_tile<float, 4, 1>(a, s);
