@@ -377,9 +377,11 @@ typedef __attribute__((ext_vector_type(16))) float att_f32x16_t;
 
 //   * a wave walks `qrep` query tiles of its pair one after the other: the transposed copy of V is staged once per
 //     wpp * qrep query tiles (at N = 1024 the staging was ~1/6 of a block's time with one tile per wave).
+template <int D>
 __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
                                                                 int C, int heads, float scale_log2e, int qrep) {
-    constexpr int D = 32;
+    constexpr int DT = D / 32, DK = D / 16;      // output tiles of 32 head dims, K steps of the score GEMM (head dim 32 or 64)
+    constexpr bool kSplitP = D == 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -401,8 +403,8 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
     {
         const int tl = (wave % wpp) * 64 + lane, nthr = wpp * 64;
         const bf16_t* vb = base + 2 * C;
-        for (int idx = tl; idx < npad * 4; idx += nthr) {
-            const int key = idx >> 2, c = idx & 3;
+        for (int idx = tl; idx < npad * (D / 8); idx += nthr) {
+            const int key = idx / (D / 8), c = idx % (D / 8);
             const int krow = key < N ? key : N - 1;                 // padded keys: any finite value (their probability is 0)
             const u32x4_t v = *(const u32x4_t*)(vb + (size_t)krow * rowstride + c * 8);
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -421,22 +423,24 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
     // ---- Q^T fragments (B operand), query = qt*32 + r ----------------------------------------------------
     const int query = qt * 32 + r;
     const int qrow = query < N ? query : N - 1;
-    att_bf16x8_t qf[2];
+    att_bf16x8_t qf[DK];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < DK; ++ks)
         qf[ks] = __builtin_bit_cast(att_bf16x8_t, *(const u32x4_t*)(base + (size_t)qrow * rowstride + ks * 16 + hh * 8));
-    att_f32x16_t o;
+    att_f32x16_t o[DT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
     float m = -INFINITY, l = 0.f;                       // running maximum in the scaled log2 domain (s * c), running sum
     // K fragments (A operand: lane = key) straight from global, one tile ahead of their use
-    auto load_k = [&](int kt, u32x4_t (&kq)[2]) __attribute__((always_inline)) {
+    auto load_k = [&](int kt, u32x4_t (&kq)[DK]) __attribute__((always_inline)) {
         const int key_r = kt * 32 + r;
         const int krow = key_r < N ? key_r : N - 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kq[ks] = *(const u32x4_t*)(kb + (size_t)krow * rowstride + ks * 16 + hh * 8);
+        for (int ks = 0; ks < DK; ++ks) kq[ks] = *(const u32x4_t*)(kb + (size_t)krow * rowstride + ks * 16 + hh * 8);
     };
-    u32x4_t kcur[2], knext[2];
+    u32x4_t kcur[DK], knext[DK];
     load_k(0, kcur);
     for (int kt = 0; kt < qtiles; ++kt) {
         load_k(kt + 1 < qtiles ? kt + 1 : kt, knext);
@@ -444,9 +448,10 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < DK; ++ks)
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8_t, kcur[ks]), qf[ks], st, 0, 0, 0);
-        kcur[0] = knext[0]; kcur[1] = knext[1];
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) kcur[ks] = knext[ks];
         if (kt == qtiles - 1 && (N & 31)) {               // uniform: the partial key tile
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -463,7 +468,9 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
             l *= alpha;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[e] *= alpha;
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
             m = mn;
         }
         float psum = 0.f;
@@ -473,16 +480,36 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
         l += psum;
 #pragma unroll
         for (int sgrp = 0; sgrp < 2; ++sgrp) {
-            u32x4_t pw, vw;
+            u32x4_t pw;
             pw.x = pack_bf16x2(st[8 * sgrp + 0], st[8 * sgrp + 1]);
             pw.y = pack_bf16x2(st[8 * sgrp + 2], st[8 * sgrp + 3]);
             pw.z = pack_bf16x2(st[8 * sgrp + 4], st[8 * sgrp + 5]);
             pw.w = pack_bf16x2(st[8 * sgrp + 6], st[8 * sgrp + 7]);
-            // V^T fragment: elements j = 0 .. 3 = keys 16 s + 4 h + j, j = 4 .. 7 = keys 16 s + 8 + 4 h + (j - 4)
-            const u32x2_t v0 = *(const u32x2_t*)(vrow + (kt * 32 + 16 * sgrp) * 2);
-            const u32x2_t v1 = *(const u32x2_t*)(vrow + (kt * 32 + 16 * sgrp + 8) * 2);
-            vw.x = v0.x; vw.y = v0.y; vw.z = v1.x; vw.w = v1.y;
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8_t, vw), __builtin_bit_cast(att_bf16x8_t, pw), o, 0, 0, 0);
+            // head dim 64 (the ADM attention blocks): the probabilities go to the matrix cores as bf16 hi + bf16 lo (two MFMAs), i.e. with ~16 mantissa
+            // bits -- a single bf16 P costs ~1e-3 of the output (it flips the bf16 rounding of a quarter of the stored elements), which the head-dim-32
+            // path of the 1-D nets accepts and the bf16-storage oracle models; here the oracle keeps its fp32 probabilities
+            u32x4_t pl = u32x4_t{0u, 0u, 0u, 0u};
+            if constexpr (kSplitP) {
+                const unsigned hw[4] = {pw.x, pw.y, pw.z, pw.w};
+                unsigned lw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float h0 = __uint_as_float(hw[j] << 16), h1 = __uint_as_float(hw[j] & 0xffff0000u);
+                    lw[j] = pack_bf16x2(st[8 * sgrp + 2 * j] - h0, st[8 * sgrp + 2 * j + 1] - h1);
+                }
+                pl = u32x4_t{lw[0], lw[1], lw[2], lw[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                // V^T fragment of head dims 32 t + r: elements j = 0 .. 3 = keys 16 s + 4 h + j, j = 4 .. 7 = keys 16 s + 8 + 4 h + (j - 4)
+                u32x4_t vw;
+                const u32x2_t v0 = *(const u32x2_t*)(vrow + t * 32 * pitch + (kt * 32 + 16 * sgrp) * 2);
+                const u32x2_t v1 = *(const u32x2_t*)(vrow + t * 32 * pitch + (kt * 32 + 16 * sgrp + 8) * 2);
+                vw.x = v0.x; vw.y = v0.y; vw.z = v1.x; vw.w = v1.y;
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8_t, vw), __builtin_bit_cast(att_bf16x8_t, pw), o[t], 0, 0, 0);
+                if constexpr (kSplitP)
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8_t, vw), __builtin_bit_cast(att_bf16x8_t, pl), o[t], 0, 0, 0);
+            }
         }
     }
     l += __shfl_xor(l, 32, 64);
@@ -490,12 +517,14 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
     if (query < N) {
         bf16_t* orow = out + ((size_t)b * N + query) * C + (size_t)hd * D;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {    // registers 4g..4g+3 = head dims 8g + 4hh .. +3
-            uint2 w;
-            w.x = pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv);
-            w.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-            *(uint2*)(orow + 8 * g + 4 * hh) = w;
-        }
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {    // registers 4g..4g+3 of tile t = head dims 32 t + 8g + 4hh .. +3
+                uint2 w;
+                w.x = pack_bf16x2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv);
+                w.y = pack_bf16x2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+                *(uint2*)(orow + t * 32 + 8 * g + 4 * hh) = w;
+            }
     }
     }
 }
@@ -520,7 +549,8 @@ static const char* attention_dispatch(const void* qkv, void* out, int B, int N, 
 
 const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N, int C, int heads, hipStream_t s) {
     if (C % heads) return "attention: C % heads != 0";
-    if (bf16 && C / heads == 32 && N <= 1024 && N >= 1) {
+    const int dh_ = C / heads;
+    if (bf16 && (dh_ == 32 || dh_ == 64) && N >= 1 && N <= (dh_ == 32 ? 1024 : 512)) {        // V^T of a pair in LDS: dh x (N padded to 32) bf16 <= 72 KB
         const int qtiles = (N + 31) / 32;
         const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);
         const int ppb = 4 / wpp;
@@ -528,16 +558,21 @@ const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N,
         const int qrep = (qtiles >= 8 && (long long)B * heads * (qtiles / 8) >= 1024) ? 2 : 1;
         const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
         const long long blocks = (long long)((B * heads + ppb - 1) / ppb) * qgroups;
-        const size_t lds = (size_t)ppb * 32 * ((size_t)qtiles * 64 + 8);       // vt[32][keys padded to 32] + 8 bytes of row padding, per pair
-        static bool attr_done[kMaxDevices] = {};
-        bool& attr = attr_done[current_device()];
+        const size_t lds = (size_t)ppb * dh_ * ((size_t)qtiles * 64 + 8);      // vt[dh][keys padded to 32] + 8 bytes of row padding, per pair
+        if (lds > 72 * 1024) return "attention_mfma: V^T does not fit LDS";
+        static bool attr_done[kMaxDevices][2] = {};
+        bool& attr = attr_done[current_device()][dh_ == 64];
+        const void* fn = dh_ == 32 ? (const void*)attention_mfma32_kernel<32> : (const void*)attention_mfma32_kernel<64>;
         if (!attr) {
-            if (hipFuncSetAttribute((const void*)attention_mfma32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
                 return "attention_mfma: hipFuncSetAttribute failed";
             attr = true;
         }
-        hipLaunchKernelGGL(attention_mfma32_kernel, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C,
-                           heads, (float)(1.4426950408889634 / sqrt(32.0)), qrep);
+        const float sl2e = (float)(1.4426950408889634 / sqrt((double)dh_));
+        if (dh_ == 32)
+            hipLaunchKernelGGL(attention_mfma32_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C, heads, sl2e, qrep);
+        else
+            hipLaunchKernelGGL(attention_mfma32_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C, heads, sl2e, qrep);
         return ADF_LAUNCH_CHECK("attention_mfma");
     }
     return bf16 ? attention_dispatch<bf16_t>(qkv, out, B, N, C, heads, s) : attention_dispatch<float>(qkv, out, B, N, C, heads, s);

@@ -128,6 +128,12 @@ def channel_layer_norm(x: torch.Tensor, g: torch.Tensor, eps: float = 1e-5) -> t
     return (x - mean) * (var + eps).rsqrt() * g
 
 
+def mfma_attention(d: int, n: int) -> bool:
+    """The shapes whose probabilities launch_attention (adf_kernels.hip) feeds to the matrix cores as ONE bf16: head dim 32 up to 1024 tokens
+    (head dim 64 goes through the same kernel with bf16 hi + lo probabilities, i.e. the fp32 arithmetic of this restatement)."""
+    return d == 32 and n <= 1024
+
+
 def self_attention(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP32, rec=None) -> torch.Tensor:
     """src/models/backbones/attention_utils.py:113-184, plain self-attention branch
     (no context, no RoPE, no mask).  x: [B, N, C].
@@ -146,10 +152,10 @@ def self_attention(p: P, pre: str, x: torch.Tensor, heads: int, q: Storage = FP3
     qq, k, v = (z.reshape(b, n, heads, d).permute(0, 2, 1, 3) for z in (qq, k, v))
     sim = torch.matmul(qq, k.transpose(-1, -2)) * (d ** -0.5)
     if q.bf16:
-        # the device's MFMA kernel (head dim 32, <= 1024 tokens) feeds the probabilities to the matrix cores as bf16; its
-        # vector kernel (other head sizes) keeps them in fp32
+        # the device's MFMA kernel at head dim 32 (<= 1024 tokens) feeds the probabilities to the matrix cores as one bf16; the other paths keep
+        # (or, at head dim 64, reconstruct) their fp32 value
         pr = torch.exp(sim - sim.amax(dim=-1, keepdim=True))
-        pv = q.r(pr) if (d == 32 and n <= 1024) else pr
+        pv = q.r(pr) if mfma_attention(d, n) else pr
         o = torch.matmul(pv, v) / pr.sum(dim=-1, keepdim=True)
     else:
         attn = sim.softmax(dim=-1, dtype=torch.float32)

@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from .unet1d import label_embedding, Storage, FP32, rel_l2
+from .unet1d import label_embedding, Storage, FP32, rel_l2, mfma_attention
 
 P = Dict[str, torch.Tensor]
 Spec = Tuple[Tuple[int, ...], str]
@@ -104,9 +104,11 @@ def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: 
     return skip + h
 
 
-def qkv_attention(qkv: torch.Tensor, heads: int, legacy: bool) -> torch.Tensor:
+def qkv_attention(qkv: torch.Tensor, heads: int, legacy: bool, st: Optional["Storage"] = None) -> torch.Tensor:
     """:324-350 (legacy: heads split first, each head's rows are q|k|v) and :352-380 (new order: q|k|v split first).
-    Both scale q and k by ch^-1/4 and take the softmax in fp32."""
+    Both scale q and k by ch^-1/4 and take the softmax in fp32.  bf16 storage (``st``) on the shapes the device serves with its MFMA attention
+    kernel: the un-normalised probabilities are rounded as the matrix operand of P V while the normaliser sums the unrounded ones (as
+    oracle/unet1d.py self_attention)."""
     b, width, n = qkv.shape
     ch = width // (3 * heads)
     if legacy:
@@ -115,6 +117,9 @@ def qkv_attention(qkv: torch.Tensor, heads: int, legacy: bool) -> torch.Tensor:
         q, k, v = (t.reshape(b * heads, ch, n) for t in qkv.chunk(3, dim=1))
     scale = 1 / math.sqrt(math.sqrt(ch))
     w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    if st is not None and st.bf16 and mfma_attention(ch, n):
+        pr = torch.exp(w.float() - w.float().amax(dim=-1, keepdim=True))
+        return (torch.einsum("bts,bcs->bct", st.r(pr), v) / pr.sum(dim=-1).unsqueeze(1)).reshape(b, -1, n)
     w = torch.softmax(w.float(), dim=-1)
     return torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, n)
 
@@ -136,7 +141,7 @@ def attention_block(p: P, l: _Layer, x: torch.Tensor, heads: int, legacy: bool, 
             qkv = dev.permute(0, 2, 1, 3, 4).reshape(b, 3 * c, -1)
         else:
             qkv = rec(".qkv", qkv.reshape(b, 3 * c, *sp[2:])).reshape(b, 3 * c, -1)
-    h = rec(".att", q.r(qkv_attention(qkv, heads, legacy)).reshape(sp)).reshape(b, c, -1)
+    h = rec(".att", q.r(qkv_attention(qkv, heads, legacy, q)).reshape(sp)).reshape(b, c, -1)
     wp = q.w(p[f"{l.pre}.proj_out.weight"]) if q.bf16 else p[f"{l.pre}.proj_out.weight"]
     h = q.r(F.conv1d(h, wp, p[f"{l.pre}.proj_out.bias"]))
     return q.r(xn + h).reshape(x.shape)
