@@ -233,6 +233,45 @@ def adm_conv_flops(cfg, batch, H, W):
     return fl * batch
 
 
+def adm_pass_bytes(cfg, batch, H, W, esize=2):
+    """Algorithmic HBM bytes of one UNetModel pass: every conv / projection launch reads its input tensor(s) once, writes its output once (a
+    residual operand is one more read) and reads its weights once; GroupNorm tables and statistics are negligible.  Same walk as adm_conv_flops."""
+    from audiodiffuser_amd.adm_config import structure
+    s = structure(cfg)
+    by = 0.0
+    def conv(h_in, w_in, cin, h, w, cout, taps, res=False):
+        return (h_in * w_in * cin + h * w * cout * (2 if res else 1)) * esize * batch + taps * cin * cout * esize
+    def run(layers, h, w):
+        nonlocal by
+        for l in layers:
+            if l.kind == "conv":
+                by += conv(h, w, l.cin, h, w, l.cout, 9)
+            elif l.kind == "res":
+                by += conv(h, w, l.cin, h, w, l.cout, 9) + conv(h, w, l.cout, h, w, l.cout, 9, res=True)
+                if l.cin != l.cout:
+                    by += conv(h, w, l.cin, h, w, l.cout, 1)
+            elif l.kind == "attn":
+                c = l.cin
+                by += 2 * h * w * c * esize * batch                          # GroupNorm applied (xn)
+                by += conv(h, w, c, h, w, 3 * c, 1) + 4 * h * w * c * esize * batch + conv(h, w, c, h, w, c, 1, res=True)
+            elif l.kind == "down":
+                by += conv(h, w, l.cin, h // 2, w // 2, l.cout, 9)
+                h, w = h // 2, w // 2
+            elif l.kind == "up":
+                by += conv(h, w, l.cin, h * 2, w * 2, l.cout, 9)
+                h, w = h * 2, w * 2
+        return h, w
+    h, w = H, W
+    by += (H * W * cfg.in_channels * 4 + H * W * s.input_ch * esize) * batch      # first conv: fp32 planes in, channels-last out
+    for blk in s.input_blocks:
+        h, w = run([l for l in blk if not (l.kind == "conv" and l.cin == cfg.in_channels)], h, w)
+    h, w = run(s.middle, h, w)
+    for blk in s.output_blocks:
+        h, w = run(blk, h, w)
+    by += (h * w * s.input_ch * esize + 2 * h * w * cfg.out_channels * 4) * batch   # last conv: reads h, reads x_noisy, writes fp32 planes
+    return by
+
+
 def adm_pass_row(net, cfg, x, device, iters):
     """One eager network pass timed with events on the launch stream (the pass launches on torch's current stream)."""
     import torch
@@ -245,7 +284,8 @@ def adm_pass_row(net, cfg, x, device, iters):
         net(x, t)
     e1.record()
     torch.cuda.synchronize()
-    return {"pass_ms": e0.elapsed_time(e1) / n, "flops": adm_conv_flops(cfg, x.shape[0], x.shape[2], x.shape[3])}
+    return {"pass_ms": e0.elapsed_time(e1) / n, "flops": adm_conv_flops(cfg, x.shape[0], x.shape[2], x.shape[3]),
+            "bytes": adm_pass_bytes(cfg, x.shape[0], x.shape[2], x.shape[3], 2 if str(getattr(net, "compute_dtype", "bf16")) == "bf16" else 4)}
 
 
 def adm_roofline(net, cfg, x, device, dtype):
@@ -255,7 +295,8 @@ def adm_roofline(net, cfg, x, device, dtype):
     return {"bound": "mfma", "kernel": "conv2d_tile_kernel / conv2d_gemm_kernel (implicit GEMM over channels-last pixels), whole network pass",
             "definition": "multiply-add flops x 2 of every conv / projection / attention contraction of one UNetModel pass / the eager pass time (events on the launch "
                           "stream): a per-pass figure, not a single launch (per-layer table: profiles/r02_adm_layer_table.txt)",
-            "level": -1, "conv": 0, "pass_ms": row["pass_ms"], "algorithmic_flops": row["flops"], "mfma_TFLOPs": tfs, "achieved": tfs,
+            "level": -1, "conv": 0, "pass_ms": row["pass_ms"], "algorithmic_flops": row["flops"], "algorithmic_bytes": row["bytes"],
+            "hbm_GBps": row["bytes"] / (row["pass_ms"] * 1e-3) / 1e9, "mfma_TFLOPs": tfs, "achieved": tfs,
             "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS[dtype], "traffic": None}
 
 
@@ -283,6 +324,19 @@ def pmc_traffic(a, level: int, conv: int):
             shutil.rmtree(tmp, ignore_errors=True)
             return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
         per = {}
+        if a.config == "c4":
+            # per network pass: every dispatch from the last conv2d_in_kernel (the first launch of a pass) to the end of the trace
+            allk = {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") == counter:
+                    allk.setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], 0.0])[1] += float(row["Counter_Value"])
+            shutil.rmtree(tmp, ignore_errors=True)
+            ids = sorted(allk)
+            starts = [i for i in ids if "conv2d_in_kernel" in allk[i][0]]
+            if not starts:
+                return None, f"no conv2d_in_kernel dispatch in the {counter} pass"
+            vals[counter] = (sum(allk[i][1] for i in ids if i >= starts[-1]), f"all {sum(1 for i in ids if i >= starts[-1])} dispatches of the last network pass")
+            continue
         for row in csv.DictReader(open(files[0])):
             if row.get("Counter_Name") != counter or ("wn_layer" if a.config == "c5" else "conv_gemm") not in row.get("Kernel_Name", ""):
                 continue
@@ -586,7 +640,7 @@ def main():
         else:
             rf = roofline(hd, a.batch, a.length, a.dtype, a.roofline_iters, device)
         res["roofline"] = rf
-        if rf and world == 1 and not a.no_pmc and not adm:
+        if rf and world == 1 and not a.no_pmc:
             traffic, detail = pmc_traffic(a, rf["level"], rf["conv"])
             rf["traffic"] = traffic
             rf["traffic_source"] = detail
