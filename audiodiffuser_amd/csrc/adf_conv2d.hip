@@ -628,78 +628,100 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ first / last conv
 constexpr int kC2InSweeps = 16;
-template <typename T>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) conv2d_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+// A workgroup covers kC2InSweeps sweeps of 256 / cpr consecutive pixels.  The 9 * cin input values of each of its pixels (c_in applied, zero outside the
+// image) are staged ONCE into LDS by one batch of global loads per thread; every thread of a pixel (one per 16-byte piece of the output row) then
+// reads them from there.  (Read straight from global they were 9 loads per thread and sweep, 16 threads fetching the same values, and the kernel
+// sat at their latency: 0.37 ms for 64 blocks of 80 x 256 against 0.06 ms at the write rate; two and four pixels in flight per thread gave 0.33 / 0.18.)
+template <typename T, int CIN>     // CIN = 1, 2: the thread's weights (its 16-byte piece of the output row x 9 taps x CIN) live in registers; 0: read from LDS per use
+__global__ void __launch_bounds__(256) conv2d_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ out, int B, int cin, int H, int W, int cout,
                                                         const float* __restrict__ coef, int coef_bstride) {
     constexpr int EPC = Elem<T>::kPerChunk;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const ws = (float*)smem;                    // [cin][9][cout] + bias [cout]
+    float* const xs = ws + cin * 9 * cout + cout;      // [pixels of this workgroup][cin][9]
+    const int cpr = cout / EPC, ppb = 256 / cpr;
+    const int npb = ppb * kC2InSweeps;                 // pixels per workgroup
+    const int npix = B * H * W, HW = H * W;
+    const int p0 = blockIdx.x * npb;
+    // stage the inputs: item i = (pixel, channel, tap); all loads of a thread before its first LDS store
+    const int nitem = npb * cin * 9;
+    constexpr int kMaxItems = 12;                      // per thread: 256 pixels x 9 taps x cin / 256 threads = 9 cin (cin = 1: 9)
+    float xv[kMaxItems];
+    for (int base = 0; base < nitem; base += 256 * kMaxItems) {
+#pragma unroll
+        for (int k = 0; k < kMaxItems; ++k) {
+            const int i = base + threadIdx.x + k * 256;
+            const int t = i % 9, ci = (i / 9) % cin, lpix = i / (9 * cin);
+            const int p = p0 + lpix;
+            const int pc = (i < nitem && p < npix) ? p : 0;
+            const int b = pc / HW, pp = pc - b * HW;
+            const int y = pp / W, xx = pp - y * W;
+            const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
+            const bool ok = i < nitem && p < npix && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            const float sc = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
+            const float v = x[((size_t)b * cin + ci) * HW + (ok ? sy * W + sx : 0)];
+            xv[k] = ok ? v * sc : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxItems; ++k) {
+            const int i = base + threadIdx.x + k * 256;
+            if (i < nitem) xs[i] = xv[k];
+        }
+    }
     for (int i = threadIdx.x; i < cout * cin * 9; i += 256) {
         const int t = i % 9, ci = (i / 9) % cin, co = i / (9 * cin);
         ws[(ci * 9 + t) * cout + co] = w[i];
     }
     for (int i = threadIdx.x; i < cout; i += 256) ws[cin * 9 * cout + i] = bias[i];
     __syncthreads();
-    // a workgroup covers kC2InSweeps sweeps of 256 / cpr consecutive pixels (32-bit index arithmetic: the launcher bounds B * H * W)
-    const int cpr = cout / EPC, ppb = 256 / cpr;
     const int cc = threadIdx.x % cpr, lp = threadIdx.x / cpr;
-    const int npix = B * H * W, HW = H * W;
     if (lp >= ppb) return;
     float bias_r[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) bias_r[e] = ws[cin * 9 * cout + cc * EPC + e];
-    // U pixels per thread and step (4 would take 269 registers): the 9 * U input loads are in flight together (one pixel at a time, the kernel sat at the latency of
-    // nine dependent-free but un-overlapped loads per 16-byte store: 0.33 ms for 64 blocks of 80 x 256 against 0.06 at the write rate)
-    constexpr int U = 2;
-    static_assert(kC2InSweeps % U == 0, "whole steps");
-    for (int sw = 0; sw < kC2InSweeps; sw += U) {
-        int pu[U];
-        float scu[U];
+    // (with the weights read from LDS for every pixel -- 18 ds_read_b128 per thread and sweep -- the LDS reads bounded the kernel at 0.35 ms)
+    constexpr int WR = CIN > 0 ? CIN : 1;
+    float wreg[WR][9][EPC];
+    if constexpr (CIN > 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            pu[u] = (blockIdx.x * kC2InSweeps + sw + u) * ppb + lp;
-            const int pc = pu[u] < npix ? pu[u] : npix - 1;
-            scu[u] = coef ? coef[(size_t)(pc / HW) * coef_bstride] : 1.0f;
-        }
-        float f[U][EPC];
+        for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[u][e] = bias_r[e];
-        for (int ci = 0; ci < cin; ++ci) {
-            float v[U][9];
+                for (int e = 0; e < EPC; ++e) wreg[ci][t][e] = ws[(ci * 9 + t) * cout + cc * EPC + e];
+    }
+    for (int sw = 0; sw < kC2InSweeps; ++sw) {
+        const int lpix = sw * ppb + lp;
+        const int p = p0 + lpix;
+        if (p >= npix) return;
+        float f[EPC];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pc = pu[u] < npix ? pu[u] : npix - 1;
-                const int b = pc / HW, pp = pc - b * HW;
-                const int y = pp / W, xx = pp - y * W;
-                const float* const xb = x + ((size_t)b * cin + ci) * HW;
+        for (int e = 0; e < EPC; ++e) f[e] = bias_r[e];
+        if constexpr (CIN > 0) {
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float* const xp = xs + (lpix * CIN + ci) * 9;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
-                    const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
-                    v[u][t] = xb[ok ? sy * W + sx : pp];
-                    if (!ok) v[u][t] = 0.0f;
+                    const float vs = xp[t];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[e] = fmaf(wreg[ci][t][e], vs, f[e]);
                 }
             }
+        } else {
+            for (int ci = 0; ci < cin; ++ci) {
+                const float* const xp = xs + (lpix * cin + ci) * 9;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float* const wp = ws + (ci * 9 + t) * cout + cc * EPC;
-                float wr[EPC];
+                for (int t = 0; t < 9; ++t) {
+                    const float vs = xp[t];
+                    const float* const wp = ws + (ci * 9 + t) * cout + cc * EPC;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) wr[e] = wp[e];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float vs = v[u][t] * scu[u];
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) f[u][e] = fmaf(wr[e], vs, f[u][e]);
+                    for (int e = 0; e < EPC; ++e) f[e] = fmaf(wp[e], vs, f[e]);
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (pu[u] < npix) *(u32x4_t*)(out + (size_t)pu[u] * cout + cc * EPC) = pack16<T>(f[u]);
+        *(u32x4_t*)(out + (size_t)p * cout + cc * EPC) = pack16<T>(f);
     }
 }
 const char* launch_conv2d_in(const float* x, const float* w, const float* bias, void* out, int bf16, int B, int cin, int H, int W, int cout,
@@ -711,10 +733,12 @@ const char* launch_conv2d_in(const float* x, const float* w, const float* bias, 
     if (npix >= (1ll << 31)) return "conv2d_in: more than 2^31 pixels";
     const int per_block = (256 / cpr) * kC2InSweeps;
     const int blocks = (int)((npix + per_block - 1) / per_block);
-    const size_t lds = ((size_t)cout * cin * 9 + cout) * 4;
-    if (lds > 64 * 1024) return "conv2d_in: weights do not fit LDS";
-    if (bf16) hipLaunchKernelGGL(conv2d_in_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, x, w, bias, (bf16_t*)out, B, cin, H, W, cout, coef, coef_bstride);
-    else hipLaunchKernelGGL(conv2d_in_kernel<float>, dim3(blocks), dim3(256), lds, s, x, w, bias, (float*)out, B, cin, H, W, cout, coef, coef_bstride);
+    const size_t lds = ((size_t)cout * cin * 9 + cout + (size_t)per_block * cin * 9) * 4;
+    if (lds > 64 * 1024) return "conv2d_in: weights and the staged inputs do not fit LDS";
+#define ADF_C2IN(T_, CI_) hipLaunchKernelGGL((conv2d_in_kernel<T_, CI_>), dim3(blocks), dim3(256), lds, s, x, w, bias, (T_*)out, B, cin, H, W, cout, coef, coef_bstride)
+    if (bf16) { if (cin == 1) ADF_C2IN(bf16_t, 1); else if (cin == 2) ADF_C2IN(bf16_t, 2); else ADF_C2IN(bf16_t, 0); }
+    else { if (cin == 1) ADF_C2IN(float, 1); else if (cin == 2) ADF_C2IN(float, 2); else ADF_C2IN(float, 0); }
+#undef ADF_C2IN
     return C2_LAUNCH_CHECK("conv2d_in");
 }
 
