@@ -1125,9 +1125,9 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
             if (W.bad) break;
             if (l.kind == 0) {
                 T2 y; y.H = x.H; y.W = x.W; y.t = W.new_act(a.input_ch, x.H * x.W);
-                if (W.live()) W.check(launch_conv2d_in(io.x, a.in_w, a.in_b, y.t.p, h->bf16, B, c.in_channels, x.H, x.W, a.input_ch, io.coef, io.coef_bstride, s));
+                y.st = alloc_fine(a.input_ch);   // here, so that the copy pushed on the skip stack carries them (the last output block reads them again)
+                if (W.live()) W.check(launch_conv2d_in(io.x, a.in_w, a.in_b, y.t.p, h->bf16, B, c.in_channels, x.H, x.W, a.input_ch, io.coef, io.coef_bstride, y.st, fg, s));
                 x = y;
-                ensure_stats(x.t, x.st);      // here, so that the copy pushed on the skip stack carries them (the last output block reads them again)
                 W.tap(ln, x.t);
             } else if (l.kind == 1) {                                  // ResBlock._forward, :248-272 (scale-shift form)
                 const AdmRes& r = a.res[l.idx];

@@ -32,9 +32,11 @@ struct Conv2dArgs {
 };
 const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s);
 
-// First conv (:467-469) straight from the fp32 [B][Cin][H][W] input with the EDM c_in scaling fused (Cin small: vector kernel).
+// First conv (:467-469) straight from the fp32 [B][Cin][H][W] input with the EDM c_in scaling fused (Cin small: vector kernel).  stats (optional,
+// pre-zeroed [B][cout / fg][2]): the FINE GroupNorm statistics of the stored output, reduced in the store when a workgroup's pixels lie in one
+// sample, by launch_gn_stats_any behind it otherwise.
 const char* launch_conv2d_in(const float* x, const float* w, const float* bias, void* out, int bf16, int B, int cin, int H, int W, int cout,
-                             const float* coef, int coef_bstride, hipStream_t s);
+                             const float* coef, int coef_bstride, double* stats, int fg, hipStream_t s);
 // Last conv (:596-600): SiLU(GroupNorm(h)) -> 3x3 conv to a few channels, written as fp32 [B][Cout][H][W], + the EDM epilogue
 // (mode 1: clamp(c_skip * x_noisy + c_out * F, -1, 1)).
 const char* launch_conv2d_out(const void* h, const float* ab, const float* w, const float* bias, float* out, int bf16, int B, int cin, int H,

@@ -628,6 +628,7 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ first / last conv
 constexpr int kC2InSweeps = 16;
+constexpr int kC2InRounds = 4;      // stagings per workgroup (weights staged and statistics flushed once for all of them)
 // A workgroup covers kC2InSweeps sweeps of 256 / cpr consecutive pixels.  The 9 * cin input values of each of its pixels (c_in applied, zero outside the
 // image) are staged ONCE into LDS by one batch of global loads per thread; every thread of a pixel (one per 16-byte piece of the output row) then
 // reads them from there.  (Read straight from global they were 9 loads per thread and sweep, 16 threads fetching the same values, and the kernel
@@ -635,40 +636,18 @@ constexpr int kC2InSweeps = 16;
 template <typename T, int CIN>     // CIN = 1, 2: the thread's weights (its 16-byte piece of the output row x 9 taps x CIN) live in registers; 0: read from LDS per use
 __global__ void __launch_bounds__(256) conv2d_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ out, int B, int cin, int H, int W, int cout,
-                                                        const float* __restrict__ coef, int coef_bstride) {
+                                                        const float* __restrict__ coef, int coef_bstride, double* __restrict__ stats, int fg) {
     constexpr int EPC = Elem<T>::kPerChunk;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const ws = (float*)smem;                    // [cin][9][cout] + bias [cout]
     float* const xs = ws + cin * 9 * cout + cout;      // [pixels of this workgroup][cin][9]
     const int cpr = cout / EPC, ppb = 256 / cpr;
     const int npb = ppb * kC2InSweeps;                 // pixels per workgroup
+    float* const st = xs + npb * cin * 9;              // [2][cout]: sums / sums of squares of this workgroup's stored outputs (stats != nullptr)
+    if (stats)
+        for (int i = threadIdx.x; i < 2 * cout; i += 256) st[i] = 0.f;
     const int npix = B * H * W, HW = H * W;
-    const int p0 = blockIdx.x * npb;
-    // stage the inputs: item i = (pixel, channel, tap); all loads of a thread before its first LDS store
-    const int nitem = npb * cin * 9;
-    constexpr int kMaxItems = 12;                      // per thread: 256 pixels x 9 taps x cin / 256 threads = 9 cin (cin = 1: 9)
-    float xv[kMaxItems];
-    for (int base = 0; base < nitem; base += 256 * kMaxItems) {
-#pragma unroll
-        for (int k = 0; k < kMaxItems; ++k) {
-            const int i = base + threadIdx.x + k * 256;
-            const int t = i % 9, ci = (i / 9) % cin, lpix = i / (9 * cin);
-            const int p = p0 + lpix;
-            const int pc = (i < nitem && p < npix) ? p : 0;
-            const int b = pc / HW, pp = pc - b * HW;
-            const int y = pp / W, xx = pp - y * W;
-            const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
-            const bool ok = i < nitem && p < npix && sy >= 0 && sy < H && sx >= 0 && sx < W;
-            const float sc = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
-            const float v = x[((size_t)b * cin + ci) * HW + (ok ? sy * W + sx : 0)];
-            xv[k] = ok ? v * sc : 0.0f;
-        }
-#pragma unroll
-        for (int k = 0; k < kMaxItems; ++k) {
-            const int i = base + threadIdx.x + k * 256;
-            if (i < nitem) xs[i] = xv[k];
-        }
-    }
+    const int p00 = blockIdx.x * npb * kC2InRounds;
     for (int i = threadIdx.x; i < cout * cin * 9; i += 256) {
         const int t = i % 9, ci = (i / 9) % cin, co = i / (9 * cin);
         ws[(ci * 9 + t) * cout + co] = w[i];
@@ -676,7 +655,7 @@ __global__ void __launch_bounds__(256) conv2d_in_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < cout; i += 256) ws[cin * 9 * cout + i] = bias[i];
     __syncthreads();
     const int cc = threadIdx.x % cpr, lp = threadIdx.x / cpr;
-    if (lp >= ppb) return;
+    const int nsw = lp < ppb ? kC2InSweeps : 0;        // (no early return: the statistics tail below has a barrier)
     float bias_r[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) bias_r[e] = ws[cin * 9 * cout + cc * EPC + e];
@@ -691,55 +670,117 @@ __global__ void __launch_bounds__(256) conv2d_in_kernel(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) wreg[ci][t][e] = ws[(ci * 9 + t) * cout + cc * EPC + e];
     }
-    for (int sw = 0; sw < kC2InSweeps; ++sw) {
-        const int lpix = sw * ppb + lp;
-        const int p = p0 + lpix;
-        if (p >= npix) return;
-        float f[EPC];
+    float a1[EPC], a2[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) f[e] = bias_r[e];
-        if constexpr (CIN > 0) {
+    for (int e = 0; e < EPC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    for (int rd = 0; rd < kC2InRounds; ++rd) {         // the workgroup's weights and statistics serve kC2InRounds stagings
+        const int p0 = p00 + rd * npb;
+        if (p0 >= npix) break;
+        if (rd) __syncthreads();                       // every thread is done with the previous round's inputs
+        // stage the inputs: item i = (pixel, channel, tap); all loads of a thread before its first LDS store
+        const int nitem = npb * cin * 9;
+        constexpr int kMaxItems = 12;                  // per thread: 256 pixels x 9 taps x cin / 256 threads = 9 cin (cin = 1: 9)
+        float xv[kMaxItems];
+        for (int base = 0; base < nitem; base += 256 * kMaxItems) {
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) {
-                const float* const xp = xs + (lpix * CIN + ci) * 9;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float vs = xp[t];
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) f[e] = fmaf(wreg[ci][t][e], vs, f[e]);
-                }
+            for (int k = 0; k < kMaxItems; ++k) {
+                const int i = base + threadIdx.x + k * 256;
+                const int t = i % 9, ci = (i / 9) % cin, lpix = i / (9 * cin);
+                const int p = p0 + lpix;
+                const int pc = (i < nitem && p < npix) ? p : 0;
+                const int b = pc / HW, pp = pc - b * HW;
+                const int y = pp / W, xx = pp - y * W;
+                const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
+                const bool ok = i < nitem && p < npix && sy >= 0 && sy < H && sx >= 0 && sx < W;
+                const float sc = coef ? coef[(size_t)b * coef_bstride] : 1.0f;
+                const float v = x[((size_t)b * cin + ci) * HW + (ok ? sy * W + sx : 0)];
+                xv[k] = ok ? v * sc : 0.0f;
             }
-        } else {
-            for (int ci = 0; ci < cin; ++ci) {
-                const float* const xp = xs + (lpix * cin + ci) * 9;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float vs = xp[t];
-                    const float* const wp = ws + (ci * 9 + t) * cout + cc * EPC;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) f[e] = fmaf(wp[e], vs, f[e]);
-                }
+            for (int k = 0; k < kMaxItems; ++k) {
+                const int i = base + threadIdx.x + k * 256;
+                if (i < nitem) xs[i] = xv[k];
             }
         }
-        *(u32x4_t*)(out + (size_t)p * cout + cc * EPC) = pack16<T>(f);
+        __syncthreads();
+        for (int sw = 0; sw < nsw; ++sw) {
+            const int lpix = sw * ppb + lp;
+            const int p = p0 + lpix;
+            if (p >= npix) break;
+            float f[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = bias_r[e];
+            if constexpr (CIN > 0) {
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float* const xp = xs + (lpix * CIN + ci) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float vs = xp[t];
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] = fmaf(wreg[ci][t][e], vs, f[e]);
+                    }
+                }
+            } else {
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float* const xp = xs + (lpix * cin + ci) * 9;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float vs = xp[t];
+                        const float* const wp = ws + (ci * 9 + t) * cout + cc * EPC;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] = fmaf(wp[e], vs, f[e]);
+                    }
+                }
+            }
+            const u32x4_t pk = pack16<T>(f);
+            *(u32x4_t*)(out + (size_t)p * cout + cc * EPC) = pk;
+            if (stats) {                                   // of the STORED values, as the separate statistics pass reads them
+                float g[EPC];
+                unpack16<T>(pk, g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { a1[e] += g[e]; a2[e] = fmaf(g[e], g[e], a2[e]); }
+            }
+        }
+    }
+    // FINE GroupNorm statistics of the output (sum, sum of squares per fg channels of a sample), what launch_gn_stats_any would reduce in a second
+    // pass over the tensor (0.12 ms at 64 x 80 x 256 x 192): the launcher passes stats only when every workgroup's pixels lie in ONE sample
+    if (stats) {
+        if (nsw) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { atomicAdd(&st[cc * EPC + e], a1[e]); atomicAdd(&st[cout + cc * EPC + e], a2[e]); }
+        }
+        __syncthreads();
+        const int b = p00 / HW, G = cout / fg;
+        for (int g = threadIdx.x; g < G; g += 256) {
+            double d1 = 0.0, d2 = 0.0;
+            for (int c = g * fg; c < (g + 1) * fg; ++c) { d1 += (double)st[c]; d2 += (double)st[cout + c]; }
+            atomicAdd(&stats[((size_t)b * G + g) * 2], d1);
+            atomicAdd(&stats[((size_t)b * G + g) * 2 + 1], d2);
+        }
     }
 }
 const char* launch_conv2d_in(const float* x, const float* w, const float* bias, void* out, int bf16, int B, int cin, int H, int W, int cout,
-                             const float* coef, int coef_bstride, hipStream_t s) {
+                             const float* coef, int coef_bstride, double* stats, int fg, hipStream_t s) {
     if (cout % (bf16 ? 8 : 4)) return "conv2d_in: output channels must be a multiple of a 16-byte chunk";
+    if (stats && (fg < 1 || cout % fg)) return "conv2d_in: the statistics group must divide the output channels";
     const int cpr = cout / (bf16 ? 8 : 4);
     if (cpr > 256) return "conv2d_in: more than 256 16-byte pieces per output pixel";
     const long long npix = (long long)B * H * W;
     if (npix >= (1ll << 31)) return "conv2d_in: more than 2^31 pixels";
     const int per_block = (256 / cpr) * kC2InSweeps;
-    const int blocks = (int)((npix + per_block - 1) / per_block);
-    const size_t lds = ((size_t)cout * cin * 9 + cout + (size_t)per_block * cin * 9) * 4;
+    const int blocks = (int)((npix + (long long)per_block * kC2InRounds - 1) / ((long long)per_block * kC2InRounds));
+    const size_t lds = ((size_t)cout * cin * 9 + cout + (size_t)per_block * cin * 9 + 2 * (size_t)cout) * 4;
     if (lds > 64 * 1024) return "conv2d_in: weights and the staged inputs do not fit LDS";
-#define ADF_C2IN(T_, CI_) hipLaunchKernelGGL((conv2d_in_kernel<T_, CI_>), dim3(blocks), dim3(256), lds, s, x, w, bias, (T_*)out, B, cin, H, W, cout, coef, coef_bstride)
+    // the statistics ride in the store when no workgroup straddles two samples; otherwise the separate pass over the stored tensor follows
+    double* const fused = stats && ((long long)H * W) % ((long long)per_block * kC2InRounds) == 0 ? stats : nullptr;
+#define ADF_C2IN(T_, CI_) hipLaunchKernelGGL((conv2d_in_kernel<T_, CI_>), dim3(blocks), dim3(256), lds, s, x, w, bias, (T_*)out, B, cin, H, W, cout, coef, coef_bstride, fused, fg)
     if (bf16) { if (cin == 1) ADF_C2IN(bf16_t, 1); else if (cin == 2) ADF_C2IN(bf16_t, 2); else ADF_C2IN(bf16_t, 0); }
     else { if (cin == 1) ADF_C2IN(float, 1); else if (cin == 2) ADF_C2IN(float, 2); else ADF_C2IN(float, 0); }
 #undef ADF_C2IN
-    return C2_LAUNCH_CHECK("conv2d_in");
+    if (const char* e = C2_LAUNCH_CHECK("conv2d_in")) return e;
+    if (stats && !fused) return launch_gn_stats_any(out, bf16, B, H * W, cout, cout / fg, stats, s);
+    return nullptr;
 }
 
 constexpr int kC2OutMax = 4;        // output channels of the last conv served by the vector kernel
