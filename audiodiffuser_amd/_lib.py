@@ -66,8 +66,18 @@ class AdfAdmConfig(C.Structure):
                 ("resblock_updown", C.c_int32), ("use_new_attention_order", C.c_int32), ("num_classes", C.c_int32), ("dtype", C.c_int32)]
 
 
+class AdfRunCounters(C.Structure):
+    """``adf_run_counters`` of include/audiodiffuser_amd.h."""
+    _fields_ = [("sampler_runs", C.c_int64), ("sampler_evals", C.c_int64), ("graph_captures", C.c_int64),
+                ("graph_replays", C.c_int64), ("denoise_calls", C.c_int64), ("net_passes", C.c_int64)]
+
+
+ABI_VERSION = 3          # ADF_ABI_VERSION of the header this binding was written against
+
 EXPORTS = {
     # name: (restype, argtypes)
+    "adf_abi_version": (C.c_int, []),
+    "adf_get_counters": (C.c_int, [C.c_void_p, C.POINTER(AdfRunCounters)]),
     "adf_create": (C.c_int, [C.POINTER(AdfNetConfig), C.POINTER(C.c_void_p)]),
     "adf_wavenet_create": (C.c_int, [C.POINTER(AdfWaveNetConfig), C.POINTER(C.c_void_p)]),
     "adf_adm_create": (C.c_int, [C.POINTER(AdfAdmConfig), C.POINTER(C.c_void_p)]),
@@ -118,6 +128,10 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.adf_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this binding was written against {ABI_VERSION}: rebuild the "
+                           "library (python -m audiodiffuser_amd.build --force)")
     _lib = lib
     return lib
 

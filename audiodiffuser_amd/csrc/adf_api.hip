@@ -161,7 +161,9 @@ struct adf_handle {
     ResW mid_pre, mid_post;
     TrW mid_tr;
     std::vector<UpW> ups;
-    std::map<std::pair<int, int>, Plan*> plans;
+    // (B, L, H): H = image height of a UNetModel handle (W = L / H), 0 otherwise -- two image shapes with equal H * W must not share
+    // a workspace: captured graphs and tap shapes carry the conv2d geometry
+    std::map<std::tuple<int, int, int>, Plan*> plans;
     Plan* last_plan = nullptr;
     WnW* wn = nullptr;                  // non-null: the handle is a WaveNetNoise (adf_wavenet_create), not a UNet1dBase
     AdmW* adm = nullptr;                // non-null: the handle is an ADM-style UNetModel (adf_adm_create)
@@ -169,6 +171,7 @@ struct adf_handle {
     // default stream, which cannot be captured); it is fenced against the caller's stream with events
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    adf_run_counters ctr{};             // what the device loop has done so far (adf_get_counters): lets a test tell it from a host-side loop
 };
 
 namespace {
@@ -658,6 +661,7 @@ int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
 int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
 
 int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
+    if (!p->dry) ++h->ctr.net_passes;
     if (h->wn) return wn_forward(h, p, io, s);
     if (h->adm) return adm_forward(h, p, io, s);
     const adf_net_config& c = h->cfg;
@@ -757,7 +761,8 @@ int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
         if (a.H % f || a.W % f || ((a.H / f) * (a.W / f)) % 64)
             return fail(h, "UNetModel: H and W must be multiples of 2^(levels-1) and the coarsest level a multiple of 64 pixels");
     }
-    auto it = h->plans.find({B, L});
+    const std::tuple<int, int, int> pkey{B, L, h->adm ? h->adm->H : 0};
+    auto it = h->plans.find(pkey);
     if (it != h->plans.end()) { *out = it->second; h->last_plan = it->second; it->second->last_use = ++h->use_clock; return 0; }
     Plan* p = new Plan();
     p->B = B; p->L = L;
@@ -796,7 +801,7 @@ int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
         destroy_plan(h, p);
         return fail(h, std::string("warm-up forward failed: ") + hipGetErrorString(hipGetLastError()));
     }
-    h->plans[{B, L}] = p;
+    h->plans[pkey] = p;
     h->last_plan = p;
     p->last_use = ++h->use_clock;
     *out = p;
@@ -873,7 +878,7 @@ int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
     const int B = p->B, T = p->L, C = c.residual_channels, NL = c.residual_layers;
     const size_t act = (size_t)B * T * C * h->esz;
     // every layer input stays resident when that is small (the parity taps y<n>); otherwise two buffers alternate
-    const bool keep = act * (size_t)NL <= ((size_t)256 << 20);
+    const bool keep = act * (size_t)NL <= ((size_t)512 << 20);   // (one bf16 waveform of 22050 samples x 36 layers = 406 MB: the full-size parity test)
     std::vector<void*> ys(keep ? NL : 2);
     for (auto& q : ys) q = W.alloc(act);
     float* const skip = (float*)W.alloc((size_t)B * T * C * 4);
@@ -2086,6 +2091,7 @@ int adf_denoise(adf_handle* h, const float* x_noisy, const float* sigmas_dev, fl
     hipStream_t s = (hipStream_t)stream;
     Plan* p;
     if (get_plan(h, B, L, s, &p)) return 1;
+    ++h->ctr.denoise_calls;
     if (!sigmas_dev) return denoise_scalar(h, p, x_noisy, sigma, sigma_data, out, s);
     if (const char* e = launch_edm_coef(sigmas_dev, 0.f, B, sigma_data, p->coef, s)) return fail(h, e);
     FwdIO io;
@@ -2211,6 +2217,7 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
         if (sigma_table(s)) return 1;
         if (run_sampler(c, &result)) return 1;
         if (hipMemcpyAsync(out, result, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
+        ++h->ctr.sampler_runs; h->ctr.sampler_evals += n_eval;
         return 0;
     }
     if (!h->gstream) {
@@ -2256,11 +2263,21 @@ int adf_sampler_run(adf_handle* h, const adf_sampler_desc* desc, const float* si
         }
         p->graphs.insert(p->graphs.begin(), std::make_pair(key, exec));
         it = p->graphs.begin();
+        ++h->ctr.graph_captures;
     }
     if (hipGraphLaunch(it->second, gs) != hipSuccess) return fail(h, "hipGraphLaunch failed");
     if (hipEventRecord(h->ev_out, gs) != hipSuccess || hipStreamWaitEvent(s, h->ev_out, 0) != hipSuccess)
         return fail(h, "stream fence (out) failed");
     if (hipMemcpyAsync(out, p->out_stage, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "result copy failed");
+    ++h->ctr.sampler_runs; ++h->ctr.graph_replays; h->ctr.sampler_evals += n_eval;
+    return 0;
+}
+
+int adf_abi_version(void) { return ADF_ABI_VERSION; }
+
+int adf_get_counters(const adf_handle* h, adf_run_counters* out) {
+    if (!h || !out) return 1;
+    *out = h->ctr;
     return 0;
 }
 

@@ -17,6 +17,13 @@ extern "C" int adf_debug_rb_stamps(unsigned long long* out) {
 }
 #endif
 
+#ifdef ADF_RB_TL
+namespace adf { __device__ unsigned adf_rb_tl[2 * 8 * 128]; }
+extern "C" int adf_debug_rb_timeline(unsigned* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adf::adf_rb_tl), sizeof(unsigned) * 2 * 8 * 128);
+}
+#endif
+
 namespace adf {
 
 namespace {
@@ -210,10 +217,10 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     static int num_cu_dev[kMaxDevices] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPpLds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess) {
             *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize, rb) failed";
             return true;
         }
@@ -221,10 +228,10 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
         attr_done[dev] = true;
     }
     const long long grid = tiles_total < num_cu_dev[dev] ? tiles_total : num_cu_dev[dev];
-    if (nh == 2 && raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, true>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
-    else if (nh == 2) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, false>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
-    else if (raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<1, true>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
-    else hipLaunchKernelGGL((conv_gemm_rb_kernel<1, false>), dim3((unsigned)grid), dim3(512), kPpLds, stream, r);
+    if (nh == 2 && raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, true>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
+    else if (nh == 2) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, false>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
+    else if (raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<1, true>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
+    else hipLaunchKernelGGL((conv_gemm_rb_kernel<1, false>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
     if (hipGetLastError() != hipSuccess) *err = "conv_gemm_rb: launch failed";
     return true;
 }

@@ -40,6 +40,17 @@ namespace adf {
 extern __device__ unsigned long long adf_rb_stamps[8 * 16];
 #endif
 
+#ifdef ADF_RB_TL
+// diagnostic build only (tools/build_variant.sh rbtl -DADF_RB_TL -fno-slp-vectorize; tools/rb_timeline.py): the WHOLE launch of two thread
+// blocks (block 0 and one from the middle of the grid) as 32-bit s_memtime stamps per wave -- entry, first DMAs issued, landed,
+// first block ready; per tile: tile start, previous tile's epilogue done, and per sub-step "MFMAs + gap work done" / "barrier
+// passed"; last epilogue done; plus s_memrealtime (100 MHz) at entry and exit, which gives the clock the launch ran at.
+// The stamps live in 4 KB of LDS beyond the product layout (the launcher asks for kRbLds) and leave at the end of the block.
+extern __device__ unsigned adf_rb_tl[2 * 8 * 128];
+constexpr int kRbLds = kPpLds + 3072;
+#else
+constexpr int kRbLds = kPpLds;
+#endif
 constexpr int kRbMaxBlk = 24;
 // timing knock-outs of diagnostic builds only (tools/build_variant.sh NAME -DADF_RB_STAMP -DADF_RB_KNOCK=bits; results are wrong by
 // construction): 1 no prologue work in the gaps, 2 no activation DMA, 4 no weight DMA, 8 no MFMA, 16 no fragment reads
@@ -576,6 +587,28 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #else
     auto kstamp = [&](int) __attribute__((always_inline)) {};
 #endif
+#ifdef ADF_RB_TL
+    const int tl_which = bidx == 0 ? 0 : (bidx == (int)gridDim.x / 2 + 3 ? 1 : -1);
+    unsigned* const tl_lds = (unsigned*)(smem + kPpOffBias + 1024) + wave * 128;
+    auto tl = [&](int id) __attribute__((always_inline)) {
+        if (tl_which >= 0 && id < 128) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) tl_lds[id] = (unsigned)t;
+        }
+    };
+    auto tl_real = [&](int id) __attribute__((always_inline)) {
+        if (tl_which >= 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0) { tl_lds[id] = (unsigned)t; tl_lds[id + 1] = (unsigned)(t >> 32); }
+        }
+    };
+    if (tl_which >= 0) for (int i = lane; i < 128; i += 64) tl_lds[i] = 0u;
+    int tl_sub = 0;
+    tl_real(120);
+    tl(0);
+#else
+    auto tl = [&](int) __attribute__((always_inline)) {};
+#endif
     kstamp(11);
     // ---- start-up: bias vector, the first sample's table, first DMAs -------------------------------------------------
     // (all start-up loads unconditional -- absent tensors through a dummy pointer, lanes past the end on a clamped index: two bias loads and the
@@ -598,9 +631,11 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     if (tid < a.n) ldsBias[tid] = (hb0 ? b0v : 0.f) + (hb1 ? b1v : 0.f);
     if (!RAW && tid < ctot0) gn_store(tid, gl, 0);
     kstamp(12);
+    tl(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     kstamp(13);
+    tl(2);
     Tile cur_tile = tile_of(0);
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
@@ -617,6 +652,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     if (RAW) zero_fill(dc, 0u); else transform_all(dc, 0u);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     kstamp(14);
+    tl(3);
 
     // ---- pipeline -----------------------------------------------------------------------------------------------------
     // K blocks are numbered over the whole thread block; block g lives in A stage g % 3 (fetched while block g-2 computes,
@@ -683,6 +719,9 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                     });
             if (u == U - 1) part_end(d1, sa1);
             stamp(3 * u + 1);
+#ifdef ADF_RB_TL
+            tl(4 + tseq * 26 + 2 + 2 * tl_sub);
+#endif
             // the next slab has landed; the activation pieces issued in this sub-step (the 2 youngest) may still fly
             if (u < 2 && has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -693,6 +732,10 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             }
             lds_barrier();
             stamp(3 * u + 3);
+#ifdef ADF_RB_TL
+            tl(4 + tseq * 26 + 3 + 2 * tl_sub);
+            ++tl_sub;
+#endif
         });
 #ifdef ADF_RB_STAMP
         if (stamp_on && lane < 16) adf_rb_stamps[wave * 16 + lane] = ((const unsigned long long*)(smem + kPpOffBias + 1024))[wave * 16 + lane];
@@ -730,6 +773,10 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 
     for (; tseq < ntiles; ++tseq) {
         cur_tile = tile_of(tseq);
+#ifdef ADF_RB_TL
+        tl_sub = 0;
+        tl(4 + tseq * 26);
+#endif
         // the previous tile's accumulators leave, this tile's start from its bias
         if (tseq > 0) {
 #ifdef ADF_RB_STAMP
@@ -737,6 +784,9 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #endif
             epilogue(tile_of(tseq - 1), cur_tile.n0);
         }
+#ifdef ADF_RB_TL
+        tl(4 + tseq * 26 + 1);
+#endif
         // blocks come in pairs (nb3 and nb1 are even): the weight stage parity is a compile-time constant
         for (kb = 0; kb < nb3; kb += 2) {
             block3(c0); rotate(); --remaining; prev_one = false;
@@ -749,8 +799,17 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     }
     {
         const Tile last = tile_of(ntiles - 1);
+        tl(108);
         epilogue(last, 0);
+        tl(109);
     }
+#ifdef ADF_RB_TL
+    tl_real(122);
+    if (tl_which >= 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 128; i += 64) adf_rb_tl[(tl_which * 8 + wave) * 128 + i] = tl_lds[i];
+    }
+#endif
 }
 
 }  // namespace adf

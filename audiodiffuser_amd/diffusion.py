@@ -11,6 +11,7 @@ compatibility and is not the accelerated path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -72,6 +73,8 @@ class EluDiffusion(nn.Module):
                     return hd.denoise(x, self.sigma_data, sigmas=sv).to(x_noisy.dtype)
                 return hd.denoise(x, self.sigma_data, sigma=float(sigma)).to(x_noisy.dtype)
         # ---- interface-compatibility branch: arbitrary `net` callable -------------------------
+        if isinstance(net, HipNet) and inference and os.environ.get("ADF_REQUIRE_NATIVE", "0") not in ("", "0"):
+            raise RuntimeError("denoise_fn: ADF_REQUIRE_NATIVE is set and this inference call on a HIP net would not be one adf_denoise call")
         b, device = x_noisy.shape[0], x_noisy.device
         if sigmas is None:
             sigmas = torch.full((b,), float(sigma), dtype=torch.float32, device=device)

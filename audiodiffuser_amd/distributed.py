@@ -9,6 +9,7 @@ its inference is unsharded (src/models/diffunet_complex_module.py:235-266).
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -66,13 +67,29 @@ def launch_ranks(script: str, n: int, argv: Sequence[str], stdout=None, timeout:
     exit code.  The caller must not have touched a GPU yet (a process that has initialised HIP must not be replaced, and
     the children open the devices themselves); rendezvous is on 127.0.0.1 (the container hostname may not resolve).
     ``bench.py --gpus N`` uses this when it is not already running under a launcher."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: needed by RCCL on this driver
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script] + list(argv)
-    return subprocess.run(cmd, env=env, stdout=stdout, timeout=timeout).returncode
+    # own session: the ranks are grandchildren, so on a timeout the whole process GROUP is ended (they would otherwise keep
+    # their GPUs and the rendezvous port); the ranks stay fresh child processes -- nothing that touched a GPU is re-exec'ed
+    proc = subprocess.Popen(cmd, env=env, stdout=stdout, start_new_session=True)
+    try:
+        return proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124

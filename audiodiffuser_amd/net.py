@@ -155,6 +155,12 @@ class NativeHandle:
                                                 C.c_void_p(_stream_ptr(noise.device))), "adf_sampler_run")
         return out
 
+    def counters(self) -> Dict[str, int]:
+        """What the device loop has done so far (``adf_get_counters``): sampler runs, evaluations, graph captures / replays."""
+        c = _lib.AdfRunCounters()
+        self.check(self.lib.adf_get_counters(self.h, C.byref(c)), "adf_get_counters")
+        return {name: int(getattr(c, name)) for name, _ in c._fields_}
+
     def tap_names(self):
         n = self.lib.adf_debug_tap_count(self.h)
         return [self.lib.adf_debug_tap_name(self.h, i).decode() for i in range(n)]

@@ -11,6 +11,7 @@ callable the same recurrences are expressed with tensor ops around ``fn`` (inter
 """
 from __future__ import annotations
 
+import os
 from math import sqrt
 from typing import Callable, Optional
 
@@ -23,18 +24,40 @@ from .diffusion import EluDiffusion
 from .net import HipNet, UNet1dBase
 
 
-def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict) -> Optional[EluDiffusion]:
-    """The whole loop runs inside the HIP library when ``fn`` is this package's ``EluDiffusion.denoise_fn`` and ``net``
-    its ``UNet1dBase``.  The only conditioning it understands is ``classes`` (labels) on a class-conditional net, where
-    ``cond_scale != 1`` is classifier-free guidance (two network passes per evaluation)."""
+# ADF_REQUIRE_NATIVE=1 (or ``samplers.REQUIRE_NATIVE = True``): a sampler call that would NOT run inside libadf_hip.so raises
+# instead of taking the interface-compatibility branch.  The GPU test-suite sets it (tests/conftest.py), so a refactor that
+# silently sends the package's own (fn, net) pair down the tensor-op restatement fails every sampler parity test.
+REQUIRE_NATIVE = os.environ.get("ADF_REQUIRE_NATIVE", "0") not in ("", "0")
+
+
+def _native_pair(fn: Callable, net, cond_scale: float, kwargs: dict, noise: Optional[Tensor] = None,
+                 who: str = "sampler") -> Optional[EluDiffusion]:
+    """The whole loop runs inside the HIP library when ``fn`` is this package's ``EluDiffusion.denoise_fn``, ``net`` one of
+    its HIP nets and ``noise`` lives on a ROCm device.  The only conditioning it understands is ``classes`` (labels) on a
+    class-conditional net, where ``cond_scale != 1`` is classifier-free guidance (two network passes per evaluation).
+    Returns the owner of ``fn`` (-> device loop) or None (-> interface-compatibility branch)."""
     owner = getattr(fn, "__self__", None)
-    if not (isinstance(owner, EluDiffusion) and getattr(fn, "__func__", None) is EluDiffusion.denoise_fn
-            and isinstance(net, HipNet) and 0.0 <= owner.dynamic_threshold <= 1.0):
-        return None
-    extra = {k: v for k, v in kwargs.items() if v is not None}
-    if net.cfg.class_cond:
-        return owner if set(extra) == {"classes"} else None
-    return owner if (not extra and cond_scale == 1.0) else None
+    why = None
+    if not (isinstance(owner, EluDiffusion) and getattr(fn, "__func__", None) is EluDiffusion.denoise_fn):
+        why = "fn is not audiodiffuser_amd.EluDiffusion.denoise_fn"
+    elif not isinstance(net, HipNet):
+        why = "net is not one of this package's HIP networks"
+    elif not 0.0 <= owner.dynamic_threshold <= 1.0:
+        why = "dynamic_threshold outside [0, 1]"
+    elif noise is not None and not noise.is_cuda:
+        why = "noise is not on a ROCm device"
+    else:
+        extra = {k: v for k, v in kwargs.items() if v is not None}
+        if net.cfg.class_cond:
+            if set(extra) != {"classes"}:
+                why = "a class-conditional net takes exactly the `classes` keyword"
+        elif extra or cond_scale != 1.0:
+            why = "conditioning keywords / cond_scale != 1 on an unconditional net"
+    if why is None:
+        return owner
+    if REQUIRE_NATIVE:
+        raise RuntimeError(f"{who}: ADF_REQUIRE_NATIVE is set and this call would leave the device loop ({why})")
+    return None
 
 
 def _condition(net: UNet1dBase, hd, device, cond_scale: float, kwargs: dict, diff: Optional[EluDiffusion] = None) -> None:
@@ -85,8 +108,8 @@ class EDMSampler(nn.Module):
     @torch.no_grad()
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
                 **kwargs) -> Tensor:
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -131,8 +154,8 @@ class EDMAlphaSampler(nn.Module):
 
     @torch.no_grad()
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -200,8 +223,8 @@ class DPMSampler(nn.Module):
     @torch.no_grad()
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
         self._check_supported()
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -298,8 +321,8 @@ class DPM2MSampler(nn.Module):
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
         if len(sigmas) < self.num_steps + 1:
             raise IndexError(f"index {self.num_steps} is out of bounds for dimension 0 with size {len(sigmas)}")
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -363,8 +386,8 @@ class LMSSampler(nn.Module):
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
         if not 1 <= self.order <= 4:
             raise ValueError("LMSSampler: order must be 1..4")
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -403,8 +426,8 @@ class DPM2Sampler(nn.Module):
     @torch.no_grad()
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
                 **kwargs) -> Tensor:
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -449,8 +472,8 @@ class ADPM2Sampler(nn.Module):
     @torch.no_grad()
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
                 **kwargs) -> Tensor:
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -492,8 +515,8 @@ class ADPMPP2SSampler(nn.Module):
     @torch.no_grad()
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, injected_noise: Optional[Tensor] = None,
                 **kwargs) -> Tensor:
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)
@@ -548,8 +571,8 @@ class UniPCSampler(nn.Module):
     @torch.no_grad()
     def forward(self, noise: Tensor, fn: Callable, net: nn.Module, sigmas: Tensor, **kwargs) -> Tensor:
         assert self.num_steps >= self.order                                        # :1001
-        diff = _native_pair(fn, net, self.cond_scale, kwargs)
-        if diff is not None and noise.is_cuda:
+        diff = _native_pair(fn, net, self.cond_scale, kwargs, noise, type(self).__name__)
+        if diff is not None:
             x = _prep(noise)
             hd = net.native(x.device)
             _condition(net, hd, x.device, self.cond_scale, kwargs, diff)

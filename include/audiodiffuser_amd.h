@@ -40,6 +40,12 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct of this header grows or an entry point's argument list changes; a binding compares it with
+ * adf_abi_version() of the library it loaded before the first call (audiodiffuser_amd/_lib.py does; INTEGRATION.md's C example too).
+ * 3: adf_sampler_run(n_injected), adf_sampler_desc.reflow, adf_get_counters. */
+#define ADF_ABI_VERSION 3
+int adf_abi_version(void);
+
 #define ADF_MAX_LAYERS 12
 
 #define ADF_DTYPE_F32 0  /* parity mode: fp32 storage, exact-fp32 MFMA */
@@ -126,7 +132,7 @@ int adf_set_image_shape(adf_handle* h, int H, int W);
 int adf_set_dynamic_threshold(adf_handle* h, float quantile);
 /* A WaveNetNoise handle.  x / out of adf_net_forward, adf_denoise, adf_sampler_run are [B][1][T] (the reference's forward takes
  * audio [B][T] and returns [B][1][T]: same memory); any T >= 1.  Debug taps: "y<n>" = input of residual layer n including its
- * diffusion-step addend (kept while all of them fit 256 MiB), "skip" = the normalised skip sum. */
+ * diffusion-step addend (kept while all of them fit 512 MiB), "skip" = the normalised skip sum. */
 int adf_wavenet_create(const adf_wavenet_config* cfg, adf_handle** out);
 void adf_destroy(adf_handle* h);
 const char* adf_last_error(const adf_handle* h);   /* h may be NULL: error of the last failed adf_create */
@@ -170,6 +176,20 @@ int adf_debug_tap_copy(adf_handle* h, const char* name, float* out_fp32, void* s
 int adf_debug_dyn_threshold(adf_handle* h, float* x_dev, int B, long long per_sample, float quantile, void* stream);
 int adf_debug_tap_count(adf_handle* h);
 const char* adf_debug_tap_name(adf_handle* h, int index);
+
+/* What the handle has enqueued so far.  The plugin classes fall back to a host-side loop of tensor ops around a foreign `fn`
+ * / `net` (interface compatibility); these counters are how a caller -- and every GPU sampler test -- tells that the device loop
+ * of adf_sampler_run ran instead.  net_passes counts network passes enqueued by host code: a captured loop counts once at
+ * capture, its replays are graph_replays (sampler_evals adds the evaluations of every run, replayed or not). */
+typedef struct adf_run_counters {
+    int64_t sampler_runs;     /* successful adf_sampler_run calls */
+    int64_t sampler_evals;    /* denoiser evaluations those runs performed on the device */
+    int64_t graph_captures;   /* step loops captured into a hipGraph */
+    int64_t graph_replays;    /* adf_sampler_run calls served by hipGraphLaunch */
+    int64_t denoise_calls;    /* adf_denoise calls */
+    int64_t net_passes;       /* network passes enqueued by host code (eager, warm-up, capture) */
+} adf_run_counters;
+int adf_get_counters(const adf_handle* h, adf_run_counters* out);
 
 /* Bytes of device memory held by the handle (weights + workspaces). */
 int64_t adf_device_bytes(const adf_handle* h);

@@ -200,6 +200,56 @@ def test_config4_sampler_with_injected_draws_vs_reference_golden(gold):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_config4_exactly_full_net_35_step_churn_sampler_vs_oracle():
+    """BASELINE configs[3] at full size: the 71 M-parameter `config_c4()` net on one 1 x 80 x 256 mel block,
+    EDMSampler(s_churn=40, s_noise=1.003, s_tmin=0.05, s_tmax=50, num_steps=35) = 69 evaluations with injected draws, fp32 mode,
+    eager and graph-replayed, against the oracle's loop around the pinned network restatement (sampler_edm.py:333-397)."""
+    from oracle import edm as E, samplers as S
+    cfg = A.config_c4()
+    net, w = make(cfg, seed=4)
+    net = net.cuda()
+    diff = A.EluDiffusion(sigma_data=0.5)
+    g = torch.Generator().manual_seed(41)
+    noise = torch.randn(1, 1, 80, 256, generator=g)
+    draws = torch.randn(35, 1, 1, 80, 256, generator=g)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 35)()
+    fn_o = lambda xx, sigma=None, sigmas=None: E.denoise(lambda xi, ti, **kw: O.unet2d_forward(w, cfg, xi, ti), xx, 0.5, sigma=sigma, sigmas=sigmas)
+    with torch.no_grad():
+        ref = S.edm_sampler(noise, fn_o, sig, 35, s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, injected_noise=draws)
+    assert float(ref.abs().max()) > 1e-3
+    for use_graph in (False, True):
+        smp = A.EDMSampler(s_tmin=0.05, s_tmax=50.0, s_churn=40.0, s_noise=1.003, num_steps=35, use_graph=use_graph)
+        y = smp(noise.cuda(), fn=diff.denoise_fn, net=net, sigmas=sig, injected_noise=draws.cuda()).cpu()
+        assert rel(y, ref) < 2e-4, (use_graph, rel(y, ref))           # 69 chained evaluations; north-star bar 1e-3
+
+
+@pytest.mark.gpu
+def test_two_image_shapes_with_equal_area_do_not_share_a_captured_graph():
+    """[B,1,16,64] and [B,1,32,32] have the same H * W; a graph captured for the first shape must not be
+    replayed for the second (the conv2d geometry is baked into the captured launches)."""
+    from oracle import edm as E, samplers as S
+    cfg = A.config_c4_small()
+    net, w = make(cfg)
+    net = net.cuda()
+    diff = A.EluDiffusion(sigma_data=0.5)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 4)()
+    g = torch.Generator().manual_seed(8)
+    fn_o = lambda xx, sigma=None, sigmas=None: E.denoise(lambda xi, ti, **kw: O.unet2d_forward(w, cfg, xi, ti), xx, 0.5, sigma=sigma, sigmas=sigmas)
+    smp = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=4, use_graph=True)
+    for shape in ((1, cfg.in_channels, 16, 64), (1, cfg.in_channels, 32, 32), (1, cfg.in_channels, 16, 64)):
+        noise = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            ref = S.edm_sampler(noise, fn_o, sig, 4, s_churn=0.0, s_noise=1.0)
+        y = smp(noise.cuda(), fn=diff.denoise_fn, net=net, sigmas=sig).cpu()
+        assert rel(y, ref) < FP32_TIGHT, (shape, rel(y, ref))
+        hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+        y1 = net(noise.cuda(), torch.tensor([0.1]).cuda()).cpu()      # taps of the last pass carry this shape's geometry
+        with torch.no_grad():
+            assert rel(y1, O.unet2d_forward(w, cfg, noise, torch.tensor([0.1]))) < FP32_TIGHT
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["o2_log", "o3_log", "o1_log", "o2_sig", "o3_sig", "o2_log_eps"])
 def test_unipc_sampler_on_the_device_vs_reference_golden(gold, tag):
     """UniPCSampler (4-D states only in the reference) on the device, eager and graph-replayed, against the REFERENCE's results."""

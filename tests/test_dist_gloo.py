@@ -87,3 +87,43 @@ def test_bench_refuses_more_gpus_than_devices():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "--gpus 64" in r.stderr
+
+
+def _json_lines(text):
+    return [l for l in text.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("how", ["torchrun", "self_launch"])
+def test_bench_rank_path_prints_one_line_from_rank_0(how):
+    """bench.py's rank path (rendezvous on 127.0.0.1, index-keyed noise slices, fences, MAX over ranks, ONE all-gather, rank 0
+    reporting) with the device layer mocked (`--mock-device`: CPU tensors, gloo, a stand-in step): exactly one JSON line,
+    n_gpus == rccl_ranks == WORLD_SIZE, the gathered batch is the global one -- started the way the driver starts it
+    (torch.distributed.run) and the way `bench.py --gpus N` starts itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--mock-device", "--batch", "3", "--length", "128", "--config", "c3", "--sampler", "dpm"]
+    if how == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), bench] + args
+    else:
+        cmd = [sys.executable, bench] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == j["rccl_ranks"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["mock_device"] is True and j["value"] is None                       # a rehearsal never reports a throughput
+    assert j["config"]["global_batch"] == 6 and j["gathered_shape"] == [6, 1, 128] and j["nfe_per_waveform"] == 49
+    want = torch.tanh(generate_noise(0, 6, 128) * 0.5)                            # sharding does not change any sample
+    assert abs(j["gathered_checksum"] - float(want.double().sum())) < 1e-9 * max(1.0, abs(float(want.double().sum())))
+    # a mismatch between --gpus and the launcher's world size is refused by every rank (exit 2), nothing is printed
+    if how == "torchrun":
+        bad = [a if a != "2" else "4" for a in cmd]
+        bad[bad.index("--nproc-per-node") + 1] = "2"
+        r = subprocess.run(bad, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and not _json_lines(r.stdout)

@@ -329,6 +329,28 @@ def test_config2_batch_independence_and_range(dtype):
         assert rel_err(yb, y32) < BF16_TOL
 
 
+@pytest.mark.timeout(600)
+def test_config2_sampler_at_batch64_bf16_is_batch_independent_through_the_whole_loop():
+    """BASELINE configs[1] through the SAMPLER at the bench batch: 64 waveforms x 16384 samples, bf16, a Heun
+    run (8 sigmas = 15 evaluations, graph-replayed); finite, inside the clamp range, and waveforms 5 and 41 equal to the same
+    noise run as a batch of 2 through the whole loop (what the multi-GPU sharding relies on).  GroupNorm statistics are
+    accumulated with atomics (order-dependent last bits), so 'equal' is a bf16-storage figure, not bitwise."""
+    cfg = A.config_c2()
+    net, _ = make_net(cfg, "bf16")
+    d = A.EluDiffusion(sigma_data=0.2)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 8)()
+    noise = generate_noise(1234, 64, 16384).cuda()
+    smp = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=8, use_graph=True)
+    y64 = smp(noise, fn=d.denoise_fn, net=net, sigmas=sig)
+    assert y64.shape == noise.shape and torch.isfinite(y64).all() and float(y64.abs().max()) <= 1.0
+    pair = noise[[5, 41]].contiguous()
+    y2 = smp(pair, fn=d.denoise_fn, net=net, sigmas=sig)
+    assert rel_l2(y64[[5, 41]].cpu(), y2.cpu()) < 2e-2, rel_l2(y64[[5, 41]].cpu(), y2.cpu())
+    assert float(y64.std()) > 1e-3                                     # not a collapsed output
+    c = net.native(noise.device).counters()
+    assert c["graph_replays"] >= 2 and c["graph_captures"] >= 2 and c["sampler_evals"] >= 30, c
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
 def test_config3_every_layer_short(dtype, tol):
     """64-channel net with attention at N = 256 / 64 / 16 / 4 tokens (head dim 32: the MFMA attention kernel in

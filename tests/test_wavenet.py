@@ -177,6 +177,41 @@ def test_denoise_and_heun_sampler_fp32_vs_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_config5_exactly_full_net_22050_samples_6_step_heun_vs_oracle():
+    """BASELINE configs[4] at full size: the 36 x 256 `config_c5()` net, T = 22050 (not a multiple of the
+    128-position tile), B = 2, 6-step Heun = 11 evaluations, fp32 mode eager and graph-replayed against the oracle's loop around the
+    pinned restatement (wavenet.py:169-180 inside sampler_edm.py:333-397); then ONE bf16 forward at T = 22050, teacher-forced
+    layer by layer against the bf16-storage oracle."""
+    cfg = A.config_c5()
+    net, w = make(cfg)
+    net = net.cuda()
+    diff = A.EluDiffusion(sigma_data=0.5)
+    g = torch.Generator().manual_seed(55)
+    x = torch.randn(2, 1, 22050, generator=g)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 6)()
+    fn_o = lambda xx, sigma=None, sigmas=None: E.denoise(W.wavenet_net(w, cfg), xx, 0.5, sigma=sigma, sigmas=sigmas)
+    with torch.no_grad():
+        ref = S.edm_sampler(x, fn_o, sig, 6, s_churn=0.0, s_noise=1.0)
+    for use_graph in (False, True):
+        y = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=6, use_graph=use_graph)(x.cuda(), fn=diff.denoise_fn, net=net, sigmas=sig).cpu()
+        assert rel(y, ref) < 1e-4, (use_graph, rel(y, ref))              # 11 chained evaluations; north-star bar 1e-3
+    n16, _ = make(cfg, "bf16")
+    n16 = n16.cuda()
+    a, st = torch.randn(1, 22050, generator=g) * 0.8, torch.tensor([0.3])
+    y16 = n16(a.cuda(), st.cuda()).cpu()
+    hd = n16.native(torch.device("cuda", torch.cuda.current_device()))
+    taps = {k: hd.tap(k, 1, torch.device("cuda")).cpu() for k in hd.tap_names()}
+    errs = {}
+    with torch.no_grad():
+        y_f = W.wavenet_forward(w, cfg, a, st, storage="bf16", force=taps, errs=errs)
+    assert len(errs) == 37 and set(errs) == set(taps)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < BF16_LAYER_TOL, (worst, errs[worst])
+    assert W.rel_l2(y16, y_f) < BF16_LAYER_TOL, W.rel_l2(y16, y_f)
+
+
+@pytest.mark.gpu
 def test_bf16_sampler_against_fp32_device_run_and_weight_reload():
     """6-step Heun on the default net: bf16 against the fp32 device path (a storage-precision figure), and a reloaded state_dict
     rebuilds the effective (weight-normed) weights."""
