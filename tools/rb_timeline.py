@@ -85,3 +85,31 @@ for which in (0, 1):
     for name, mx, mn in rows:
         print(f"{name:100s} {mx:8d} {mn:8d}" if mx or mn else name)
     print(f"inside the K loops: {in_k} cycles = {100.0 * in_k / end:.1f} % of the launch; outside (start-up, epilogues): {out_k} = {100.0 * out_k / end:.1f} %")
+    # per wave: entry skew, and for tile 1 the work (previous barrier -> MFMAs + gap work done) and the wait (-> barrier passed) of every sub-step
+    print("per wave (w0 .. w7)")
+    print(f"{'entry after the first wave':40s}" + "".join(f"{d(S[w][0], t0):7d}" for w in range(8)))
+    for nm, a, b in (("entry -> DMAs issued + table stored", 0, 1), ("-> landed + barrier", 1, 2), ("-> first block activated", 2, 3)):
+        print(f"{nm:40s}" + "".join(f"{d(S[w][b], S[w][a]):7d}" for w in range(8)))
+    base = 4 + 26
+    print(f"{'tile 1: epilogue of tile 0':40s}" + "".join(f"{d(S[w][base + 1], S[w][base]):7d}" for w in range(8)))
+    for u in range(12):
+        prev = base + 1 if u == 0 else base + 3 + 2 * (u - 1)
+        print(f"{'tile 1 sub-step %2d work' % u:40s}" + "".join(f"{d(S[w][base + 2 + 2 * u], S[w][prev]):7d}" for w in range(8)))
+        print(f"{'                   wait + barrier':40s}" + "".join(f"{d(S[w][base + 3 + 2 * u], S[w][base + 2 + 2 * u]):7d}" for w in range(8)))
+    if any(S[w][110] for w in range(8)):
+        print("fine stamps (role-split kernel): consumers = last epilogue: entry / stores issued / statistics done; producers = tile 1 block 1:")
+        print("   per sub-step u: DMAs issued / prologue done / slab wait done      (cycles from the sub-step's start = previous barrier)")
+        for w in range(8):
+            if not S[w][113]:
+                print(f"   w{w}: stores {d(S[w][111], S[w][110])}  statistics {d(S[w][112], S[w][111])}  whole epilogue + bias {d(S[w][109], S[w][108])}")
+            else:
+                base = 4 + 26
+                row = []
+                for u in range(3):
+                    k = 3 + u           # sub-steps 3..5 of the tile = block 1
+                    prev = base + 3 + 2 * (k - 1)
+                    row.append("u%d: %d / %d / %d (end %d)" % (u, d(S[w][110 + 3 * u], S[w][prev]), d(S[w][111 + 3 * u], S[w][prev]), d(S[w][112 + 3 * u], S[w][prev]), d(S[w][base + 2 + 2 * k], S[w][prev])))
+                print(f"   w{w}: " + "   ".join(row))
+import json
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump({"resblock": rb, "conv": conv, "us_per_launch_stamped_build": ms.value * 1e3, "stamps": list(buf)}, open(f"gpurun_out/rb_timeline_raw_{rb}_{conv}.json", "w"))
