@@ -183,35 +183,35 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
         }
     };
     add_seg(g0.src0, g0.src1, g0.c0, g0.c1, g0.w, 3, !raw0, 1.0f);
-    r.nb3 = nb;
+    r.h.nb3 = nb;
     if (a.nseg > 1) {
         const GemmSeg& g1 = a.seg[1];
         if (g1.taps != 1 || g1.off0 != 0 || g1.stride != 1 || g1.step != 1 || g1.ab || g1.gn.gamma || g1.act) return false;
         if (g1.c0 % 64 || g1.c1 % 64 || ((g1.c0 + g1.c1) / 64) % 2 || nb + (g1.c0 + g1.c1) / 64 > kRbMaxBlk) return false;
         add_seg(g1.src0, g1.src1, g1.c0, g1.c1, g1.w, 1, false, g1.scale1);
     }
-    r.res = a.nseg == 1 ? a.res : nullptr;                             // identity residual: added in the epilogue (fp32, before the rounding)
+    r.h.res = a.nseg == 1 ? a.res : nullptr;                             // identity residual: added in the epilogue (fp32, before the rounding)
     (void)ident;
-    r.nb1 = nb - r.nb3;
-    r.B = a.B; r.L = a.mrows;
-    r.tm_shift = 0;
-    while ((1 << r.tm_shift) < a.mrows / 256) ++r.tm_shift;
+    r.h.nb1 = nb - r.h.nb3;
+    r.h.B = a.B; r.h.L = a.mrows;
+    r.h.tm_shift = 0;
+    while ((1 << r.h.tm_shift) < a.mrows / 256) ++r.h.tm_shift;
     // n = 256: one 256 x 256 tile per 256 rows (the activations are fetched and activated once) when that still gives
     // every CU a tile, else two 256 x 128 tiles
     const int nh = (a.n == 256 && (long long)a.B * (a.mrows / 256) >= min_tiles) ? 2 : 1;
-    r.tiles_n = a.n / (kPpTN * nh);
-    const long long tiles_total = (long long)a.B * (a.mrows / 256) * r.tiles_n;
+    r.h.tiles_n = a.n / (kPpTN * nh);
+    const long long tiles_total = (long long)a.B * (a.mrows / 256) * r.h.tiles_n;
     if (tiles_total < min_tiles || tiles_total > (1 << 22)) return false;       // fewer tiles than CUs: the 128-row kernel fills the chip better
-    r.tiles_total = (int)tiles_total;
-    r.n = a.n;
-    r.gn = g0.gn;
-    r.bias0 = a.bias0; r.bias1 = a.bias1;
-    r.out = a.out;
-    r.stats = nullptr; r.stats_groups = 0;
+    r.h.tiles_total = (int)tiles_total;
+    r.h.n = a.n;
+    r.h.gn = g0.gn;
+    r.h.bias0 = a.bias0; r.h.bias1 = a.bias1;
+    r.h.out = a.out;
+    r.h.stats = nullptr; r.h.stats_groups = 0;
     if (a.stats) {
         const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
         if (!(gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
-        r.stats = a.stats; r.stats_groups = a.stats_groups;
+        r.h.stats = a.stats; r.h.stats_groups = a.stats_groups;
     }
     static bool attr_done[kMaxDevices] = {};
     static int num_cu_dev[kMaxDevices] = {};

@@ -68,9 +68,11 @@ struct RbBlk {
     int pad_;
 };
 
-struct RbArgs {
-    RbBlk blk[kRbMaxBlk];     // K blocks of one tile, in order: nb3 three-tap blocks (GroupNorm + SiLU), then nb1 one-tap raw blocks
-    int nb3, nb1;
+// Everything but the block table: the kernel copies it to registers in ONE scalar-load round trip at its entry (round 3: read field
+// by field where first used, the kernel arguments were ~12 serialised scalar-cache round trips ahead of the first DMA -- ~7 K cycles
+// from wave start to the first DMA instruction, profiles/r03_rb_launch_timeline.txt).
+struct RbHead {
+    int nb3, nb1;             // K blocks of one tile, in order: nb3 three-tap blocks (GroupNorm + SiLU), then nb1 one-tap raw blocks
     int B, L;                 // samples, rows per sample
     int tm_shift;             // log2(256-row tiles per sample)
     int tiles_n;              // N tiles (1 or 2), N tile index fastest
@@ -81,6 +83,10 @@ struct RbArgs {
     void* out;
     const void* res;          // identity residual (same layout as out), added in the epilogue in fp32 before the rounding, or nullptr
     double* stats; int stats_groups;
+};
+struct RbArgs {
+    RbHead h;
+    RbBlk blk[kRbMaxBlk];
 };
 
 // two DMA pieces of 1 KB from one uniform base: lane offsets va / vb, LDS destinations la / lb (+ 16 * lane)
@@ -112,6 +118,11 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     constexpr int TM = 256, HP = 32;
     constexpr int TNB = kPpTN * NH;                      // columns of the block tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the argument head and the first three block descriptors: one batch of scalar loads, one wait
+    const RbHead H = a.h;
+    const RbBlk e_first[3] = {a.blk[0], a.blk[1], a.blk[2]};
+    asm volatile("" :: "s"(H.nb3), "s"(H.tiles_total), "s"(H.gn.stats0), "s"(H.gn.gamma), "s"(H.gn.film), "s"(H.bias0), "s"(H.out), "s"(H.stats),
+                 "s"(e_first[0].src), "s"(e_first[1].src), "s"(e_first[2].src), "s"(e_first[0].tab), "s"(e_first[1].tab), "s"(e_first[2].tab));
     char* const ldsScr = smem + kPpOffScr;
     char* const ldsTab = smem + kPpOffTab;
     float* const ldsBias = (float*)(smem + kPpOffBias);
@@ -127,14 +138,14 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 
     const int nblk_grid = (int)gridDim.x, bidx = (int)blockIdx.x;
     // (tiles_total <= 2^22 and the grid <= 256 blocks: the products fit 32 bits)
-    const int t_lo = (int)((unsigned)bidx * (unsigned)a.tiles_total / (unsigned)nblk_grid);
-    const int t_hi = (int)((unsigned)(bidx + 1) * (unsigned)a.tiles_total / (unsigned)nblk_grid);
+    const int t_lo = (int)((unsigned)bidx * (unsigned)H.tiles_total / (unsigned)nblk_grid);
+    const int t_hi = (int)((unsigned)(bidx + 1) * (unsigned)H.tiles_total / (unsigned)nblk_grid);
     const int ntiles = t_hi - t_lo;
     if (ntiles <= 0) return;
-    const int nb3 = a.nb3, nb1 = a.nb1, nb = nb3 + nb1;
-    const int ctot0 = a.gn.c0 + a.gn.c1;
-    const int tn_shift = a.tiles_n > 1 ? 1 : 0;
-    const int tm_mask = (1 << a.tm_shift) - 1;
+    const int nb3 = H.nb3, nb1 = H.nb1, nb = nb3 + nb1;
+    const int ctot0 = H.gn.c0 + H.gn.c1;
+    const int tn_shift = H.tiles_n > 1 ? 1 : 0;
+    const int tm_mask = (1 << H.tm_shift) - 1;
 
     // ---- tile geometry: advanced once per tile ------------------------------------------------------------------
     struct Tile { int b0, m0, n0; };
@@ -142,8 +153,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         const int t = t_lo + tseq;
         const int tml = t >> tn_shift;
         Tile g;
-        g.n0 = (t & (a.tiles_n - 1)) * TNB;
-        g.b0 = tml >> a.tm_shift;
+        g.n0 = (t & (H.tiles_n - 1)) * TNB;
+        g.b0 = tml >> H.tm_shift;
         g.m0 = (tml & tm_mask) * TM;
         return g;
     };
@@ -165,27 +176,27 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     // made the register allocator move accumulator tiles through scratch).
     int d_t = 0, d_k = 0;                              // (tile, block) cursor of the descriptor stream
     Tile d_tile = tile_of(0);
-    auto make_desc = [&]() __attribute__((always_inline)) -> Blk {
-        const RbBlk& e = a.blk[d_k];
+    auto make_desc_of = [&](const RbBlk& e) __attribute__((always_inline)) -> Blk {
         Blk d;
         const int three = d_k < nb3;
         const int p_lo = d_tile.m0 - three;
         d.pitch = e.pitch;
-        d.abase = e.src + (long long)(d_tile.b0 * a.L + p_lo) * (long long)e.pitch;
+        d.abase = e.src + (long long)(d_tile.b0 * H.L + p_lo) * (long long)e.pitch;
         d.w = e.w + (unsigned)d_tile.n0 * (unsigned)kRowBytes;
         d.tab = e.tab >= 0 ? ((d_tile.b0 - b_first) & 1) * kPpTab + e.tab : -1;
         d.scale = e.scale;
         d.taps = three ? 3 : 1;
-        d.edge = three ? ((d_tile.m0 == 0 ? 1 : 0) | (d_tile.m0 + TM >= a.L ? 2 : 0)) : 0;
+        d.edge = three ? ((d_tile.m0 == 0 ? 1 : 0) | (d_tile.m0 + TM >= H.L ? 2 : 0)) : 0;
         return d;
     };
+    auto make_desc = [&]() __attribute__((always_inline)) -> Blk { return make_desc_of(a.blk[d_k]); };
     auto advance = [&]() __attribute__((always_inline)) {
         if (++d_k == nb) {
             d_k = 0;
             if (++d_t < ntiles) d_tile = tile_of(d_t);    // past the end: a valid but unused descriptor
         }
     };
-    const unsigned slab = (unsigned)a.n * (unsigned)kRowBytes;           // one tap of packed weights
+    const unsigned slab = (unsigned)H.n * (unsigned)kRowBytes;           // one tap of packed weights
 
     // ---- DMA ----------------------------------------------------------------------------------------------------
     const unsigned colbytes = (unsigned)chunk * 16u;
@@ -224,13 +235,13 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     //  the landing time of the first DMAs.)
     struct GnLoaded { double s0, q0, s1, q1; float gamma, beta, f1s, f1h, f2s, f2h; };     // raw loads: nothing is computed from them before gn_store
     auto gn_two = [&](int c) __attribute__((always_inline)) -> bool {
-        const GnFinalizeArgs& g = a.gn;
+        const GnFinalizeArgs& g = H.gn;
         const int ctot = g.c0 + g.c1, gs = ctot / g.G;
         const bool from1 = (c / gs) * gs >= g.c0;
         return gs > (from1 ? g.c1 : g.c0) / g.G;          // two stored (fine) groups per coarse group: two equal sources
     };
     auto gn_load = [&](int b, int c) __attribute__((always_inline)) -> GnLoaded {
-        const GnFinalizeArgs& g = a.gn;
+        const GnFinalizeArgs& g = H.gn;
         const int ctot = g.c0 + g.c1;
         const int gs = ctot / g.G;                         // channels per (coarse) group
         const int cstart = (c / gs) * gs;
@@ -259,14 +270,14 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     };
     auto gn_store = [&](int c, const GnLoaded& v, int slot) __attribute__((always_inline)) {
         const bool two = gn_two(c);
-        const bool hf = a.gn.film != nullptr, hf2 = hf && a.gn.film2 != nullptr;           // uniform
+        const bool hf = H.gn.film != nullptr, hf2 = hf && H.gn.film2 != nullptr;           // uniform
         GnRaw r;
         r.sum = v.s0 + (two ? v.s1 : 0.0); r.sq = v.q0 + (two ? v.q1 : 0.0);
         r.gamma = v.gamma; r.beta = v.beta;
         r.fs = hf ? v.f1s + 1.0f + (hf2 ? v.f2s : 0.f) : 1.0f;
         r.fh = hf ? v.f1h + (hf2 ? v.f2h : 0.f) : 0.0f;
         float A, Bc;
-        gn_affine_finish<true>(a.gn, c, r, A, Bc);
+        gn_affine_finish<true>(H.gn, c, r, A, Bc);
         *(f32x2_t*)(ldsTab + slot * kPpTab + c * 8) = f32x2_t{A, Bc};
     };
     auto fill_table = [&](int b, int slot) __attribute__((always_inline)) {
@@ -497,84 +508,100 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 
     // ---- wave-local epilogue of one finished tile ---------------------------------------------------------------
     const int cc = lane & 7, rsub = lane >> 3;
-    auto epilogue = [&](const Tile& g, int next_n0) __attribute__((always_inline)) {
-        float* sc = (float*)(ldsScr + wave * 2048);          // [8][64] fp32
-        float* scw = sc + (4 * h) * 64 + r;
-        const float* scr = sc + rsub * 64 + cc * 8;
-        T* out = (T*)a.out;
-        const bool stats_here = a.stats != nullptr;
-        const int gs = stats_here ? a.n / a.stats_groups : 8;
+    // Round 3 (profiles/r03_rb_launch_timeline.txt: 6.3 K cycles per tile, a seventh of the launch, as eight serial passes of
+    // LDS write -> wait -> LDS read -> wait -> store): the passes are software-pipelined over TWO 2 KB buffers per wave -- while pass p is
+    // packed and stored, the rows of pass p + 1 are already on their way back from LDS and the accumulators of pass p + 2 on their way
+    // in.  LDS operations of one wave execute in issue order, so "write p + 2 behind read p" is all the ordering the two buffers need.
+    // The buffers live in the activation stage that is free at a tile boundary (`scr_stage`: the ring stage of the tile's last block).
+    auto epilogue = [&](const Tile& g, int next_n0, unsigned scr_stage) __attribute__((always_inline)) {
+        float* const sc0 = (float*)(smem + scr_stage + wave * 4096);          // 2 x [8][64] fp32
+        T* out = (T*)H.out;
+        const bool stats_here = H.stats != nullptr;
+        const int gs = stats_here ? H.n / H.stats_groups : 8;
         const int tpg = gs / 8;
         const int mw0 = g.m0 + wm * 64;
-        const T* resp = (const T*)a.res;
+        const T* resp = (const T*)H.res;
         const bool has_res = resp != nullptr;                                   // uniform
-        // the identity residual chunk of a pass is fetched one pass ahead (the queue of this wave is empty here: every DMA of the
-        // finished tile has been waited for, the next ones are issued after the epilogue)
-        auto res_off = [&](int hf, int pass) __attribute__((always_inline)) -> unsigned {
-            const int m = mw0 + (pass >> 2) * 32 + 8 * (pass & 3) + rsub;
-            return (unsigned)((g.b0 * a.L + m) * a.n + g.n0 + hf * kPpTN + wn * 64 + cc * 8);
+        constexpr int P = NH * 8;                                               // passes: (N half, 32-row half, 8-row quarter)
+        auto res_off = [&](int pass) __attribute__((always_inline)) -> unsigned {
+            const int hf = pass >> 3, q = pass & 7;
+            const int m = mw0 + (q >> 2) * 32 + 8 * (q & 3) + rsub;
+            return (unsigned)((g.b0 * H.L + m) * H.n + g.n0 + hf * kPpTN + wn * 64 + cc * 8);
         };
-        u32x4_t rnext = u32x4_t{0u, 0u, 0u, 0u};
-        if (has_res) rnext = *(const u32x4_t*)(resp + res_off(0, 0));
+        float nb_[NH][2];
 #pragma unroll
-        for (int hf = 0; hf < NH; ++hf) {
-        const int n = g.n0 + hf * kPpTN + wn * 64 + cc * 8;
+        for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) nb_[hf][j] = ldsBias[next_n0 + hf * kPpTN + wn * 64 + j * 32 + r];
+        // accumulators of pass p -> buffer p & 1 (and the next tile's bias into them)
+        auto wr = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int hf = p >> 3, i = (p >> 2) & 1, p4 = p & 3;
+            float* const scw = sc0 + (p & 1) * 512 + (4 * h) * 64 + r;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    scw[e4 * 64 + j * 32] = acc[hf][i][j][4 * p4 + e4];
+                    acc[hf][i][j][4 * p4 + e4] = nb_[hf][j];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        struct Row { float4 q0, q1; u32x4_t res; };
+        auto rd = [&](auto pc, Row& rw) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            const float* const scr = sc0 + (p & 1) * 512 + rsub * 64 + cc * 8;
+            rw.q0 = *(const float4*)(scr);
+            rw.q1 = *(const float4*)(scr + 4);
+            if (has_res) rw.res = *(const u32x4_t*)(resp + res_off(p));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
         f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
-        float nb_[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) nb_[j] = ldsBias[next_n0 + hf * kPpTN + wn * 64 + j * 32 + r];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int p4 = 0; p4 < 4; ++p4) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) {
-                        const int e = 4 * p4 + e4;
-                        scw[e4 * 64 + j * 32] = acc[hf][i][j][e];
-                        acc[hf][i][j][e] = nb_[j];
-                    }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const int m = mw0 + i * 32 + 8 * p4 + rsub;
-                const unsigned off = (unsigned)((g.b0 * a.L + m) * a.n + n);
-                float v[8];
-                {
-                    const float4 q0 = *(const float4*)(scr), q1 = *(const float4*)(scr + 4);
-                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        auto flush_stats = [&](int hf) __attribute__((always_inline)) {
+            if (stats_here) {
+                const int n = g.n0 + hf * kPpTN + wn * 64 + cc * 8;
+                float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
+                for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                for (int o = 8; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (lane < 8 && (cc & (tpg - 1)) == 0) {
+                    double* sp = H.stats + ((size_t)g.b0 * H.stats_groups + n / gs) * 2;
+                    atomicAdd(sp, (double)s1);
+                    atomicAdd(sp + 1, (double)s2);
                 }
-                if (has_res) {
-                    const u32x4_t rc = rnext;
-                    const int nxt = hf * 8 + i * 4 + p4 + 1;
-                    if (nxt < NH * 8) rnext = *(const u32x4_t*)(resp + res_off(nxt >> 3, nxt & 7));
-                    float rf[8];
-                    unpack16<T>(rc, rf);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rf[e];
-                }
-                *(u32x4_t*)(out + off) = pack16_stored<T>(v);
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const f32x2_t v2 = {v[e], v[e + 1]};
-                    s1v += v2;
-                    s2v += v2 * v2;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
-        }
-        if (stats_here) {
-            float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
-            for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-            for (int o = 8; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-            if (lane < 8 && (cc & (tpg - 1)) == 0) {
-                double* sp = a.stats + ((size_t)g.b0 * a.stats_groups + n / gs) * 2;
-                atomicAdd(sp, (double)s1);
-                atomicAdd(sp + 1, (double)s2);
+            s1v = f32x2_t{0.f, 0.f}; s2v = f32x2_t{0.f, 0.f};
+        };
+        auto process = [&](auto pc, const Row& rw) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            float v[8];
+            v[0] = rw.q0.x; v[1] = rw.q0.y; v[2] = rw.q0.z; v[3] = rw.q0.w; v[4] = rw.q1.x; v[5] = rw.q1.y; v[6] = rw.q1.z; v[7] = rw.q1.w;
+            if (has_res) {
+                float rf[8];
+                unpack16<T>(rw.res, rf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rf[e];
             }
-        }
-        }
+            *(u32x4_t*)(out + res_off(p)) = pack16_stored<T>(v);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2_t v2 = {v[e], v[e + 1]};
+                s1v += v2;
+                s2v += v2 * v2;
+            }
+            if ((p & 7) == 7) flush_stats(p >> 3);
+        };
+        Row rows[2];
+        wr(std::integral_constant<int, 0>{});
+        wr(std::integral_constant<int, 1>{});
+        rd(std::integral_constant<int, 0>{}, rows[0]);
+        rb_static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            if constexpr (p + 1 < P) rd(std::integral_constant<int, p + 1>{}, rows[(p + 1) & 1]);
+            if constexpr (p + 2 < P) wr(std::integral_constant<int, p + 2>{});
+            process(pc, rows[p & 1]);
+        });
     };
 
 #ifdef ADF_RB_STAMP
@@ -613,22 +640,23 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     // ---- start-up: bias vector, the first sample's table, first DMAs -------------------------------------------------
     // (all start-up loads unconditional -- absent tensors through a dummy pointer, lanes past the end on a clamped index: two bias loads and the
     //  table loads under conditions were seven serialised round trips ahead of the first DMA)
-    const bool hb0 = a.bias0 != nullptr, hb1 = a.bias1 != nullptr;                    // uniform
+    const bool hb0 = H.bias0 != nullptr, hb1 = H.bias1 != nullptr;                    // uniform
     const float* const dummy_f = (const float*)a.blk[0].w;                            // always there, >= 1 KB
-    const int bidx_l = tid < a.n ? tid : 0;
-    const float b0v = (hb0 ? a.bias0 : dummy_f)[bidx_l], b1v = (hb1 ? a.bias1 : dummy_f)[bidx_l];
+    const int bidx_l = tid < H.n ? tid : 0;
+    const float b0v = (hb0 ? H.bias0 : dummy_f)[bidx_l], b1v = (hb1 ? H.bias1 : dummy_f)[bidx_l];
     GnLoaded gl = {};
     if constexpr (!RAW) gl = gn_load(b_first, tid < ctot0 ? tid : ctot0 - 1);
-    Blk dc = make_desc();
+    // (blocks 0, 1 and 2 mod nb of the first tile -- or, with two blocks per tile, block 0 of the next one -- from the preloaded entries)
+    Blk dc = make_desc_of(e_first[0]);
     advance();
     issue_a01(dc, 0u); issue_a23(dc, 0u); issue_halo(dc, 0u);
     issue_w(dc.w, 0);
-    Blk d1 = make_desc();
+    Blk d1 = make_desc_of(e_first[1]);
     advance();
     issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage);
-    Blk d2 = make_desc();
+    Blk d2 = make_desc_of(d_k == 0 ? e_first[0] : e_first[2]);
     advance();
-    if (tid < a.n) ldsBias[tid] = (hb0 ? b0v : 0.f) + (hb1 ? b1v : 0.f);
+    if (tid < H.n) ldsBias[tid] = (hb0 ? b0v : 0.f) + (hb1 ? b1v : 0.f);
     if (!RAW && tid < ctot0) gn_store(tid, gl, 0);
     kstamp(12);
     tl(1);
@@ -782,7 +810,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #ifdef ADF_RB_STAMP
             if (tseq == 1) kstamp(15);
 #endif
-            epilogue(tile_of(tseq - 1), cur_tile.n0);
+            epilogue(tile_of(tseq - 1), cur_tile.n0, sa2);       // (sa2: the stage of the previous tile's last block, not yet refilled)
         }
 #ifdef ADF_RB_TL
         tl(4 + tseq * 26 + 1);
@@ -800,7 +828,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     {
         const Tile last = tile_of(ntiles - 1);
         tl(108);
-        epilogue(last, 0);
+        epilogue(last, 0, sa2);
         tl(109);
     }
 #ifdef ADF_RB_TL

@@ -9,6 +9,15 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # The CPU oracle runs on torch's CPU convolutions, which do not scale to every core of a large host: on the 128-core GPU box one
+    # evaluation takes 18x longer at 128 threads than at 16 (bench.py's thread scan) -- the two full-size sampler tests alone took
+    # 290 s of a 616 s suite before this cap.
+    try:
+        import torch
+        if torch.get_num_threads() > 16:
+            torch.set_num_threads(16)
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "compat_branch: a gpu test that exercises the interface-compatibility branch on purpose")
 
