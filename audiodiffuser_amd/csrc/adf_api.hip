@@ -14,6 +14,7 @@
 #include "adf_conv2d.h"
 #include "adf_transformer.h"
 #include "adf_resblock_small.h"
+#include "adf_resblock_split.h"
 
 #include <algorithm>
 #include <cmath>
@@ -510,8 +511,9 @@ struct Walker {
         f1.stats0 = s0; f1.stats1 = s1; f1.c0 = x.C; f1.c1 = skip ? skip->C : 0; f1.L = x.L; f1.G = G; f1.B = B;
         f1.scale1 = sscale; f1.eps = 1e-5f; f1.gamma = r.g1w; f1.beta = r.g1b; f1.film = nullptr; f1.ab = ab1;
         // short levels in bf16 mode: the whole resblock in one launch (adf_resblock_small.h); ADF_RB_FUSED=0 keeps the separate launches
+        // (2 = four workgroups per sample in two launches when the batch leaves CUs idle, adf_resblock_split.h; 1 = always the one-launch kernel)
         static int rb_fused = -1;
-        if (rb_fused < 0) rb_fused = adf_route_switch("ADF_RB_FUSED", 1);
+        if (rb_fused < 0) rb_fused = adf_route_switch("ADF_RB_FUSED", 2);
         if (rb_fused && h->bf16 && (x.L == 16 || x.L == 64) && r.cout == 256 && x.C == 256 && (!skip || skip->C == 256) && G == 8 &&
             r.c1.wfrag && r.c2.wfrag && (!r.has_res || r.cr.wfrag) && r.c1.n_pad == 256 && !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) {
             Act y = new_act(r.cout, x.L);
@@ -526,7 +528,12 @@ struct Walker {
             fa.b1 = r.c1.bias; fa.b2 = r.c2.bias; fa.br = r.has_res ? r.cr.bias : nullptr;
             fa.skip_scale = sscale; fa.eps = 1e-5f;
             y.stats = alloc_stats(); fa.stats = y.stats;
-            if (live()) check(launch_resblock_small(fa, B, x.L, ctot, s));
+            if (rb_fused >= 2 && B * 4 <= 256) {
+                Act hact = new_act(r.cout, x.L);
+                RbSplitArgs sa;
+                sa.f = fa; sa.hact = (bf16_t*)hact.p;
+                if (live()) check(launch_resblock_split(sa, B, x.L, ctot, s));
+            } else if (live()) check(launch_resblock_small(fa, B, x.L, ctot, s));
             RbRec rec{name, GemmArgs{}, GemmArgs{}, r.cin, r.cout, x.L};
             rec.g1.nseg = 0;                               // marks a fused block for adf_bench_resblock (keeps the block numbering)
             p->rbs.push_back(rec);

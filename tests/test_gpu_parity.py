@@ -494,12 +494,13 @@ def test_transposed_conv_kernel_matches_the_generic_routes(tmp_path):
 @pytest.mark.parametrize("classes", ["", "1"])
 def test_fused_short_level_resblock_matches_the_unfused_launches(tmp_path, classes):
     """adf_resblock_small.h (one launch per ResnetBlock1d at the 64- and 16-position levels, bf16 mode; identity and 1x1-conv
-    residual, skip concat, FiLM -- with and without the per-sample class addend of a class-conditional net) against the
-    launches it replaces (ADF_RB_FUSED=0)."""
+    residual, skip concat, FiLM -- with and without the per-sample class addend of a class-conditional net) and adf_resblock_split.h
+    (the same blocks as two launches of four workgroups per sample, ADF_RB_FUSED=2: the default at batches <= 64) against the
+    launches they replace (ADF_RB_FUSED=0), and against each other: same arithmetic and rounding points, only the K sum is split."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         path = str(tmp_path / f"rb{mode}.pt")
         env = dict(os.environ, ADF_RB_FUSED=mode, ADF_TR_FUSED="0", B="5", CLASSES=classes)
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
@@ -513,6 +514,13 @@ def test_fused_short_level_resblock_matches_the_unfused_launches(tmp_path, class
     assert rel("down4.block0") < 1e-3, rel("down4.block0")   # identity residual, 64 positions
     assert rel("down5.block1") < 1e-2, rel("down5.block1")   # 16 positions
     assert rel("up0.block0") < 2e-2, rel("up0.block0")       # skip concat + 1x1 residual conv
+    assert rel("out") < 3e-2, rel("out")
+    a, b = outs["2"], outs["1"]                          # four workgroups per sample against one
+    assert all(bool(torch.isfinite(v).all()) for v in a.values())
+    assert rel("down4.conv") == 0.0
+    assert rel("down4.block0") < 1e-3, rel("down4.block0")
+    assert rel("down5.block1") < 1e-2, rel("down5.block1")
+    assert rel("up0.block0") < 2e-2, rel("up0.block0")
     assert rel("out") < 3e-2, rel("out")
 
 
