@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .adm_config import ADMConfig, param_specs
+from .adm_config import ADMConfig, param_specs, structure
 from .net import HipNet, _DTYPES
 
 _ZERO_INIT = (".out_layers.3.", ".proj_out.", "out.2.")        # zero_module, unet2d_oai.py:227, :309, :599
@@ -56,6 +56,15 @@ class UNetModel(HipNet):
                              conv_resample=conv_resample, num_classes=num_classes, num_heads=num_heads, num_head_channels=num_head_channels,
                              use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
                              use_new_attention_order=use_new_attention_order)
+        if compute_dtype in ("bf16", "bfloat16"):
+            # the bf16 (MFMA) conv routes read K in 64-channel chunks from either source of a skip concat: say which layer breaks that HERE,
+            # not as a generic "input channels must be a multiple of the 128-byte K chunk" at the first forward (WaveNetNoise does the same)
+            st = structure(self.cfg)
+            for layers in st.input_blocks[1:] + [st.middle] + st.output_blocks:
+                for l in layers:
+                    if l.cin % 64 or l.cout % 64:
+                        raise ValueError(f"compute_dtype='bf16' needs every conv width to be a multiple of 64 channels: {l.pre} is "
+                                         f"{l.cin} -> {l.cout} (model_channels={model_channels}, channel_mult={tuple(channel_mult)}); use compute_dtype='fp32'")
         for name, (shape, kind) in param_specs(self.cfg).items():
             self._register(name, nn.Parameter(_init_like_reference(name, shape, kind)))
 

@@ -79,8 +79,15 @@ def _draws(x: Tensor, n: int, injected: Optional[Tensor], needed: bool) -> Optio
             raise ValueError(f"injected_noise must be shaped [>= {n}, {', '.join(str(d) for d in x.shape)}] (one draw per step), "
                              f"got {tuple(injected.shape)}")
         return injected[:n].detach().to(device=x.device, dtype=torch.float32).contiguous()
-    draws = [torch.randn_like(x) for _ in range(n)]
-    return torch.stack(draws) if needed and n > 0 else None
+    if not needed or n <= 0:
+        scratch = torch.empty_like(x)                # the draws only advance the generator: one buffer, n times
+        for _ in range(n):
+            scratch.normal_()
+        return None
+    out = torch.empty((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)     # one [n, *x.shape] tensor filled row by row: the same
+    for i in range(n):                                                            # generator, the same order as n randn_like calls,
+        out[i].normal_()                                                          # half the transient memory of stack()
+    return out
 
 
 def _prep(noise: Tensor) -> Tensor:

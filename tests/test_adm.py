@@ -51,6 +51,9 @@ def test_plugin_state_dict_contract_and_refusals():
     for kw in ({"class_embed_dim": 8}, {"resblock_updown": True}, {"use_scale_shift_norm": False}, {"conv_resample": False}):
         with pytest.raises(NotImplementedError):
             A.UNetModel(**kw)
+    with pytest.raises(ValueError, match="multiple of 64 channels: input_blocks.1.0"):    # the bf16 routes' constraint is reported at construction
+        A.UNetModel(model_channels=48, compute_dtype="bf16")
+    A.UNetModel(model_channels=48, compute_dtype="fp32")
     assert C.sizeof(_lib.AdfAdmConfig) == 4 * (4 + 1 + 8 + 1 + 8 + 8)
     c = _lib.make_adm_config(cfg, _lib.DTYPE_BF16)
     assert (c.n_mult, list(c.channel_mult)[:4], c.n_attention_ds, c.attention_ds[0]) == (4, [1, 2, 2, 4], 1, 16)
