@@ -14,11 +14,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadf_hip.so")
-SOURCES = ["adf_gemm.hip", "adf_kernels.hip", "adf_wavenet.hip", "adf_conv2d.hip", "adf_api.hip"]
+SOURCES = ["adf_gemm.hip", "adf_kernels.hip", "adf_wavenet.hip", "adf_conv2d.hip", "adf_api.hip", "adf_net_unet1d.hip", "adf_net_wavenet.hip",
+           "adf_net_adm.hip", "adf_sampler.hip", "adf_bench_replay.hip"]
 # adf_gemm.hip: the SLP vectoriser would pair the prologue arithmetic that adf_gemm_pp.h places one element per MFMA gap
 # into v_pk_* operations (which are slower beside MFMAs and land in one gap instead of two)
 EXTRA_FLAGS = {"adf_gemm.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["adf_common.h", "adf_gemm.h", "adf_gemm_pp.h", "adf_gemm_rb.h", "adf_gemm_up.h", "adf_kernels.h", "adf_wavenet.h", "adf_conv2d.h", "adf_transformer.h", "adf_resblock_small.h", "adf_resblock_split.h", os.path.join("..", "..", "include", "audiodiffuser_amd.h")]
+HEADERS = ["adf_common.h", "adf_gemm.h", "adf_gemm_pp.h", "adf_gemm_rb.h", "adf_gemm_up.h", "adf_kernels.h", "adf_wavenet.h", "adf_conv2d.h", "adf_transformer.h", "adf_resblock_small.h", "adf_resblock_split.h", "adf_api_internal.h", os.path.join("..", "..", "include", "audiodiffuser_amd.h")]
 ARCH = "gfx950"
 
 
@@ -59,7 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
         return o
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(bdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

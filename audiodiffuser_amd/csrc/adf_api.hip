@@ -7,751 +7,14 @@
 //   Down/UpsampleBlock1d      src/models/backbones/unet1d.py:441-468, :542-566
 //   Diffusion.denoise_fn      src/models/components/diffusion.py:32-63
 //   EDMSampler / Alpha / DPM  src/models/components/sampler_edm.py:333-397, :251-300, :624-768
-#include "../../include/audiodiffuser_amd.h"
-#include "adf_gemm.h"
-#include "adf_kernels.h"
-#include "adf_wavenet.h"
-#include "adf_conv2d.h"
-#include "adf_transformer.h"
-#include "adf_resblock_small.h"
-#include "adf_resblock_split.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <cstdlib>
-#include <map>
-#include <string>
-#include <vector>
+#include "adf_api_internal.h"
 
 using namespace adf;
+using namespace adf_api;
 
-namespace {
+namespace adf_api {
 
 std::string g_create_error;
-
-struct ConvW {
-    void* w = nullptr;
-    void* wfrag = nullptr;   // transformer 1x1 weights (bf16): second copy in MFMA-fragment order (adf_transformer.h)
-    float* bias = nullptr;
-    int cout = 0, cin = 0, K = 0, n = 0, n_pad = 0, nchunk = 0, taps = 0, f = 0;
-};
-struct ResW {
-    int cin = 0, cout = 0, film_off = 0;
-    float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr;
-    ConvW c1, c2, cr;
-    bool has_res = false;
-};
-struct TrW {
-    int c = 0, mid = 0;
-    float *lnw = nullptr, *lnb = nullptr, *g0 = nullptr, *g3 = nullptr;
-    ConvW qkv, proj, ff1, ff2;
-};
-struct DownW { ConvW down; std::vector<ResW> blocks; bool attn = false; TrW tr; int factor = 1, cin = 0, cout = 0; };
-struct UpW { std::vector<ResW> blocks; bool attn = false; TrW tr; ConvW up; int factor = 1, cin = 0, cout = 0; };
-
-struct Slot {
-    int kind = 0;  // 0 = fp32 copy, 1 = pack conv/linear, 2 = pack transposed conv
-    void* dst = nullptr;
-    void* frag = nullptr;    // also repacked to ConvW::wfrag after packing
-    int64_t numel = 0;
-    bool loaded = false;
-    int cout = 0, cin = 0, K = 0, f = 0, n_offset = 0, n_pad = 0, nchunk = 0, taps = 0;
-};
-
-struct Act { void* p = nullptr; int C = 0, L = 0; double* stats = nullptr; };
-struct TapRec { std::string name; void* p; int C, L; int f32 = 0; float scale = 1.0f; };   // f32: an fp32 buffer whatever the storage mode
-
-// WaveNetNoise (wavenet.py:153-180): a weight-normed conv keeps the state-dict tensors (bias, 0-dim g, v) in fp32 and a packed
-// GEMM operand of the effective weight v * g / ||v||, rebuilt when a tensor was (re)loaded
-struct WnConv {
-    float *bias = nullptr, *g = nullptr, *v = nullptr;
-    void* packed = nullptr;
-    int cout = 0, cin = 0, K = 0;
-};
-// ADM-style 2-D U-Net (unet2d_oai.py:382-635): the module list of UNetModel.__init__ as data
-struct AdmRes { int cin = 0, cout = 0, film_off = 0; float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr; ConvW c1, c2, skip; bool has_skip = false; };
-struct AdmAttn { int c = 0, heads = 0; float *gw = nullptr, *gb = nullptr; ConvW qkv, proj; float* qkv_tmp = nullptr; };
-struct AdmLayer { int kind; int idx; };       // kind: 0 input conv, 1 ResBlock, 2 AttentionBlock, 3 Downsample, 4 Upsample
-struct AdmW {
-    adf_adm_config cfg;
-    int H = 0, W = 0;                    // image shape of the calls that follow (adf_set_image_shape)
-    std::vector<AdmRes> res;
-    std::vector<AdmAttn> attn;
-    std::vector<ConvW> resample;
-    std::vector<std::vector<AdmLayer>> input_blocks, output_blocks;
-    std::vector<AdmLayer> middle;
-    std::vector<int> skip_ch;            // channels of the input-block outputs, in push order
-    float *in_w = nullptr, *in_b = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
-    float *out_gw = nullptr, *out_gb = nullptr, *out_w = nullptr, *out_b = nullptr;
-    int input_ch = 0, final_ch = 0;
-    int fg = 4;                          // channels per fine statistics group: gcd of every GroupNorm group size of the net (incl. the skip concats)
-};
-
-struct WnW {
-    adf_wavenet_config cfg;
-    WnConv in, sp;
-    std::vector<WnConv> dil, outp;
-    float *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr, *out_w = nullptr, *out_b = nullptr;
-    double* sumsq = nullptr;             // scratch of the norm reduction
-    bool packed = false;
-};
-struct RbRec { std::string name; GemmArgs g1, g2; int cin, cout, L; };
-
-struct Plan {
-    int B = 0, L = 0;
-    char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
-    char* stats = nullptr; size_t stats_bytes = 0, stats_off = 0;
-    bool dry = false;
-    std::vector<TapRec> taps;
-    std::vector<RbRec> rbs;
-    float *temb = nullptr, *film = nullptr, *coef = nullptr;
-    // per sampler run: (c_in, c_noise, c_skip, c_out), sigma embedding and the FiLM projections of EVERY denoiser evaluation of
-    // the run, computed by three launches at the head of the loop (sigma is uniform over the batch and the whole schedule is
-    // known on the host) instead of three launches per evaluation
-    float *coef_all = nullptr, *temb_all = nullptr, *film_all = nullptr;
-    int pre_cap = 0;
-    // sampler state (fp32 [B][C][L] each)
-    float* sb[10] = {nullptr};
-    float* noise_stage = nullptr; float* out_stage = nullptr; float* inj_stage = nullptr; size_t inj_cap = 0;
-    float* cfg_c = nullptr; float* cfg_n = nullptr;      // raw network outputs of the two CFG branches
-    float* dyn_scale = nullptr;                          // [B] per-sample scales of the dynamic threshold
-    // captured sampler loops, most recently used first; at most kMaxGraphsPerPlan are kept (the oldest is destroyed)
-    std::vector<std::pair<std::string, hipGraphExec_t>> graphs;
-    std::vector<void*> allocs;                            // device memory owned by this plan (released when the plan is evicted)
-    int64_t bytes = 0;
-    unsigned long long last_use = 0;
-    // timing replay buffers of adf_bench_resblock (rotating copies of one layer's operands), sized on first use
-    char* bench_buf = nullptr; size_t bench_cap = 0;
-    // WaveNetNoise: the layer launches of the last pass, for adf_bench_wavenet_layer
-    WnIO wn_io; std::vector<WnLayerArgs> wn_layers;
-};
-constexpr size_t kMaxGraphsPerPlan = 8;
-constexpr size_t kMaxPlans = 4;      // (B, L) workspaces kept per handle; the least recently used one is released beyond that
-
-}  // namespace
-
-struct adf_handle {
-    adf_net_config cfg;
-    int device = 0;                     // the device that was current at adf_create: every entry point runs on it
-    unsigned long long use_clock = 0;
-    bool bf16 = false;
-    int esz = 4, kc = 32;
-    std::string err;
-    std::vector<void*> allocs;
-    int64_t bytes = 0;
-    std::vector<std::string> names;
-    std::map<std::string, Slot> slots;
-    float *to_in_w = nullptr, *to_out_w = nullptr, *fourier = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr,
-          *t_b2 = nullptr, *film_w = nullptr, *film_b = nullptr;
-    int film_total = 0;
-    // class conditioning (LabelEmbedder) and the state set by adf_set_condition
-    float *lab_null = nullptr, *lab_emb = nullptr, *lab_lnw = nullptr, *lab_lnb = nullptr, *lab_w1 = nullptr, *lab_b1 = nullptr,
-          *lab_w2 = nullptr, *lab_b2 = nullptr;
-    int cdim = 0;                       // width of the class embedding (4 * channels) or 0
-    bool cond_on = false;
-    int cond_B = 0;
-    float cond_scale = 1.0f;
-    float dyn_q = 0.0f;                                  // > 0: dynamic thresholding at this quantile instead of clamp(-1, 1) (adf_set_dynamic_threshold)
-    long long* cond_classes = nullptr;  // [cond_B]
-    float* cond_emb = nullptr;          // [cond_B + 1][cdim], last row = null embedding
-    float* cond_film = nullptr;         // [cond_B + 1][film_total]: class part of every FiLM projection
-    int cond_cap = 0;
-    std::vector<DownW> downs;
-    ResW mid_pre, mid_post;
-    TrW mid_tr;
-    std::vector<UpW> ups;
-    // (B, L, H): H = image height of a UNetModel handle (W = L / H), 0 otherwise -- two image shapes with equal H * W must not share
-    // a workspace: captured graphs and tap shapes carry the conv2d geometry
-    std::map<std::tuple<int, int, int>, Plan*> plans;
-    Plan* last_plan = nullptr;
-    WnW* wn = nullptr;                  // non-null: the handle is a WaveNetNoise (adf_wavenet_create), not a UNet1dBase
-    AdmW* adm = nullptr;                // non-null: the handle is an ADM-style UNetModel (adf_adm_create)
-    // graphs are captured and replayed on a library-owned stream (the caller's stream may be the legacy
-    // default stream, which cannot be captured); it is fenced against the caller's stream with events
-    hipStream_t gstream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    adf_run_counters ctr{};             // what the device loop has done so far (adf_get_counters): lets a test tell it from a host-side loop
-};
-
-namespace {
-
-int fail(adf_handle* h, const std::string& m) { h->err = m; return 1; }
-
-// Makes the handle's device current for the duration of a C entry point (and restores the caller's afterwards): buffers,
-// kernel attributes and launches of one handle all belong to the device it was created on, whatever is current in the caller.
-struct DeviceScope {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceScope(const adf_handle* h) {
-        if (!h) return;
-        int cur = -1;
-        if (hipGetDevice(&cur) != hipSuccess) { ok = false; return; }
-        if (cur != h->device) {
-            if (hipSetDevice(h->device) != hipSuccess) { ok = false; return; }
-            prev = cur;
-        }
-    }
-    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-#define ADF_ON_DEVICE(h)                                                            \
-    DeviceScope adf_scope_(h);                                                      \
-    if (!adf_scope_.ok) return fail(h, "could not make the handle's device current")
-
-// device memory owned by the handle (weights, condition buffers) or, with `owner`, by one (B, L) plan
-void* dalloc(adf_handle* h, size_t bytes, Plan* owner = nullptr) {
-    void* p = nullptr;
-    bytes = (bytes + 255) & ~(size_t)255;
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, bytes);
-    (owner ? owner->allocs : h->allocs).push_back(p);
-    if (owner) owner->bytes += (int64_t)bytes;
-    h->bytes += (int64_t)bytes;
-    return p;
-}
-void dfree(adf_handle* h, void* ptr, size_t bytes, Plan* owner = nullptr) {
-    if (!ptr) return;
-    std::vector<void*>& v = owner ? owner->allocs : h->allocs;
-    auto it = std::find(v.begin(), v.end(), ptr);
-    if (it != v.end()) v.erase(it);
-    bytes = (bytes + 255) & ~(size_t)255;
-    if (owner) owner->bytes -= (int64_t)bytes;
-    h->bytes -= (int64_t)bytes;
-    (void)hipFree(ptr);
-}
-void drop_graphs(Plan* p) {
-    for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.second);
-    p->graphs.clear();
-}
-// (the caller has synchronised the device if work of this plan may still be in flight)
-void destroy_plan(adf_handle* h, Plan* p) {
-    drop_graphs(p);
-    for (void* q : p->allocs) (void)hipFree(q);
-    h->bytes -= p->bytes;
-    if (h->last_plan == p) h->last_plan = nullptr;
-    delete p;
-}
-
-// ---- weight registry ---------------------------------------------------------------------------
-struct Registrar {
-    adf_handle* h;
-    bool ok = true;
-    float* reg_f32(const std::string& name, int64_t numel, float* dst = nullptr) {
-        if (!dst) dst = (float*)dalloc(h, (size_t)numel * 4);
-        if (!dst) { ok = false; return nullptr; }
-        Slot s; s.kind = 0; s.dst = dst; s.numel = numel;
-        h->names.push_back(name); h->slots[name] = s;
-        return dst;
-    }
-    // Conv1d / Linear weight (cout, cin, K) packed as GEMM operand; several tensors may share one packed
-    // buffer at different row offsets (fused qkv).
-    void reg_pack(const std::string& name, ConvW& w, int cout, int cin, int K, int n_offset, int n_total, bool transposed, int f) {
-        if (!w.w) {
-            w.cin = cin; w.K = K; w.f = f;
-            w.taps = transposed ? 2 : K;
-            w.n = n_total; w.n_pad = round_up(n_total, 32);
-            w.nchunk = ceil_div(cin, h->kc);
-            // + kTapGroup slabs of 128 rows: the kernel's weight staging loads are unguarded (adf_gemm.h)
-            w.w = dalloc(h, ((size_t)w.nchunk * w.taps * w.n_pad + (size_t)kTapGroup * (w.n_pad + 128)) * kRowBytes);
-            if (!w.w) { ok = false; return; }
-        }
-        w.cout = cout;
-        Slot s; s.kind = transposed ? 2 : 1; s.dst = w.w; s.numel = (int64_t)cout * cin * K;
-        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = n_offset; s.n_pad = w.n_pad; s.nchunk = w.nchunk; s.taps = w.taps;
-        h->names.push_back(name); h->slots[name] = s;
-    }
-    void conv(const std::string& pre, ConvW& w, int cout, int cin, int K, bool bias) {
-        reg_pack(pre + ".weight", w, cout, cin, K, 0, cout, false, 0);
-        if (bias) w.bias = reg_f32(pre + ".bias", cout);
-    }
-    // Strided Conv1d (kernel f*km + 1, stride f, pad f*(km/2)) folded to a stride-1 conv with km + 1 taps over
-    // f*cin channels: the contiguous [L][cin] input is the same memory as [L/f][f*cin], so the fast stride-1 GEMM
-    // kernels apply unchanged (the folded taps beyond the real kernel length are zero weights)
-    void conv_folded(const std::string& pre, ConvW& w, int cout, int cin, int K, int f) {
-        w.cin = f * cin; w.K = K; w.f = f;
-        w.taps = (K - 1) / f + 1;
-        w.n = cout; w.n_pad = round_up(cout, 32);
-        w.nchunk = ceil_div(f * cin, h->kc);
-        w.w = dalloc(h, ((size_t)w.nchunk * w.taps * w.n_pad + (size_t)kTapGroup * (w.n_pad + 128)) * kRowBytes);
-        if (!w.w) { ok = false; return; }
-        w.cout = cout;
-        Slot s; s.kind = 3; s.dst = w.w; s.numel = (int64_t)cout * cin * K;
-        s.cout = cout; s.cin = cin; s.K = K; s.f = f; s.n_offset = 0; s.n_pad = w.n_pad; s.nchunk = w.nchunk; s.taps = w.taps;
-        h->names.push_back(pre + ".weight"); h->slots[pre + ".weight"] = s;
-        w.bias = reg_f32(pre + ".bias", cout);
-    }
-    void resblock(const std::string& pre, ResW& r, int cin, int cout, int temb) {
-        r.cin = cin; r.cout = cout;
-        r.film_off = h->film_total;
-        h->film_total += 2 * cout;
-        // FiLM weights are registered later (one concatenated matrix), remember the order via names
-        film_names.push_back({pre, r.film_off, 2 * cout});
-        r.g1w = reg_f32(pre + ".block1.groupnorm.weight", cin);
-        r.g1b = reg_f32(pre + ".block1.groupnorm.bias", cin);
-        conv(pre + ".block1.project", r.c1, cout, cin, 3, true);
-        r.g2w = reg_f32(pre + ".block2.groupnorm.weight", cout);
-        r.g2b = reg_f32(pre + ".block2.groupnorm.bias", cout);
-        conv(pre + ".block2.project", r.c2, cout, cout, 3, true);
-        r.has_res = cin != cout;
-        if (r.has_res) conv(pre + ".to_out", r.cr, cout, cin, 1, true);
-        if (h->bf16 && (cout == 256 || cout == 128) && (cin == cout || cin == 2 * cout)) {   // fragment-major copies: adf_resblock_small.h, adf_gemm_tile.h
-            const std::pair<const char*, ConvW*> m[] = {{".block1.project.weight", &r.c1}, {".block2.project.weight", &r.c2}, {".to_out.weight", &r.cr}};
-            for (const auto& kv : m) {
-                ConvW* w = kv.second;
-                if (!w->w) continue;
-                w->wfrag = dalloc(h, (size_t)w->nchunk * w->taps * w->n_pad * kRowBytes);
-                if (!w->wfrag) { ok = false; return; }
-                h->slots[pre + kv.first].frag = w->wfrag;
-            }
-        }
-        (void)temb;
-    }
-    void transformer(const std::string& pre, TrW& t, int c, int mult) {
-        t.c = c; t.mid = c * mult;
-        t.lnw = reg_f32(pre + ".norm.weight", c);
-        t.lnb = reg_f32(pre + ".norm.bias", c);
-        reg_pack(pre + ".attention.to_q.weight", t.qkv, c, c, 1, 0, 3 * c, false, 0);
-        reg_pack(pre + ".attention.to_kv.weight", t.qkv, 2 * c, c, 1, c, 3 * c, false, 0);
-        t.qkv.cout = 3 * c;
-        conv(pre + ".attention.to_out", t.proj, c, c, 1, false);
-        t.g0 = reg_f32(pre + ".feed_forward.0.g", c);
-        conv(pre + ".feed_forward.1", t.ff1, t.mid, c, 1, false);
-        t.g3 = reg_f32(pre + ".feed_forward.3.g", t.mid);
-        conv(pre + ".feed_forward.4", t.ff2, c, t.mid, 1, false);
-        if (h->bf16) {
-            for (ConvW* w : {&t.qkv, &t.proj, &t.ff1, &t.ff2}) {
-                w->wfrag = dalloc(h, (size_t)w->nchunk * w->n_pad * kRowBytes);
-                if (!w->wfrag) { ok = false; return; }
-            }
-            const std::pair<const char*, ConvW*> m[] = {{".attention.to_q.weight", &t.qkv}, {".attention.to_kv.weight", &t.qkv},
-                                                       {".attention.to_out.weight", &t.proj}, {".feed_forward.1.weight", &t.ff1},
-                                                       {".feed_forward.4.weight", &t.ff2}};
-            for (const auto& kv : m) h->slots[pre + kv.first].frag = kv.second->wfrag;
-        }
-    }
-    struct FilmName { std::string pre; int off, rows; };
-    std::vector<FilmName> film_names;
-};
-
-int build_weights(adf_handle* h) {
-    const adf_net_config& c = h->cfg;
-    Registrar R{h};
-    const int ch = c.channels, tdim = 4 * ch, n = c.num_layers;
-    h->cdim = c.num_classes > 0 ? 4 * ch : 0;
-    const int temb = tdim + h->cdim;     // every FiLM Linear reads cat(time_embed, class_embed) (unet1d.py:272)
-    if (c.num_classes > 0) {             // conditioner.py:64-90, registered before the U-Net
-        h->lab_null = R.reg_f32("label_conditioner.null_classes_emb", ch);
-        h->lab_emb = R.reg_f32("label_conditioner.label_emb.weight", (int64_t)c.num_classes * ch);
-        h->lab_lnw = R.reg_f32("label_conditioner.class_to_cond.0.weight", ch);
-        h->lab_lnb = R.reg_f32("label_conditioner.class_to_cond.0.bias", ch);
-        h->lab_w1 = R.reg_f32("label_conditioner.class_to_cond.1.weight", (int64_t)h->cdim * ch);
-        h->lab_b1 = R.reg_f32("label_conditioner.class_to_cond.1.bias", h->cdim);
-        h->lab_w2 = R.reg_f32("label_conditioner.class_to_cond.3.weight", (int64_t)h->cdim * h->cdim);
-        h->lab_b2 = R.reg_f32("label_conditioner.class_to_cond.3.bias", h->cdim);
-    }
-    h->to_in_w = R.reg_f32("unet.to_in.to_in.weight", (int64_t)c.num_filters * c.in_channels * c.window_length);
-    h->to_out_w = R.reg_f32("unet.to_out.to_out.weight", (int64_t)c.num_filters * c.out_channels * c.window_length);
-    h->fourier = R.reg_f32("unet.to_time.0.0.weights", ch / 2);
-    h->t_w1 = R.reg_f32("unet.to_time.0.1.weight", (int64_t)tdim * (ch + 1));
-    h->t_b1 = R.reg_f32("unet.to_time.0.1.bias", tdim);
-    h->t_w2 = R.reg_f32("unet.to_time.2.weight", (int64_t)tdim * tdim);
-    h->t_b2 = R.reg_f32("unet.to_time.2.bias", tdim);
-    h->downs.resize(n);
-    for (int i = 0; i < n; ++i) {
-        DownW& d = h->downs[i];
-        d.cin = ch * c.multipliers[i]; d.cout = ch * c.multipliers[i + 1]; d.factor = c.factors[i];
-        const std::string pre = "unet.downsamples." + std::to_string(i);
-        R.conv_folded(pre + ".downsample", d.down, d.cout, d.cin, d.factor * c.kernel_multiplier_downsample + 1, d.factor);
-        d.blocks.resize(c.num_blocks[i]);
-        for (int j = 0; j < c.num_blocks[i]; ++j) R.resblock(pre + ".blocks." + std::to_string(j), d.blocks[j], d.cout, d.cout, temb);
-        d.attn = c.attentions[i] != 0;
-        if (d.attn) R.transformer(pre + ".transformer", d.tr, d.cout, c.attention_multiplier);
-    }
-    const int cb = ch * c.multipliers[n];
-    R.resblock("unet.bottleneck.pre_block", h->mid_pre, cb, cb, temb);
-    if (c.use_attention_bottleneck) R.transformer("unet.bottleneck.transformer", h->mid_tr, cb, c.attention_multiplier);
-    R.resblock("unet.bottleneck.post_block", h->mid_post, cb, cb, temb);
-    h->ups.resize(n);
-    for (int u = 0; u < n; ++u) {
-        const int i = n - 1 - u;
-        UpW& up = h->ups[u];
-        up.cin = ch * c.multipliers[i + 1]; up.cout = ch * c.multipliers[i]; up.factor = c.factors[i];
-        const std::string pre = "unet.upsamples." + std::to_string(u);
-        const int nb = c.num_blocks[i] + (c.attentions[i] ? 1 : 0);
-        up.blocks.resize(nb);
-        for (int j = 0; j < nb; ++j) R.resblock(pre + ".blocks." + std::to_string(j), up.blocks[j], 2 * up.cin, up.cin, temb);
-        up.attn = c.attentions[i] != 0;
-        if (up.attn) R.transformer(pre + ".transformer", up.tr, up.cin, c.attention_multiplier);
-        const int f = up.factor;
-        R.reg_pack(pre + ".upsample.weight", up.up, up.cout, up.cin, 2 * f, 0, f * up.cout, true, f);
-        if (h->bf16 && up.up.w && (up.cin == 128 || up.cin == 256) && (up.cout == 64 || up.cout == 128 || up.cout == 256) && (f == 2 || f == 4)) {
-            up.up.wfrag = dalloc(h, (size_t)up.up.nchunk * up.up.taps * up.up.n_pad * kRowBytes);   // fragment-major copy: adf_gemm_up.h
-            if (!up.up.wfrag) R.ok = false;
-            else h->slots[pre + ".upsample.weight"].frag = up.up.wfrag;
-        }
-        up.up.bias = R.reg_f32(pre + ".upsample.bias", up.cout);
-    }
-    // one concatenated FiLM projection for all resblocks
-    h->film_w = (float*)dalloc(h, (size_t)h->film_total * temb * 4);
-    h->film_b = (float*)dalloc(h, (size_t)h->film_total * 4);
-    if (!h->film_w || !h->film_b) R.ok = false;
-    for (const auto& fn : R.film_names) {
-        R.reg_f32(fn.pre + ".to_cond_embedding.1.weight", (int64_t)fn.rows * temb, h->film_w + (size_t)fn.off * temb);
-        R.reg_f32(fn.pre + ".to_cond_embedding.1.bias", fn.rows, h->film_b + fn.off);
-    }
-    return R.ok ? 0 : fail(h, "device allocation failed while building the weight registry");
-}
-
-// ---- per-(B, L) plan -----------------------------------------------------------------------------
-struct Walker {
-    adf_handle* h;
-    Plan* p;
-    hipStream_t s;
-    bool bad = false;
-    const float* film2 = nullptr;       // class part of the FiLM projections for this pass (FwdIO::film2)
-    int film2_bstride = 0;
-    const float* film = nullptr;        // time part: Plan::film, or the evaluation's row of Plan::film_all
-
-    void check(const char* e) { if (e && !bad) { bad = true; h->err = e; } }
-    void* alloc(size_t bytes) {
-        bytes = (bytes + 255) & ~(size_t)255;
-        const size_t off = p->arena_off;
-        p->arena_off += bytes;
-        if (p->dry) return nullptr;
-        if (p->arena_off > p->arena_bytes) { check("arena overflow"); return nullptr; }
-        return p->arena + off;
-    }
-    double* alloc_stats() {
-        const size_t bytes = ((size_t)p->B * h->cfg.resnet_groups * 2 * sizeof(double) + 255) & ~(size_t)255;
-        const size_t off = p->stats_off;
-        p->stats_off += bytes;
-        if (p->dry) return (double*)(uintptr_t)(off + 256);  // non-null marker
-        if (p->stats_off > p->stats_bytes) { check("stats arena overflow"); return nullptr; }
-        return (double*)(p->stats + off);
-    }
-    Act new_act(int C, int L) { Act a; a.C = C; a.L = L; a.p = alloc((size_t)p->B * L * C * h->esz); return a; }
-    void tap(const std::string& name, const Act& a) { p->taps.push_back({name, a.p, a.C, a.L}); }
-    bool live() const { return !p->dry && !bad; }
-
-    bool can_fuse_stats(int C) const {
-        if (h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS) return false;
-        const int G = h->cfg.resnet_groups;
-        if (C % G) return false;
-        const int gs = C / G;
-        return (gs & (gs - 1)) == 0;
-    }
-    double* ensure_stats(Act& t) {
-        if (!t.stats) {
-            t.stats = alloc_stats();
-            if (live()) check(launch_gn_stats(t.p, h->bf16, p->B, t.L, t.C, h->cfg.resnet_groups, t.stats, s));
-        }
-        return t.stats;
-    }
-
-    GemmArgs gemm_base(const Act& out, int lin, int mrows, const ConvW& w) {
-        GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        g.nseg = 1; g.B = p->B; g.lin = lin; g.mrows = mrows; g.n = w.n; g.n_pad = w.n_pad;
-        g.bias0 = w.bias; g.bias_mod = w.n > 0 ? w.n : 1;
-        g.out = out.p; g.out_rows = out.L; g.out_c = out.C;
-        return g;
-    }
-    static GemmSeg seg_of(const Act& x, const Act* skip, const float* ab, float scale1, int act, int taps, int stride, int off0,
-                          int step, const ConvW& w) {
-        GemmSeg sg;
-        memset(&sg, 0, sizeof(sg));
-        sg.src0 = x.p; sg.c0 = x.C;
-        sg.src1 = skip ? skip->p : nullptr; sg.c1 = skip ? skip->C : 0;
-        sg.ab = ab; sg.scale1 = scale1; sg.act = act;
-        sg.taps = taps; sg.stride = stride; sg.off0 = off0; sg.step = step;
-        sg.w = w.w; sg.wfrag = w.wfrag; sg.nchunk = w.nchunk;
-        return sg;
-    }
-    void run_gemm(GemmArgs& g, Act& out, bool want_stats) {
-        const bool ask = want_stats && can_fuse_stats(out.C);      // also for the phase-scattered transposed convs
-        if (ask) {
-            out.stats = alloc_stats();
-            g.stats = out.stats; g.stats_groups = h->cfg.resnet_groups;
-        }
-        if (live()) {
-            bool fused = false;
-            check(launch_conv_gemm(g, h->bf16, s, &fused));
-            // the launcher may decline (tile shape / group size): fill the same buffer with the separate pass
-            if (ask && !fused) check(launch_gn_stats(out.p, h->bf16, p->B, out.L, out.C, h->cfg.resnet_groups, out.stats, s));
-        }
-    }
-
-    Act linear(const Act& x, const ConvW& w, const void* res, int gelu, bool want_stats) {
-        // a 1x1 op has no halo: run it over the flattened [B*L] rows as one long sample
-        Act out = new_act(w.n, x.L);
-        const int rows = p->B * x.L;
-        GemmArgs g = gemm_base(out, rows, rows, w);
-        g.B = 1; g.out_rows = rows;
-        g.seg[0] = seg_of(x, nullptr, nullptr, 1.f, 0, 1, 1, 0, 1, w);
-        g.res = res; g.gelu = gelu;
-        run_gemm(g, out, false);
-        (void)want_stats;   // per-sample statistics come from the separate pass (ensure_stats) when needed
-        return out;
-    }
-
-    Act resblock(const std::string& name, Act& x, Act* skip, const ResW& r, int nb) {
-        const int B = p->B, G = h->cfg.resnet_groups;
-        const float sscale = h->cfg.use_skip_scale ? 0.70710678118654752440f : 1.0f;
-        const int ctot = x.C + (skip ? skip->C : 0);
-        if (ctot != r.cin) check("resblock: channel mismatch");
-        double* s0 = ensure_stats(x);
-        double* s1 = skip ? ensure_stats(*skip) : nullptr;
-        static int short_max = -1;       // ADF_SHORT_LEVEL: longest level that materialises silu(GN(x)) for flat GEMM tiles
-        if (short_max < 0) short_max = (int)adf_tuning("ADF_SHORT_LEVEL", 32);
-        const bool short_level = x.L <= short_max && (x.L & (x.L - 1)) == 0;
-        float* ab1 = (float*)alloc((size_t)B * ctot * 2 * 4);
-        GnFinalizeArgs f1;
-        memset(&f1, 0, sizeof(f1));
-        f1.stats0 = s0; f1.stats1 = s1; f1.c0 = x.C; f1.c1 = skip ? skip->C : 0; f1.L = x.L; f1.G = G; f1.B = B;
-        f1.scale1 = sscale; f1.eps = 1e-5f; f1.gamma = r.g1w; f1.beta = r.g1b; f1.film = nullptr; f1.ab = ab1;
-        // short levels in bf16 mode: the whole resblock in one launch (adf_resblock_small.h); ADF_RB_FUSED=0 keeps the separate launches
-        // (2 = four workgroups per sample in two launches when the batch leaves CUs idle, adf_resblock_split.h; 1 = always the one-launch kernel)
-        static int rb_fused = -1;
-        if (rb_fused < 0) rb_fused = adf_route_switch("ADF_RB_FUSED", 2);
-        if (rb_fused && h->bf16 && (x.L == 16 || x.L == 64) && r.cout == 256 && x.C == 256 && (!skip || skip->C == 256) && G == 8 &&
-            r.c1.wfrag && r.c2.wfrag && (!r.has_res || r.cr.wfrag) && r.c1.n_pad == 256 && !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) {
-            Act y = new_act(r.cout, x.L);
-            RbFusedArgs fa;
-            memset(&fa, 0, sizeof(fa));
-            fa.x = (const bf16_t*)x.p; fa.skip = skip ? (const bf16_t*)skip->p : nullptr; fa.out = (bf16_t*)y.p;
-            fa.gn1 = f1;
-            fa.gamma2 = r.g2w; fa.beta2 = r.g2b;
-            fa.film = film + r.film_off; fa.film_bstride = nb == 1 ? 0 : h->film_total;
-            if (film2) { fa.film2 = film2 + r.film_off; fa.film2_bstride = film2_bstride; }
-            fa.w1 = r.c1.wfrag; fa.w2 = r.c2.wfrag; fa.wr = r.has_res ? r.cr.wfrag : nullptr;
-            fa.b1 = r.c1.bias; fa.b2 = r.c2.bias; fa.br = r.has_res ? r.cr.bias : nullptr;
-            fa.skip_scale = sscale; fa.eps = 1e-5f;
-            y.stats = alloc_stats(); fa.stats = y.stats;
-            if (rb_fused >= 2 && B * 4 <= 256) {
-                Act hact = new_act(r.cout, x.L);
-                RbSplitArgs sa;
-                sa.f = fa; sa.hact = (bf16_t*)hact.p;
-                if (live()) check(launch_resblock_split(sa, B, x.L, ctot, s));
-            } else if (live()) check(launch_resblock_small(fa, B, x.L, ctot, s));
-            RbRec rec{name, GemmArgs{}, GemmArgs{}, r.cin, r.cout, x.L};
-            rec.g1.nseg = 0;                               // marks a fused block for adf_bench_resblock (keeps the block numbering)
-            p->rbs.push_back(rec);
-            tap(name, y);
-            return y;
-        }
-        Act h1 = new_act(r.cout, x.L);
-        GemmArgs g1 = gemm_base(h1, x.L, x.L, r.c1);
-        if (short_level) {
-            // short levels: one launch normalises + activates the (concatenated) input; the GEMM then takes raw tiles
-            Act a1 = new_act(ctot, x.L);
-            if (live()) check(launch_gn_norm_apply(x.p, skip ? skip->p : nullptr, f1, 1, a1.p, h->bf16, s));
-            g1.seg[0] = seg_of(a1, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, r.c1);
-        } else {
-            g1.seg[0] = seg_of(x, skip, ab1, sscale, 1, 3, 1, -1, 1, r.c1);
-            g1.seg[0].gn = f1;           // launch_conv_gemm derives the table (in the DMA kernel) or launches gn_finalize
-        }
-        run_gemm(g1, h1, true);
-        tap(name + ".h1", h1);        // the block's stored intermediate (not there when the whole block is one launch)
-        double* sh = ensure_stats(h1);
-        float* ab2 = (float*)alloc((size_t)B * r.cout * 2 * 4);
-        GnFinalizeArgs f2;
-        memset(&f2, 0, sizeof(f2));
-        f2.stats0 = sh; f2.c0 = r.cout; f2.L = x.L; f2.G = G; f2.B = B; f2.scale1 = 1.f; f2.eps = 1e-5f;
-        f2.gamma = r.g2w; f2.beta = r.g2b;
-        f2.film = film + r.film_off; f2.film_bstride = nb == 1 ? 0 : h->film_total; f2.ab = ab2;
-        if (film2) { f2.film2 = film2 + r.film_off; f2.film2_bstride = film2_bstride; }
-        Act y = new_act(r.cout, x.L);
-        GemmArgs g2 = gemm_base(y, x.L, x.L, r.c2);
-        if (short_level) {
-            Act a2 = new_act(r.cout, x.L);
-            if (live()) check(launch_gn_norm_apply(h1.p, nullptr, f2, 1, a2.p, h->bf16, s));
-            g2.seg[0] = seg_of(a2, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, r.c2);
-        } else {
-            g2.seg[0] = seg_of(h1, nullptr, ab2, 1.f, 1, 3, 1, -1, 1, r.c2);
-            g2.seg[0].gn = f2;
-        }
-        if (r.has_res) {
-            g2.nseg = 2;
-            g2.seg[1] = seg_of(x, skip, nullptr, sscale, 0, 1, 1, 0, 1, r.cr);
-            g2.bias1 = r.cr.bias;
-        } else {
-            if (skip) check("resblock: identity residual with a skip input");
-            g2.res = x.p;
-        }
-        run_gemm(g2, y, true);
-        p->rbs.push_back({name, g1, g2, r.cin, r.cout, x.L});
-        tap(name, y);
-        return y;
-    }
-
-    Act transformer(const std::string& name, Act& x, const TrW& t) {
-        const long long rows = (long long)p->B * x.L;
-        // short levels in bf16 mode: the whole block in one launch (adf_transformer.h); ADF_TR_FUSED=0 keeps the nine launches
-        static int tr_fused = -1;
-        if (tr_fused < 0) tr_fused = adf_route_switch("ADF_TR_FUSED", 2);
-        if (tr_fused && h->bf16 && t.c == 256 && t.mid == 512 && h->cfg.attention_heads == 8 && (x.L == 16 || x.L == 64) &&
-            x.C == 256 && t.qkv.nchunk == 4 && t.ff2.nchunk == 8 && t.qkv.wfrag) {
-            Act x2 = new_act(t.c, x.L);
-            TrFusedArgs fa;
-            memset(&fa, 0, sizeof(fa));
-            fa.x = (const bf16_t*)x.p; fa.out = (bf16_t*)x2.p;
-            fa.ln_w = t.lnw; fa.ln_b = t.lnb; fa.g0 = t.g0; fa.g3 = t.g3;
-            fa.wqkv = t.qkv.wfrag; fa.wproj = t.proj.wfrag; fa.wff1 = t.ff1.wfrag; fa.wff2 = t.ff2.wfrag;
-            fa.npad_qkv = t.qkv.n_pad; fa.npad_proj = t.proj.n_pad; fa.npad_ff1 = t.ff1.n_pad; fa.npad_ff2 = t.ff2.n_pad;
-            fa.eps = 1e-5f;
-            if (h->cfg.resnet_groups == 8 && !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) { x2.stats = alloc_stats(); fa.stats = x2.stats; }
-            if (live()) check(launch_transformer_small(fa, p->B, x.L, s));
-            tap(name, x2);
-            return x2;
-        }
-        // longer samples (256 tokens): two fused launches around the attention kernel (ADF_TR_FUSED=1 keeps these unfused)
-        if (tr_fused >= 2 && h->bf16 && t.c == 256 && t.mid == 512 && h->cfg.attention_heads == 8 && x.L % 64 == 0 && x.L > 64 &&
-            x.C == 256 && t.qkv.nchunk == 4 && t.ff2.nchunk == 8 && t.qkv.wfrag && h->cfg.resnet_groups == 8 &&
-            !(h->cfg.flags & ADF_FLAG_SEPARATE_GN_STATS)) {
-            Act qkv = new_act(3 * t.c, x.L), att = new_act(t.c, x.L), x2 = new_act(t.c, x.L);
-            TrFusedArgs fa;
-            memset(&fa, 0, sizeof(fa));
-            fa.x = (const bf16_t*)x.p; fa.out = (bf16_t*)x2.p; fa.qkv_out = (bf16_t*)qkv.p; fa.att = (const bf16_t*)att.p;
-            fa.ln_w = t.lnw; fa.ln_b = t.lnb; fa.g0 = t.g0; fa.g3 = t.g3;
-            fa.wqkv = t.qkv.wfrag; fa.wproj = t.proj.wfrag; fa.wff1 = t.ff1.wfrag; fa.wff2 = t.ff2.wfrag;
-            fa.npad_qkv = t.qkv.n_pad; fa.npad_proj = t.proj.n_pad; fa.npad_ff1 = t.ff1.n_pad; fa.npad_ff2 = t.ff2.n_pad;
-            fa.eps = 1e-5f;
-            x2.stats = alloc_stats(); fa.stats = x2.stats;
-            if (live()) {
-                check(launch_transformer_tiles(fa, (int)rows, x.L, 1, s));
-                check(launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
-                check(launch_transformer_tiles(fa, (int)rows, x.L, 2, s));
-            }
-            tap(name + ".qkv", qkv);
-            tap(name + ".att", att);
-            tap(name, x2);
-            return x2;
-        }
-        // the nine-launch path: every stored tensor of the block is a recorded activation (the parity tests hold each launch to
-        // the oracle on its own; the fused kernels above are then held to this path)
-        Act xn = new_act(t.c, x.L);
-        if (live()) check(launch_ln_rows(x.p, xn.p, h->bf16, rows, t.c, t.lnw, t.lnb, 1e-5f, s));
-        tap(name + ".ln", xn);
-        Act qkv = linear(xn, t.qkv, nullptr, 0, false);
-        tap(name + ".qkv", qkv);
-        Act att = new_act(t.c, x.L);
-        if (live()) check(launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
-        tap(name + ".att", att);
-        Act x1 = linear(att, t.proj, x.p, 0, false);
-        tap(name + ".x1", x1);
-        Act n1 = new_act(t.c, x.L);
-        if (live()) check(launch_ln_rows(x1.p, n1.p, h->bf16, rows, t.c, t.g0, nullptr, 1e-5f, s));
-        tap(name + ".n1", n1);
-        Act f1 = linear(n1, t.ff1, nullptr, 1, false);
-        tap(name + ".f1", f1);
-        Act n2 = new_act(t.mid, x.L);
-        if (live()) check(launch_ln_rows(f1.p, n2.p, h->bf16, rows, t.mid, t.g3, nullptr, 1e-5f, s));
-        tap(name + ".n2", n2);
-        Act x2 = linear(n2, t.ff2, x1.p, 0, true);
-        tap(name, x2);
-        return x2;
-    }
-};
-
-struct FwdIO {
-    const float* x = nullptr; float* out = nullptr;
-    const float* t = nullptr; int t_stride = 0; int nb = 0;
-    const float* coef = nullptr; int coef_bstride = 0; int mode = 0; const float* x_noisy = nullptr;
-    const float* film2 = nullptr; int film2_bstride = 0;   // class part of the FiLM projections (rows of adf_handle::cond_film)
-    const float* film_pre = nullptr;                       // this evaluation's row of Plan::film_all: sigma embedding + FiLM already computed
-    const float* temb_pre = nullptr;                       // this evaluation's row of Plan::temb_all (class-conditional ADM net: the FiLM rows are per sample)
-    bool null_cond = false;                                // class-conditional ADM net: every sample takes the null class embedding (guidance branch)
-};
-
-int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
-int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s);
-
-int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
-    if (!p->dry) ++h->ctr.net_passes;
-    if (h->wn) return wn_forward(h, p, io, s);
-    if (h->adm) return adm_forward(h, p, io, s);
-    const adf_net_config& c = h->cfg;
-    Walker W{h, p, s};
-    W.film2 = io.film2; W.film2_bstride = io.film2_bstride;
-    W.film = io.film_pre ? io.film_pre : p->film;
-    p->arena_off = 0; p->stats_off = 0;
-    p->taps.clear(); p->rbs.clear();
-    const int B = p->B, L = p->L, n = c.num_layers;
-    const int pad = c.window_length / 2 - c.stride / 2;
-    const int tdim = 4 * c.channels;
-    if (!p->dry && p->stats_bytes) {
-        if (hipMemsetAsync(p->stats, 0, p->stats_bytes, s) != hipSuccess) return fail(h, "hipMemsetAsync(stats) failed");
-    }
-    // sigma embedding + every resblock's FiLM projection (unless the sampler computed them for the whole run already)
-    if (W.live() && !io.film_pre) {
-        TimeEmbedArgs te;
-        te.t = io.t; te.t_stride = io.t_stride; te.nb = io.nb; te.ch = c.channels;
-        te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb;
-        W.check(launch_time_embed(te, s));
-        W.check(launch_film(p->temb, tdim, h->film_w, tdim + h->cdim, 0, h->film_b, p->film, io.nb, h->film_total, s));
-    }
-    Act x = W.new_act(c.num_filters, L / c.stride);
-    if (W.live())
-        W.check(launch_to_in(io.x, h->to_in_w, x.p, h->bf16, B, c.in_channels, L, c.num_filters, c.window_length, c.stride, pad,
-                             io.coef, io.coef_bstride, s));
-    W.tap("to_in", x);
-    std::vector<std::vector<Act>> skips_list;
-    for (int i = 0; i < n; ++i) {
-        const DownW& d = h->downs[i];
-        const int f = d.factor, km = c.kernel_multiplier_downsample;
-        Act y = W.new_act(d.cout, x.L / f);
-        // Downsample1d (unet1d.py:214-225) as a stride-1 conv over the row-folded view [L/f][f*C] (Registrar::conv_folded)
-        if (x.L % f) return fail(h, "downsample: length not divisible by the factor");
-        Act xv = x;
-        xv.C = x.C * f; xv.L = x.L / f; xv.stats = nullptr;
-        GemmArgs g = W.gemm_base(y, xv.L, y.L, d.down);
-        g.seg[0] = Walker::seg_of(xv, nullptr, nullptr, 1.f, 0, km + 1, 1, -(km / 2), 1, d.down);
-        W.run_gemm(g, y, true);
-        W.tap("down" + std::to_string(i) + ".conv", y);
-        x = y;
-        std::vector<Act> skips;
-        for (size_t j = 0; j < d.blocks.size(); ++j) {
-            x = W.resblock("down" + std::to_string(i) + ".block" + std::to_string(j), x, nullptr, d.blocks[j], io.nb);
-            skips.push_back(x);
-        }
-        if (d.attn) {
-            x = W.transformer("down" + std::to_string(i) + ".attn", x, d.tr);
-            skips.push_back(x);
-        }
-        skips_list.push_back(skips);
-    }
-    x = W.resblock("mid.pre", x, nullptr, h->mid_pre, io.nb);
-    if (c.use_attention_bottleneck) x = W.transformer("mid.attn", x, h->mid_tr);
-    x = W.resblock("mid.post", x, nullptr, h->mid_post, io.nb);
-    for (int u = 0; u < n; ++u) {
-        const UpW& up = h->ups[u];
-        std::vector<Act>& skips = skips_list.back();
-        for (size_t j = 0; j < up.blocks.size(); ++j) {
-            if (skips.empty()) { W.check("upsample: skip stack underflow"); break; }
-            Act sk = skips.back();
-            skips.pop_back();
-            x = W.resblock("up" + std::to_string(u) + ".block" + std::to_string(j), x, &sk, up.blocks[j], io.nb);
-        }
-        skips_list.pop_back();
-        if (up.attn) x = W.transformer("up" + std::to_string(u) + ".attn", x, up.tr);
-        const int f = up.factor;
-        Act y = W.new_act(up.cout, x.L * f);
-        GemmArgs g = W.gemm_base(y, x.L, x.L + 1, up.up);
-        g.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, 2, 1, 0, -1, up.up);
-        g.bias_mod = up.cout;
-        g.scatter_f = f; g.scatter_pad = f / 2 + f % 2;
-        W.run_gemm(g, y, u + 1 < n);
-        W.tap("up" + std::to_string(u) + ".conv", y);
-        x = y;
-    }
-    if (W.live())
-        W.check(launch_to_out(x.p, h->to_out_w, io.out, h->bf16, B, c.out_channels, x.L, c.num_filters, c.window_length, c.stride, pad,
-                              io.mode, io.x_noisy, io.coef, io.coef_bstride, s));
-    return W.bad ? 1 : 0;
-}
-
-int wn_pack_weights(adf_handle* h, hipStream_t s);
 
 int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
     const adf_net_config& c = h->cfg;
@@ -815,1076 +78,7 @@ int get_plan(adf_handle* h, int B, int L, hipStream_t s, Plan** out) {
     return 0;
 }
 
-// ---- WaveNetNoise ----------------------------------------------------------------------------------------------------
-// Registration order = the reference module's state_dict order (wavenet.py:158-167; the custom WeightNorm re-registers
-// g and v after the bias, :37-42).
-int wn_build_weights(adf_handle* h) {
-    WnW& w = *h->wn;
-    const adf_wavenet_config& c = w.cfg;
-    Registrar R{h};
-    const int C = c.residual_channels;
-    auto conv = [&](const std::string& pre, WnConv& cv, int cout, int cin, int K, int layout) {
-        cv.cout = cout; cv.cin = cin; cv.K = K;
-        cv.bias = R.reg_f32(pre + ".conv.module.bias", cout);
-        cv.g = R.reg_f32(pre + ".conv.module.weight_g", 1);
-        cv.v = R.reg_f32(pre + ".conv.module.weight_v", (int64_t)cout * cin * K);
-        cv.packed = dalloc(h, (size_t)cout * cin * K * (layout == 1 ? 2 : 4));
-        if (!cv.packed) R.ok = false;
-    };
-    const int lay = h->bf16 ? 1 : 0;
-    conv("input_projection", w.in, C, 1, 1, 2);
-    w.fc1w = R.reg_f32("residual_layer.fc_t1.weight", (int64_t)c.dim_mid * c.dim_in);
-    w.fc1b = R.reg_f32("residual_layer.fc_t1.bias", c.dim_mid);
-    w.fc2w = R.reg_f32("residual_layer.fc_t2.weight", (int64_t)c.dim_out * c.dim_mid);
-    w.fc2b = R.reg_f32("residual_layer.fc_t2.bias", c.dim_out);
-    // the per-layer diffusion projections, concatenated: one launch_film call computes every layer's addend
-    h->film_total = c.residual_layers * C;
-    h->film_w = (float*)dalloc(h, (size_t)h->film_total * c.dim_out * 4);
-    h->film_b = (float*)dalloc(h, (size_t)h->film_total * 4);
-    if (!h->film_w || !h->film_b) R.ok = false;
-    w.dil.resize(c.residual_layers);
-    w.outp.resize(c.residual_layers);
-    for (int n = 0; n < c.residual_layers && R.ok; ++n) {
-        const std::string pre = "residual_layer.residual_blocks." + std::to_string(n);
-        conv(pre + ".dilated_conv", w.dil[n], 2 * C, C, 3, lay);
-        R.reg_f32(pre + ".diffusion_projection.weight", (int64_t)C * c.dim_out, h->film_w + (size_t)n * C * c.dim_out);
-        R.reg_f32(pre + ".diffusion_projection.bias", C, h->film_b + (size_t)n * C);
-        conv(pre + ".output_projection", w.outp[n], 2 * C, C, 1, lay);
-    }
-    conv("skip_projection", w.sp, C, C, 1, lay);
-    w.out_w = R.reg_f32("output_projection.conv.weight", C);
-    w.out_b = R.reg_f32("output_projection.conv.bias", 1);
-    w.sumsq = (double*)dalloc(h, 256);
-    if (!w.sumsq) R.ok = false;
-    return R.ok ? 0 : fail(h, "device allocation failed while building the weight registry");
-}
-
-// effective weights of every weight-normed conv, as GEMM operands (stream-ordered; the one sumsq scratch is reused in order)
-int wn_pack_weights(adf_handle* h, hipStream_t s) {
-    WnW& w = *h->wn;
-    const int lay = h->bf16 ? 1 : 0;
-    auto one = [&](const WnConv& cv, int layout) -> int {
-        if (const char* e = launch_wn_sumsq(cv.v, (long long)cv.cout * cv.cin * cv.K, w.sumsq, s)) return fail(h, e);
-        if (const char* e = launch_wn_pack(cv.v, cv.g, w.sumsq, cv.packed, layout, cv.cout, cv.cin, cv.K, s)) return fail(h, e);
-        return 0;
-    };
-    if (one(w.in, 2) || one(w.sp, lay)) return 1;
-    for (size_t n = 0; n < w.dil.size(); ++n)
-        if (one(w.dil[n], lay) || one(w.outp[n], lay)) return 1;
-    w.packed = true;
-    return 0;
-}
-
-// WaveNetNoise.forward (wavenet.py:169-180) for x [B][1][T]; io as for the U-Net (EDM scalars fused into the first and last kernel)
-int wn_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
-    WnW& w = *h->wn;
-    const adf_wavenet_config& c = w.cfg;
-    Walker W{h, p, s};
-    p->arena_off = 0; p->stats_off = 0;
-    p->taps.clear(); p->rbs.clear(); p->wn_layers.clear();
-    const int B = p->B, T = p->L, C = c.residual_channels, NL = c.residual_layers;
-    const size_t act = (size_t)B * T * C * h->esz;
-    // every layer input stays resident when that is small (the parity taps y<n>); otherwise two buffers alternate
-    const bool keep = act * (size_t)NL <= ((size_t)512 << 20);   // (one bf16 waveform of 22050 samples x 36 layers = 406 MB: the full-size parity test)
-    std::vector<void*> ys(keep ? NL : 2);
-    for (auto& q : ys) q = W.alloc(act);
-    float* const skip = (float*)W.alloc((size_t)B * T * C * 4);
-    if (p->dry) return 0;
-    const float* film = io.film_pre ? io.film_pre : p->film;
-    if (!io.film_pre) {
-        W.check(launch_wn_step_embed(io.t, io.t_stride, io.nb, w.fc1w, w.fc1b, w.fc2w, w.fc2b, c.dim_in, c.dim_mid, c.dim_out, p->temb, s));
-        W.check(launch_film(p->temb, c.dim_out, h->film_w, c.dim_out, 0, h->film_b, p->film, io.nb, h->film_total, s));
-    }
-    WnIO wio;
-    wio.B = B; wio.T = T; wio.C = C; wio.bf16 = h->bf16 ? 1 : 0;
-    wio.e = film; wio.e_bstride = io.nb > 1 ? h->film_total : 0;
-    W.check(launch_wn_input(wio, io.x, io.coef, io.coef_bstride, (const float*)w.in.packed, w.in.bias, ys[0], s));
-    for (int n = 0; n < NL && !W.bad; ++n) {
-        WnLayerArgs a;
-        a.y = ys[keep ? n : (n & 1)];
-        a.y_next = n + 1 < NL ? ys[keep ? n + 1 : ((n + 1) & 1)] : nullptr;
-        a.skip = skip;
-        a.w1 = w.dil[n].packed; a.b1 = w.dil[n].bias;
-        a.w2 = w.outp[n].packed; a.b2 = w.outp[n].bias;
-        a.n = n; a.first = n == 0 ? 1 : 0;
-        a.dilation = 1 << (n % c.dilation_cycle);
-        if (keep) p->taps.push_back({"y" + std::to_string(n), (void*)a.y, C, T});
-        p->wn_layers.push_back(a);
-        W.check(launch_wn_layer(wio, a, s));
-    }
-    p->wn_io = wio;
-    WnFinalArgs f;
-    f.skip = skip; f.skip_scale = (float)std::sqrt(1.0 / (double)NL);
-    f.w_sp = w.sp.packed; f.b_sp = w.sp.bias; f.w_out = w.out_w; f.b_out = w.out_b;
-    f.out = io.out; f.mode = io.mode; f.x_noisy = io.x_noisy; f.coef = io.coef; f.coef_bstride = io.coef_bstride;
-    TapRec sk{"skip", (void*)skip, C, T};
-    sk.f32 = 1; sk.scale = f.skip_scale;
-    p->taps.push_back(sk);
-    W.check(launch_wn_final(wio, f, s));
-    return W.bad ? 1 : 0;
-}
-
-// ---- ADM-style 2-D U-Net ---------------------------------------------------------------------------------------------
-// The module list UNetModel.__init__ builds (unet2d_oai.py:467-594), registered in state_dict order.
-int adm_build_weights(adf_handle* h) {
-    AdmW& a = *h->adm;
-    const adf_adm_config& c = a.cfg;
-    const int mc = c.model_channels, ted = 4 * mc;
-    auto has_att = [&](int ds) { for (int i = 0; i < c.n_attention_ds; ++i) if (c.attention_ds[i] == ds) return true; return false; };
-    auto heads_of = [&](int ch) { return c.num_head_channels == -1 ? c.num_heads : ch / c.num_head_channels; };
-    // pass 1: structure
-    auto new_res = [&](int cin, int cout) { AdmRes r; r.cin = cin; r.cout = cout; r.has_skip = cin != cout; r.film_off = h->film_total; h->film_total += 2 * cout;
-                                            a.res.push_back(r); return AdmLayer{1, (int)a.res.size() - 1}; };
-    auto new_attn = [&](int ch) { AdmAttn t; t.c = ch; t.heads = heads_of(ch); a.attn.push_back(t); return AdmLayer{2, (int)a.attn.size() - 1}; };
-    int ch = a.input_ch = c.channel_mult[0] * mc;
-    a.input_blocks.push_back({AdmLayer{0, 0}});
-    std::vector<int> chans{ch};
-    int ds = 1;
-    for (int level = 0; level < c.n_mult; ++level) {
-        for (int k = 0; k < c.num_res_blocks; ++k) {
-            std::vector<AdmLayer> ls{new_res(ch, c.channel_mult[level] * mc)};
-            ch = c.channel_mult[level] * mc;
-            if (has_att(ds)) ls.push_back(new_attn(ch));
-            a.input_blocks.push_back(ls);
-            chans.push_back(ch);
-        }
-        if (level != c.n_mult - 1) {
-            a.resample.emplace_back();
-            a.resample.back().cin = ch; a.resample.back().cout = ch;
-            a.input_blocks.push_back({AdmLayer{3, (int)a.resample.size() - 1}});
-            chans.push_back(ch);
-            ds *= 2;
-        }
-    }
-    a.skip_ch = chans;
-    a.middle = {new_res(ch, ch), new_attn(ch), new_res(ch, ch)};
-    for (int level = c.n_mult - 1; level >= 0; --level) {
-        for (int i = 0; i <= c.num_res_blocks; ++i) {
-            const int ich = chans.back(); chans.pop_back();
-            std::vector<AdmLayer> ls{new_res(ch + ich, mc * c.channel_mult[level])};
-            ch = mc * c.channel_mult[level];
-            if (has_att(ds)) ls.push_back(new_attn(ch));
-            if (level && i == c.num_res_blocks) {
-                a.resample.emplace_back();
-                a.resample.back().cin = ch; a.resample.back().cout = ch;
-                ls.push_back(AdmLayer{4, (int)a.resample.size() - 1});
-                ds /= 2;
-            }
-            a.output_blocks.push_back(ls);
-        }
-    }
-    a.final_ch = ch;
-    if (a.final_ch != a.input_ch) return fail(h, "UNetModel: the last level's width must equal the first's (out conv, unet2d_oai.py:599)");
-    {
-        auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
-        int g = a.final_ch / 32;
-        for (const AdmRes& r : a.res) { g = gcd(g, r.cin / 32); g = gcd(g, r.cout / 32); }
-        for (const AdmAttn& t : a.attn) g = gcd(g, t.c / 32);
-        for (int sc : a.skip_ch) g = gcd(g, sc);       // a concat splits at the skip's width
-        a.fg = g < 1 ? 1 : (g > 4 ? 4 : g);
-        while (128 % a.fg) --a.fg;
-    }
-    // pass 2: registry, in the module's registration order
-    Registrar R{h};
-    h->film_w = (float*)dalloc(h, (size_t)h->film_total * ted * 4);
-    h->film_b = (float*)dalloc(h, (size_t)h->film_total * 4);
-    if (!h->film_w || !h->film_b) R.ok = false;
-    a.t_w1 = R.reg_f32("time_embed.0.weight", (int64_t)ted * mc);
-    a.t_b1 = R.reg_f32("time_embed.0.bias", ted);
-    a.t_w2 = R.reg_f32("time_embed.2.weight", (int64_t)ted * ted);
-    a.t_b2 = R.reg_f32("time_embed.2.bias", ted);
-    if (c.num_classes > 0) {             // LabelEmbedder(num_classes, None, model_channels, 4 * model_channels), conditioner.py:64-90; unet2d_oai.py:461-468
-        h->cdim = ted;
-        h->lab_null = R.reg_f32("label_conditioner.null_classes_emb", mc);
-        h->lab_emb = R.reg_f32("label_conditioner.label_emb.weight", (int64_t)c.num_classes * mc);
-        h->lab_lnw = R.reg_f32("label_conditioner.class_to_cond.0.weight", mc);
-        h->lab_lnb = R.reg_f32("label_conditioner.class_to_cond.0.bias", mc);
-        h->lab_w1 = R.reg_f32("label_conditioner.class_to_cond.1.weight", (int64_t)ted * mc);
-        h->lab_b1 = R.reg_f32("label_conditioner.class_to_cond.1.bias", ted);
-        h->lab_w2 = R.reg_f32("label_conditioner.class_to_cond.3.weight", (int64_t)ted * ted);
-        h->lab_b2 = R.reg_f32("label_conditioner.class_to_cond.3.bias", ted);
-    }
-    auto reg_layer = [&](const AdmLayer& l, const std::string& pre) {
-        if (l.kind == 0) {
-            a.in_w = R.reg_f32(pre + ".weight", (int64_t)a.input_ch * c.in_channels * 9);
-            a.in_b = R.reg_f32(pre + ".bias", a.input_ch);
-        } else if (l.kind == 1) {
-            AdmRes& r = a.res[l.idx];
-            r.g1w = R.reg_f32(pre + ".in_layers.0.weight", r.cin);
-            r.g1b = R.reg_f32(pre + ".in_layers.0.bias", r.cin);
-            R.conv(pre + ".in_layers.2", r.c1, r.cout, r.cin, 9, true);
-            R.reg_f32(pre + ".emb_layers.1.weight", (int64_t)2 * r.cout * ted, h->film_w + (size_t)r.film_off * ted);
-            R.reg_f32(pre + ".emb_layers.1.bias", 2 * r.cout, h->film_b + r.film_off);
-            r.g2w = R.reg_f32(pre + ".out_layers.0.weight", r.cout);
-            r.g2b = R.reg_f32(pre + ".out_layers.0.bias", r.cout);
-            R.conv(pre + ".out_layers.3", r.c2, r.cout, r.cout, 9, true);
-            if (r.has_skip) R.conv(pre + ".skip_connection", r.skip, r.cout, r.cin, 1, true);
-        } else if (l.kind == 2) {
-            AdmAttn& t = a.attn[l.idx];
-            t.gw = R.reg_f32(pre + ".norm.weight", t.c);
-            t.gb = R.reg_f32(pre + ".norm.bias", t.c);
-            R.conv(pre + ".qkv", t.qkv, 3 * t.c, t.c, 1, true);
-            R.conv(pre + ".proj_out", t.proj, t.c, t.c, 1, true);
-            if (!c.use_new_attention_order) {
-                // QKVAttentionLegacy (:338-340) keeps each head's q | k | v rows together; the attention kernel reads q | k | v blocks:
-                // the rows of the weight and of the bias are permuted once at load (slot kinds 4 / 5)
-                t.qkv_tmp = (float*)dalloc(h, (size_t)3 * t.c * t.c * 4);
-                if (!t.qkv_tmp) R.ok = false;
-                Slot& sw = h->slots[pre + ".qkv.weight"]; sw.kind = 4; sw.frag = t.qkv_tmp; sw.f = t.heads;
-                Slot& sb = h->slots[pre + ".qkv.bias"]; sb.kind = 5; sb.f = t.heads; sb.cout = 3 * t.c;
-            }
-        } else {
-            ConvW& w = a.resample[l.idx];
-            R.conv(pre + (l.kind == 3 ? ".op" : ".conv"), w, w.cout, w.cin, 9, true);
-        }
-    };
-    for (size_t i = 0; i < a.input_blocks.size(); ++i)
-        for (size_t j = 0; j < a.input_blocks[i].size(); ++j) reg_layer(a.input_blocks[i][j], "input_blocks." + std::to_string(i) + "." + std::to_string(j));
-    for (size_t j = 0; j < a.middle.size(); ++j) reg_layer(a.middle[j], "middle_block." + std::to_string(j));
-    for (size_t i = 0; i < a.output_blocks.size(); ++i)
-        for (size_t j = 0; j < a.output_blocks[i].size(); ++j) reg_layer(a.output_blocks[i][j], "output_blocks." + std::to_string(i) + "." + std::to_string(j));
-    a.out_gw = R.reg_f32("out.0.weight", a.final_ch);
-    a.out_gb = R.reg_f32("out.0.bias", a.final_ch);
-    a.out_w = R.reg_f32("out.2.weight", (int64_t)c.out_channels * a.input_ch * 9);
-    a.out_b = R.reg_f32("out.2.bias", c.out_channels);
-    return R.ok ? 0 : fail(h, "device allocation failed while building the weight registry");
-}
-
-// UNetModel.forward (unet2d_oai.py:603-634) on channels-last activations; x / out are the reference's [B][C][H][W] fp32
-int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
-    AdmW& a = *h->adm;
-    const adf_adm_config& c = a.cfg;
-    Walker W{h, p, s};
-    p->arena_off = 0; p->stats_off = 0;
-    p->taps.clear(); p->rbs.clear();
-    const int B = p->B, ted = 4 * c.model_channels;
-    if (!p->dry && p->stats_bytes && hipMemsetAsync(p->stats, 0, p->stats_bytes, s) != hipSuccess) return fail(h, "hipMemsetAsync(stats) failed");
-    const float* film = io.film_pre ? io.film_pre : p->film;
-    int film_bs = io.nb > 1 ? h->film_total : 0;
-    if (h->cdim > 0) {
-        // class-conditional: emb[b] = time_embed(t) + label_conditioner(classes[b]) (unet2d_oai.py:619-623), so every sample has its own FiLM rows
-        float* emb_b = (float*)W.alloc((size_t)B * ted * 4);
-        film = p->film; film_bs = h->film_total;
-        if (W.live()) {
-            const float* te = io.temb_pre;
-            int te_bs = 0;
-            if (!te) {
-                W.check(launch_adm_time_embed(io.t, io.t_stride, io.nb, c.model_channels, a.t_w1, a.t_b1, a.t_w2, a.t_b2, ted, p->temb, s));
-                te = p->temb; te_bs = io.nb > 1 ? ted : 0;
-            }
-            const float* ce = io.null_cond ? h->cond_emb + (size_t)B * ted : h->cond_emb;       // last row = the null embedding
-            W.check(launch_add_rows(emb_b, te, te_bs, ce, io.null_cond ? 0 : ted, B, ted, s));
-            W.check(launch_film(emb_b, ted, h->film_w, ted, 0, h->film_b, p->film, B, h->film_total, s));
-        }
-    } else if (W.live() && !io.film_pre) {
-        W.check(launch_adm_time_embed(io.t, io.t_stride, io.nb, c.model_channels, a.t_w1, a.t_b1, a.t_w2, a.t_b2, ted, p->temb, s));
-        W.check(launch_film(p->temb, ted, h->film_w, ted, 0, h->film_b, p->film, io.nb, h->film_total, s));
-    }
-    // st: FINE GroupNorm statistics of the tensor ([B][C / fg][2]), when its producer reduced them; t1 / st1: the second source of a virtual
-    // concat (the skip of an output block, unet2d_oai.py:629: never materialised -- convs and the GroupNorm table read both sources)
-    struct T2 { Act t; int H, W; double* st = nullptr; Act t1; double* st1 = nullptr; };
-    const int fg = a.fg;
-    auto alloc_fine = [&](int C) -> double* {
-        const size_t bytes = ((size_t)B * (C / fg) * 2 * sizeof(double) + 255) & ~(size_t)255;
-        const size_t off = p->stats_off;
-        p->stats_off += bytes;
-        if (p->dry) return (double*)(uintptr_t)(off + 256);
-        if (p->stats_off > p->stats_bytes) { W.check("stats arena overflow"); return nullptr; }
-        return (double*)(p->stats + off);
-    };
-    auto ensure_stats = [&](const Act& t, double*& st) {
-        if (st) return;
-        st = alloc_fine(t.C);
-        if (W.live()) W.check(launch_gn_stats_any(t.p, h->bf16, B, t.L, t.C, t.C / fg, st, s));
-    };
-    // GroupNorm32 (:10-21) (+ scale-shift, :262-267) of a tensor (or a virtual concat) folded to the per-(sample, channel) table a conv prologue reads
-    auto gn_table = [&](T2& x, const float* gamma, const float* beta, const float* fl) -> float* {
-        ensure_stats(x.t, x.st);
-        if (x.t1.p || x.t1.C) ensure_stats(x.t1, x.st1);
-        const int ctot = x.t.C + x.t1.C;
-        float* ab = (float*)W.alloc((size_t)B * ctot * 2 * 4);
-        if (W.live()) {
-            GnFineArgs g;
-            memset(&g, 0, sizeof(g));
-            g.stats0 = x.st; g.stats1 = x.st1; g.c0 = x.t.C; g.c1 = x.t1.C; g.L = x.t.L; g.G = 32; g.B = B; g.fg = fg; g.eps = 1e-5f;
-            g.gamma = gamma; g.beta = beta; g.film = fl; g.film_bstride = film_bs; g.ab = ab;
-            W.check(launch_gn_finalize_fine(g, s));
-        }
-        return ab;
-    };
-    // stats: also reduce the (fine) GroupNorm statistics of the output in the epilogue (where a GroupNorm reads this tensor next)
-    auto conv = [&](const T2& x, const ConvW& w, const float* ab, int act, int mode, const void* res, bool stats) -> T2 {
-        T2 y;
-        if (stats && w.cout % fg == 0 && (w.cout <= 128 || w.cout % 128 == 0)) y.st = alloc_fine(w.cout);
-        y.H = mode == 1 ? x.H * 2 : (mode == 2 ? x.H / 2 : x.H);
-        y.W = mode == 1 ? x.W * 2 : (mode == 2 ? x.W / 2 : x.W);
-        y.t = W.new_act(w.cout, y.H * y.W);
-        if (W.live()) {
-            Conv2dArgs g;
-            g.x = x.t.p; g.x1 = x.t1.C ? x.t1.p : nullptr; g.c0 = x.t.C;
-            g.ab = ab; g.act = act; g.B = B; g.H = y.H; g.W = y.W; g.cin = x.t.C + x.t1.C; g.cout = w.cout; g.n_pad = w.n_pad;
-            g.taps = w.taps; g.mode = mode; g.w = w.w; g.nchunk = w.nchunk; g.bias = w.bias; g.res = res; g.out = y.t.p;
-            g.stats = y.st; g.stats_groups = w.cout / fg;
-            W.check(launch_conv2d(g, h->bf16, s));
-        }
-        return y;
-    };
-    auto run = [&](const std::vector<AdmLayer>& ls, T2 x, const std::string& bname) -> T2 {
-        int lj = -1;
-        for (const AdmLayer& l : ls) {
-            ++lj;
-            const std::string ln = bname + "." + std::to_string(lj);
-            if (W.bad) break;
-            if (l.kind == 0) {
-                T2 y; y.H = x.H; y.W = x.W; y.t = W.new_act(a.input_ch, x.H * x.W);
-                y.st = alloc_fine(a.input_ch);   // here, so that the copy pushed on the skip stack carries them (the last output block reads them again)
-                if (W.live()) W.check(launch_conv2d_in(io.x, a.in_w, a.in_b, y.t.p, h->bf16, B, c.in_channels, x.H, x.W, a.input_ch, io.coef, io.coef_bstride, y.st, fg, s));
-                x = y;
-                W.tap(ln, x.t);
-            } else if (l.kind == 1) {                                  // ResBlock._forward, :248-272 (scale-shift form)
-                const AdmRes& r = a.res[l.idx];
-                const float* ab1 = gn_table(x, r.g1w, r.g1b, nullptr);
-                T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr, true);
-                W.tap(ln + ".h1", hh.t);
-                const float* ab2 = gn_table(hh, r.g2w, r.g2b, film + r.film_off);
-                const void* skip = x.t.p;
-                if (r.has_skip) { T2 sk2 = conv(x, r.skip, nullptr, 0, 0, nullptr, false); W.tap(ln + ".skip", sk2.t); skip = sk2.t.p; }
-                x = conv(hh, r.c2, ab2, 1, 0, skip, true);
-                W.tap(ln, x.t);
-            } else if (l.kind == 2) {                                   // AttentionBlock._forward, :316-322
-                const AdmAttn& t = a.attn[l.idx];
-                const float* ab = gn_table(x, t.gw, t.gb, nullptr);
-                T2 xn; xn.H = x.H; xn.W = x.W; xn.t = W.new_act(t.c, x.t.L);
-                if (W.live()) W.check(launch_gn_apply(x.t.p, nullptr, t.c, 0, x.t.L, B, ab, 0, xn.t.p, h->bf16, s));
-                W.tap(ln + ".xn", xn.t);
-                T2 qkv = conv(xn, t.qkv, nullptr, 0, 0, nullptr, false);
-                W.tap(ln + ".qkv", qkv.t);         // q | k | v blocks (the rows were permuted at load for the legacy order)
-                T2 att; att.H = x.H; att.W = x.W; att.t = W.new_act(t.c, x.t.L);
-                if (W.live()) W.check(launch_attention(qkv.t.p, att.t.p, h->bf16, B, x.t.L, t.c, t.heads, s));
-                W.tap(ln + ".att", att.t);
-                x = conv(att, t.proj, nullptr, 0, 0, xn.t.p, true);    // the residual is the NORMALISED input (:318-322)
-                W.tap(ln, x.t);
-            } else {
-                x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr, true);
-                W.tap(ln, x.t);
-            }
-        }
-        return x;
-    };
-    T2 x; x.H = a.H; x.W = a.W; x.t = Act{};
-    std::vector<T2> hs;
-    for (size_t i = 0; i < a.input_blocks.size() && !W.bad; ++i) {
-        x = run(a.input_blocks[i], x, "input_blocks." + std::to_string(i));
-        W.tap("input_blocks." + std::to_string(i), x.t);
-        hs.push_back(x);
-    }
-    x = run(a.middle, x, "middle_block");
-    W.tap("middle_block", x.t);
-    for (size_t i = 0; i < a.output_blocks.size() && !W.bad; ++i) {
-        const T2 sk = hs.back(); hs.pop_back();
-        if (sk.H != x.H || sk.W != x.W) { W.check("UNetModel: skip shape mismatch"); break; }
-        T2 cat = x;                                                    // [x ; skip] along channels, by reference
-        cat.t1 = sk.t; cat.st1 = sk.st;
-        x = run(a.output_blocks[i], cat, "output_blocks." + std::to_string(i));
-        W.tap("output_blocks." + std::to_string(i), x.t);
-    }
-    const float* abo = gn_table(x, a.out_gw, a.out_gb, nullptr);
-    if (W.live())
-        W.check(launch_conv2d_out(x.t.p, abo, a.out_w, a.out_b, io.out, h->bf16, B, a.final_ch, x.H, x.W, c.out_channels, io.mode, io.x_noisy, io.coef,
-                                  io.coef_bstride, s));
-    return W.bad ? 1 : 0;
-}
-
-// class part of the FiLM projections for one network pass: the per-sample rows, or the null row for every sample
-int cond_rows(adf_handle* h, int B, bool null_branch, FwdIO& io) {
-    if (h->cdim == 0) return 0;
-    if (!h->cond_on || h->cond_B != B)
-        return fail(h, "class-conditional network: call adf_set_condition with the labels of this batch first");
-    io.null_cond = null_branch;
-    if (h->adm) return 0;            // the ADM net adds the class embedding to the time embedding before the FiLM projections (adm_forward)
-    if (null_branch) { io.film2 = h->cond_film + (size_t)B * h->film_total; io.film2_bstride = 0; }
-    else { io.film2 = h->cond_film; io.film2_bstride = h->film_total; }
-    return 0;
-}
-
-// (allocated outside graph capture: adf_sampler_run calls this before it starts capturing)
-int ensure_cfg_buffers(adf_handle* h, Plan* p) {
-    if (p->cfg_c) return 0;
-    const size_t wave = (size_t)p->B * h->cfg.out_channels * p->L;
-    p->cfg_c = (float*)dalloc(h, wave * 4, p);
-    p->cfg_n = (float*)dalloc(h, wave * 4, p);
-    if (!p->cfg_c || !p->cfg_n) return fail(h, "device allocation failed for the guidance buffers");
-    return 0;
-}
-
-// One denoiser evaluation.  io carries x / t / coef (preconditioning scalars already in p->coef); with classifier-free
-// guidance the network runs twice (labels, null labels) in raw mode and cfg_combine applies guidance + preconditioning.
-// Dynamic thresholding (EluDiffusion(dynamic_threshold = q), components/utils.py:23-33): the estimate leaves the combine kernel unclipped and is
-// rescaled in place by its per-sample quantile.
-int denoise_io(adf_handle* h, Plan* p, FwdIO io, float* out, hipStream_t s) {
-    const bool cfg = h->cdim > 0 && h->cond_on && h->cond_scale != 1.0f;
-    const bool dyn = h->dyn_q > 0.0f;
-    if (!cfg && !dyn) {
-        if (cond_rows(h, p->B, false, io)) return 1;
-        io.out = out; io.mode = 1;
-        return forward(h, p, io, s);
-    }
-    const long long per_sample = (long long)h->cfg.out_channels * p->L;
-    const size_t wave = (size_t)p->B * per_sample;
-    if (ensure_cfg_buffers(h, p)) return 1;
-    if (dyn && !p->dyn_scale) {
-        p->dyn_scale = (float*)dalloc(h, (size_t)p->B * 4, p);
-        if (!p->dyn_scale) return fail(h, "device allocation failed for the dynamic-threshold scales");
-    }
-    io.mode = 0;                                     // raw network output; c_in is still applied by to_in
-    io.out = p->cfg_c;
-    if (cond_rows(h, p->B, false, io) || forward(h, p, io, s)) return 1;
-    if (cfg) {
-        io.out = p->cfg_n;
-        if (cond_rows(h, p->B, true, io) || forward(h, p, io, s)) return 1;
-    }
-    if (const char* e = launch_cfg_combine(out, io.x_noisy, p->cfg_c, cfg ? p->cfg_n : p->cfg_c, io.coef, io.coef_bstride, cfg ? h->cond_scale : 1.0f,
-                                           per_sample, (long long)wave, dyn ? 0 : 1, s))
-        return fail(h, e);
-    if (dyn)
-        if (const char* e = launch_dyn_threshold(out, p->B, per_sample, h->dyn_q, p->dyn_scale, s)) return fail(h, e);
-    return 0;
-}
-
-int denoise_scalar(adf_handle* h, Plan* p, const float* x, float sigma, float sigma_data, float* out, hipStream_t s) {
-    if (const char* e = launch_edm_coef(nullptr, sigma, 1, sigma_data, p->coef, s)) return fail(h, e);
-    FwdIO io;
-    io.x = x; io.t = p->coef + 1; io.t_stride = 4; io.nb = 1;
-    io.coef = p->coef; io.coef_bstride = 0; io.x_noisy = x;
-    return denoise_io(h, p, io, out, s);
-}
-
-// ---- sampler drivers -----------------------------------------------------------------------------------
-struct SamplerCtx {
-    adf_handle* h; Plan* p; const adf_sampler_desc* d; const float* sig; int nsig; hipStream_t s; long long n;
-    int nfe = 0;
-    bool count_only = false;
-    std::vector<float>* collect = nullptr;     // count_only pass: the sigma of every evaluation, in order
-    bool precomputed = false;                  // real pass: evaluation k reads row k of Plan::coef_all / film_all
-    int den(const float* x, float sigma, float* out) {
-        const int k = nfe++;
-        if (count_only) { if (collect) collect->push_back(sigma); return 0; }
-        if (precomputed) {
-            FwdIO io;
-            io.x = x; io.t = p->coef_all + (size_t)k * 4 + 1; io.t_stride = 4; io.nb = 1;
-            io.coef = p->coef_all + (size_t)k * 4; io.coef_bstride = 0; io.x_noisy = x;
-            if (h->adm && h->cdim > 0) io.temb_pre = p->temb_all + (size_t)k * 4 * h->cfg.channels;
-            else io.film_pre = p->film_all + (size_t)k * h->film_total;
-            return denoise_io(h, p, io, out, s);
-        }
-        return denoise_scalar(h, p, x, sigma, d->sigma_data, out, s);
-    }
-    int ck(const char* e) { if (e) { h->err = e; return 1; } return 0; }
-    // DPMSampler.model_fn (sampler_edm.py:692-708): the denoised estimate, or with eps_pred the noise prediction (x - D) / sigma
-    int model(const float* x, float sigma, float* out) {
-        if (den(x, sigma, out)) return 1;
-        if (d->eps_pred && !count_only) return ck(launch_eps(out, x, sigma, n, s));
-        return 0;
-    }
-};
-
-// returns the buffer holding the final sample through *result
-int run_edm(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const int N = d.num_steps;
-    if (c.nsig < N) return c.count_only ? 1 : fail(c.h, "EDMSampler: need at least num_steps sigmas");
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* XH = c.count_only ? nullptr : p->sb[2];
-    float* XE = c.count_only ? nullptr : p->sb[3];
-    float* D = c.count_only ? nullptr : p->sb[4];
-    float* DEN = c.count_only ? nullptr : p->sb[5];
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    const float gmax = fminf(d.s_churn / (float)N, (float)(std::sqrt(2.0) - 1.0));
-    for (int i = 0; i < N; ++i) {
-        const float sg = c.sig[i];
-        const float sn = (i + 1 < c.nsig) ? c.sig[i + 1] : 0.0f;
-        const float gamma = (sg >= d.s_tmin && sg <= d.s_tmax) ? gmax : 0.0f;
-        float s_hat = sg;
-        const float* xh = X;
-        if (gamma > 0.f) {
-            s_hat = sg + gamma * sg;
-            const float cc = sqrtf(s_hat * s_hat - sg * sg);
-            if (!c.count_only) {
-                if (!p->inj_stage) return fail(c.h, "EDMSampler with churn needs injected_noise");
-                if (c.ck(launch_churn(XH, X, p->inj_stage + (size_t)i * c.n, cc, d.s_noise, c.n, c.s))) return 1;
-            }
-            xh = XH;
-        }
-        if (c.den(xh, s_hat, DEN)) return 1;
-        const float dt = sn - s_hat;
-        if (!c.count_only && c.ck(launch_euler(XE, D, xh, DEN, s_hat, dt, c.n, c.s))) return 1;
-        if (sn != 0.f && d.use_heun) {
-            if (c.den(XE, sn, DEN)) return 1;
-            if (!c.count_only && c.ck(launch_rk2(XN, xh, D, XE, DEN, sn, 0.5f * dt, 1.0f, 1.0f, c.n, c.s))) return 1;
-            std::swap(X, XN);
-        } else {
-            std::swap(X, XE);
-        }
-    }
-    *result = X;
-    return 0;
-}
-
-int run_edm_alpha(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const int N = d.num_steps;
-    if (c.nsig < N) return c.count_only ? 1 : fail(c.h, "EDMAlphaSampler: need at least num_steps sigmas");
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* XE = c.count_only ? nullptr : p->sb[3];
-    float* D = c.count_only ? nullptr : p->sb[4];
-    float* DEN = c.count_only ? nullptr : p->sb[5];
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    const float alpha = d.alpha;
-    for (int i = 0; i + 1 < N; ++i) {
-        const float sg = c.sig[i], sn = c.sig[i + 1];
-        const float hh = sn - sg;
-        if (c.den(X, sg, DEN)) return 1;
-        const float sp = sg + alpha * hh;
-        if (sp != 0.f && d.use_heun) {
-            if (!c.count_only && c.ck(launch_euler(XE, D, X, DEN, sg, alpha * hh, c.n, c.s))) return 1;
-            if (c.den(XE, sp, DEN)) return 1;
-            const float w1 = (float)(1.0 - 0.5 / (double)alpha), w2 = (float)(0.5 / (double)alpha);
-            if (!c.count_only && c.ck(launch_rk2(XN, X, D, XE, DEN, sp, hh, w1, w2, c.n, c.s))) return 1;
-            std::swap(X, XN);
-        } else {
-            if (!c.count_only && c.ck(launch_euler(XE, D, X, DEN, sg, hh, c.n, c.s))) return 1;
-            std::swap(X, XE);
-        }
-    }
-    *result = X;
-    return 0;
-}
-
-// DPMSampler.get_lambda / lambd / sigma / inv_lambd (sampler_edm.py:528-556) on host fp32 scalars.  log spacing: the
-// grid holds lambda = -log sigma, a torch.linspace over n + 1 points between the first and the last sigma; otherwise the
-// grid IS the sigma list.
-struct DpmGrid {
-    std::vector<float> g;
-    bool logsp;
-    float lam(float v) const { return logsp ? v : -logf(v); }
-    float sig(float v) const { return logsp ? expf(-v) : v; }
-    float inv(float v) const { return logsp ? v : expf(-v); }
-};
-DpmGrid dpm_grid(const float* sig, int nsig, int n, bool logsp) {
-    DpmGrid r;
-    r.logsp = logsp;
-    if (!logsp) { r.g.assign(sig, sig + nsig); return r; }
-    const float start = -logf(sig[0]), end = -logf(sig[nsig - 1]);
-    const int steps = n + 1;
-    const float step = (end - start) / (float)(steps - 1);
-    r.g.resize(steps);
-    for (int i = 0; i < steps; ++i)                                   // torch.linspace: from the start in the first half, from the end in the second
-        r.g[i] = i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - 1 - i);
-    return r;
-}
-
-int run_dpm(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const bool logsp = d.log_time_spacing != 0;
-    const int steps = logsp ? d.num_steps : d.num_steps - 1;  // sampler_edm.py:526
-    const int order = d.order;
-    if (order < 1 || order > 3) return c.count_only ? 1 : fail(c.h, "DPMSampler: order must be 1, 2 or 3");
-    if (steps < order || c.nsig < 2 || (!logsp && c.nsig < steps + 1)) return c.count_only ? 1 : fail(c.h, "DPMSampler: not enough steps / sigmas");
-    const DpmGrid G = dpm_grid(c.sig, c.nsig, steps, logsp);
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* M[3] = {c.count_only ? nullptr : p->sb[6], c.count_only ? nullptr : p->sb[7], c.count_only ? nullptr : p->sb[8]};
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    // history of grid values: index 0 = most recent
-    float sh[3] = {G.g[0], 0.f, 0.f};
-    const bool eps = d.eps_pred != 0;
-    if (c.model(X, G.sig(G.g[0]), M[0])) return 1;
-    for (int step = 1; step <= steps; ++step) {
-        const int ord = step < order ? step : std::min(order, steps + 1 - step);
-        const float sc = G.g[step];
-        const float hcur = G.lam(sc) - G.lam(sh[0]);
-        DpmArgs a;
-        memset(&a, 0, sizeof(a));
-        a.order = ord;
-        a.ratio = eps ? 1.0f : G.sig(sc) / G.sig(sh[0]);
-        const float scur = G.sig(sc);
-        // noise-prediction forms (:640-645, :660-662, :685-689): x - (s phi1) m0 - 0.5 (s phi1) D1_0, resp. - (s phi2) D1 - (s phi3) D2
-        const float e1 = expm1f(hcur);
-        a.phi1 = eps ? scur * e1 : expm1f(-hcur);
-        a.m0 = M[0]; a.m1 = M[1]; a.m2 = M[2];
-        if (ord == 2) {
-            const float h1 = G.lam(sh[0]) - G.lam(sh[1]);
-            const float r0 = h1 / hcur;
-            a.inv_r0 = 1.0f / r0;
-        } else if (ord == 3) {
-            const float h1 = G.lam(sh[1]) - G.lam(sh[2]);
-            const float h0 = G.lam(sh[0]) - G.lam(sh[1]);
-            const float r0 = h0 / hcur, r1 = h1 / hcur;
-            a.inv_r0 = 1.0f / r0; a.inv_r1 = 1.0f / r1;
-            a.r0_frac = r0 / (r0 + r1);
-            a.inv_r01 = 1.0f / (r0 + r1);
-            if (eps) {
-                const float p2 = e1 / hcur - 1.0f, p3 = p2 / hcur - 0.5f;
-                a.phi2 = -(scur * p2);                      // the kernel forms v + phi2 D1 - phi3 D2
-                a.phi3 = scur * p3;
-            } else {
-                a.phi2 = a.phi1 / hcur + 1.0f;
-                a.phi3 = a.phi2 / hcur - 0.5f;
-            }
-        }
-        const int last = step == steps;
-        if (!c.count_only && c.ck(launch_dpm_update(XN, X, a, last, c.n, c.s))) return 1;
-        std::swap(X, XN);
-        sh[2] = sh[1]; sh[1] = sh[0]; sh[0] = sc;
-        if (!last) {
-            float* oldest = M[2];
-            M[2] = M[1]; M[1] = M[0]; M[0] = oldest;
-            if (c.model(X, G.sig(sc), M[0])) return 1;
-        }
-    }
-    *result = X;
-    return 0;
-}
-
-// DPMSampler with multisteps=False, x0_pred=True ("DPM-Solver-fast"): sampler_edm.py:769-805 + :568-622.  Kept as
-// written: with log_time_spacing=False the grid is the whole sigma list but only len(orders) intervals are walked (the
-// run stops early), and the intermediate points add a lambda-space step to a sigma before inv_lambd (:584, :604).
-int run_dpm_single(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const bool logsp = d.log_time_spacing != 0;
-    const int n_eff = logsp ? d.num_steps : d.num_steps - 1;
-    const int order = d.order;
-    if (order < 1 || order > 3) return c.count_only ? 1 : fail(c.h, "DPMSampler: order must be 1, 2 or 3");
-    if (n_eff < 1 || c.nsig < 2) return c.count_only ? 1 : fail(c.h, "DPMSampler: not enough steps / sigmas");
-    std::vector<int> orders;
-    int K;
-    if (order == 3) {
-        K = n_eff / 3 + 1;
-        if (n_eff % 3 == 0) { orders.assign(std::max(K - 2, 0), 3); orders.push_back(2); orders.push_back(1); }
-        else { orders.assign(K - 1, 3); orders.push_back(n_eff % 3); }
-    } else if (order == 2) {
-        K = (n_eff + 1) / 2;
-        orders.assign(n_eff / 2, 2);
-        if (n_eff % 2) orders.push_back(1);
-    } else {
-        K = n_eff;
-        orders.assign(n_eff, 1);
-    }
-    if (!logsp && c.nsig < (int)orders.size() + 1) return c.count_only ? 1 : fail(c.h, "DPMSampler: fewer sigmas than solver intervals");
-    const DpmGrid G = dpm_grid(c.sig, c.nsig, K, logsp);
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* U = c.count_only ? nullptr : p->sb[2];
-    float* E0 = c.count_only ? nullptr : p->sb[6];
-    float* E1 = c.count_only ? nullptr : p->sb[7];
-    float* E2 = c.count_only ? nullptr : p->sb[8];
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    auto comb = [&](float* out, const float* e1, float a, float b, float cc, int clampit) -> int {
-        return c.count_only ? 0 : c.ck(launch_lincomb(out, X, E0, e1, a, b, cc, clampit, c.n, c.s));
-    };
-    for (size_t i = 0; i < orders.size(); ++i) {
-        const float cur = G.g[i], nxt = G.g[i + 1];
-        const float h = G.lam(nxt) - G.lam(cur);
-        const float ratio = G.sig(nxt) / G.sig(cur);
-        const int last = i + 1 == orders.size();
-        if (c.model(X, G.sig(cur), E0)) return 1;
-        if (d.eps_pred) {
-            // noise-prediction forms (:578-579, :594-597, :617-621): every update is x - b eps + c (eps' - eps)
-            const float sn = G.sig(nxt), eh = expm1f(h);
-            if (orders[i] == 1) {
-                if (comb(XN, nullptr, 1.0f, sn * eh, 0.f, last)) return 1;
-            } else if (orders[i] == 2) {
-                const float r1 = 0.5f;
-                const float s1 = G.inv(cur + r1 * h);
-                if (comb(U, nullptr, 1.0f, G.sig(s1) * expm1f(r1 * h), 0.f, 0)) return 1;
-                if (c.model(U, G.sig(s1), E1)) return 1;
-                if (comb(XN, E1, 1.0f, sn * eh, -(sn / (float)(2.0 * 0.5) * eh), last)) return 1;
-            } else {
-                const double r1d = 1.0 / 3.0, r2d = 2.0 / 3.0;
-                const float r1 = (float)r1d, r2 = (float)r2d;
-                const float s1 = G.inv(cur + r1 * h), s2 = G.inv(cur + r2 * h);
-                if (comb(U, nullptr, 1.0f, G.sig(s1) * expm1f(r1 * h), 0.f, 0)) return 1;
-                if (c.model(U, G.sig(s1), E1)) return 1;
-                const float cu2 = -(G.sig(s2) * (float)(r2d / r1d) * (expm1f(r2 * h) / (r2 * h) - 1.0f));
-                if (comb(U, E1, 1.0f, G.sig(s2) * expm1f(r2 * h), cu2, 0)) return 1;
-                if (c.model(U, G.sig(s2), E2)) return 1;
-                const float cx3 = -(sn / (float)r2d * (eh / h - 1.0f));
-                if (comb(XN, E2, 1.0f, sn * eh, cx3, last)) return 1;
-            }
-        } else if (orders[i] == 1) {
-            if (comb(XN, nullptr, ratio, expm1f(-h), 0.f, last)) return 1;
-        } else if (orders[i] == 2) {
-            const float r1 = 0.5f;
-            const float s1 = G.inv(cur + r1 * h);
-            if (comb(U, nullptr, G.sig(s1) / G.sig(cur), expm1f(-r1 * h), 0.f, 0)) return 1;
-            if (c.model(U, G.sig(s1), E1)) return 1;
-            if (comb(XN, E1, ratio, expm1f(-h), -((float)(1.0 / (2.0 * 0.5)) * expm1f(-h)), last)) return 1;
-        } else {
-            const double r1d = 1.0 / 3.0, r2d = 2.0 / 3.0;
-            const float r1 = (float)r1d, r2 = (float)r2d;
-            const float s1 = G.inv(cur + r1 * h), s2 = G.inv(cur + r2 * h);
-            if (comb(U, nullptr, G.sig(s1) / G.sig(cur), expm1f(-r1 * h), 0.f, 0)) return 1;
-            if (c.model(U, G.sig(s1), E1)) return 1;
-            const float cu2 = (float)(r2d / r1d) * (expm1f(-r2 * h) / (r2 * h) + 1.0f);
-            if (comb(U, E1, G.sig(s2) / G.sig(cur), expm1f(-r2 * h), cu2, 0)) return 1;
-            if (c.model(U, G.sig(s2), E2)) return 1;
-            const float cx3 = (float)(1.0 / r2d) * (expm1f(-h) / h + 1.0f);
-            if (comb(XN, E2, ratio, expm1f(-h), cx3, last)) return 1;
-        }
-        std::swap(X, XN);
-    }
-    *result = X;
-    return 0;
-}
-
-// DPM2MSampler: sampler_edm.py:1111-1131 (num_steps updates over sigmas[i], sigmas[i + 1]; the schedule must hold num_steps + 1
-// entries -- with fewer the reference raises IndexError), :1072-1109 (step), fp32 scalars on the host
-int run_dpm2m(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const int N = d.num_steps;
-    if (N < 1 || c.nsig < N + 1) return c.count_only ? 1 : fail(c.h, "DPM2MSampler: the schedule must hold num_steps + 1 sigmas (the reference indexes sigmas[i + 1])");
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* D[2] = {c.count_only ? nullptr : p->sb[5], c.count_only ? nullptr : p->sb[6]};
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    for (int i = 0; i < N; ++i) {
-        const float sg = c.sig[i], sn = c.sig[i + 1];
-        float* den = D[i & 1];
-        const float* old = i > 0 ? D[(i + 1) & 1] : nullptr;
-        if (c.den(X, sg, den)) return 1;
-        if (d.reflow && !c.count_only && c.ck(launch_reflow(den, X, sg, c.n, c.s))) return 1;     // stochastic_sampler_edm.py:214-215
-        const float t = -logf(sg), tn = -logf(sn);
-        const float h = tn - t;
-        const float ratio = fminf(expf(-tn), expf(-t)) / fmaxf(expf(-tn), expf(-t));
-        if (!old || sn == 0.0f) {
-            if (!c.count_only && c.ck(launch_dpm2m(XN, X, den, nullptr, ratio, expm1f(-h), 1.f, 0.f, c.n, c.s))) return 1;
-        } else {
-            const float h_last = t - (-logf(c.sig[i - 1]));
-            const float h_min = fminf(h_last, h), h_max = fmaxf(h_last, h);
-            const float r = h_max / h_min;
-            const float h_d = (h_max + h_min) / 2.0f;
-            const float c2 = 1.0f / (2.0f * r);
-            if (!c.count_only && c.ck(launch_dpm2m(XN, X, den, old, ratio, expm1f(-h_d), 1.0f + c2, c2, c.n, c.s))) return 1;
-        }
-        std::swap(X, XN);
-    }
-    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
-    *result = X;
-    return 0;
-}
-
-// LMSSampler.linear_multistep_coeff (sampler_edm.py:1149-1160): the integral over [t_i, t_{i+1}] of the Lagrange basis
-// polynomial of node t_{i-j} among t_i .. t_{i-order+1}.  Degree <= 3, so 3-point Gauss-Legendre in double is exact (the
-// reference integrates numerically with scipy quad to 1e-4 relative).
-double lms_coeff(int order, const float* t, int i, int j) {
-    static const double gx[3] = {-0.7745966692414834, 0.0, 0.7745966692414834};
-    static const double gw[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
-    const double a = t[i], b = t[i + 1], half = 0.5 * (b - a), mid = 0.5 * (a + b);
-    double s = 0.0;
-    for (int q = 0; q < 3; ++q) {
-        const double tau = mid + half * gx[q];
-        double prod = 1.0;
-        for (int k = 0; k < order; ++k) {
-            if (k == j) continue;
-            prod *= (tau - (double)t[i - k]) / ((double)t[i - j] - (double)t[i - k]);
-        }
-        s += gw[q] * prod;
-    }
-    return s * half;
-}
-
-// LMSSampler.forward: sampler_edm.py:1162-1190 (num_steps - 1 evaluations, history of `order` derivatives, final clamp)
-int run_lms(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const int N = d.num_steps, order = d.order;
-    if (order < 1 || order > 4) return c.count_only ? 1 : fail(c.h, "LMSSampler: order must be 1..4");
-    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "LMSSampler: need at least num_steps (>= 2) sigmas");
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* DEN = c.count_only ? nullptr : p->sb[5];
-    float* D[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (!c.count_only) { D[0] = p->sb[1]; D[1] = p->sb[2]; D[2] = p->sb[3]; D[3] = p->sb[4]; }
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    for (int i = 0; i + 1 < N; ++i) {
-        if (c.den(X, c.sig[i], DEN)) return 1;
-        const int cur = std::min(i + 1, order);
-        LmsArgs a;
-        memset(&a, 0, sizeof(a));
-        a.order = cur;
-        for (int j = 0; j < cur; ++j) a.c[j] = (float)lms_coeff(cur, c.sig, i, j);
-        a.dcur = D[i & 3];
-        a.d1 = D[(i + 3) & 3]; a.d2 = D[(i + 2) & 3]; a.d3 = D[(i + 1) & 3];
-        if (!c.count_only && c.ck(launch_lms(X, DEN, c.sig[i], a, c.n, c.s))) return 1;
-    }
-    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
-    *result = X;
-    return 0;
-}
-
-// DPM2Sampler: sampler_edm.py:470-493 (loop over num_steps-1 steps, final clamp), :428-468 (step).  As written in
-// the reference the churned point only feeds the first derivative; both updates start from the un-churned x.
-int run_dpm2(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const int N = d.num_steps;
-    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "DPM2Sampler: need at least num_steps (>= 2) sigmas");
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* XH = c.count_only ? nullptr : p->sb[2];
-    float* X2 = c.count_only ? nullptr : p->sb[3];
-    float* DEN = c.count_only ? nullptr : p->sb[5];
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    const float gmax = fminf(d.s_churn / (float)N, (float)(std::sqrt(2.0) - 1.0));
-    for (int i = 0; i + 1 < N; ++i) {
-        const float sg = c.sig[i], sn = c.sig[i + 1];
-        const float gamma = (sg >= d.s_tmin && sg <= d.s_tmax) ? gmax : 0.0f;
-        const float s_hat = sg + gamma * sg;
-        const float* xh = X;
-        if (gamma > 0.f) {
-            if (!c.count_only) {
-                if (!p->inj_stage) return fail(c.h, "DPM2Sampler with churn needs injected_noise");
-                const float cc = sqrtf(s_hat * s_hat - sg * sg);
-                if (c.ck(launch_churn(XH, X, p->inj_stage + (size_t)i * c.n, cc, d.s_noise, c.n, c.s))) return 1;
-            }
-            xh = XH;
-        }
-        if (c.den(xh, s_hat, DEN)) return 1;
-        if (sn == 0.0f) {
-            if (!c.count_only && c.ck(launch_dstep(XN, X, xh, DEN, s_hat, sn - s_hat, c.n, c.s))) return 1;
-        } else {
-            const float lh = logf(s_hat), ln = logf(sn);
-            const float s_mid = expf(lh + 0.5f * (ln - lh));                 // log().lerp(log(), 0.5).exp() in fp32
-            if (!c.count_only && c.ck(launch_dstep(X2, X, xh, DEN, s_hat, s_mid - s_hat, c.n, c.s))) return 1;
-            if (c.den(X2, s_mid, DEN)) return 1;
-            if (!c.count_only && c.ck(launch_dstep(XN, X, X2, DEN, s_mid, sn - s_hat, c.n, c.s))) return 1;
-        }
-        std::swap(X, XN);
-    }
-    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
-    *result = X;
-    return 0;
-}
-
-// ADPM2Sampler: stochastic_sampler_edm.py:85-100 (loop, final clamp), :53-83 (step), :29-32 (get_sigmas); fp32 scalars
-int run_adpm2(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const int N = d.num_steps;
-    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "ADPM2Sampler: need at least num_steps (>= 2) sigmas");
-    if (!(d.rho > 0.f)) return c.count_only ? 1 : fail(c.h, "ADPM2Sampler: rho must be positive");
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* XM = c.count_only ? nullptr : p->sb[3];
-    float* DEN = c.count_only ? nullptr : p->sb[5];
-    if (!c.count_only && !p->inj_stage) return fail(c.h, "ADPM2Sampler needs injected_noise (one draw per step)");
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    for (int i = 0; i + 1 < N; ++i) {
-        const float sg = c.sig[i], sn = c.sig[i + 1];
-        const float up_raw = d.eta * sqrtf(sn * sn * (sg * sg - sn * sn) / (sg * sg));
-        const float s_up = sn < up_raw ? sn : up_raw;                          // python min(sigma_next, ...)
-        const float s_down = sqrtf(sn * sn - s_up * s_up);
-        const float inv = 1.0f / d.rho;
-        const float s_mid = powf((powf(sg, inv) + powf(s_down, inv)) / 2.0f, d.rho);
-        if (c.den(X, sg, DEN)) return 1;
-        if (!c.count_only && c.ck(launch_dstep(XM, X, X, DEN, sg, s_mid - sg, c.n, c.s))) return 1;
-        if (c.den(XM, s_mid, DEN)) return 1;
-        if (!c.count_only) {
-            if (c.ck(launch_dstep(XN, X, XM, DEN, s_mid, s_down - sg, c.n, c.s))) return 1;
-            if (c.ck(launch_churn(X, XN, p->inj_stage + (size_t)i * c.n, s_up, 1.0f, c.n, c.s))) return 1;   // x + sigma_up * randn
-        }
-    }
-    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
-    *result = X;
-    return 0;
-}
-
-// ADPMPP2SSampler: stochastic_sampler_edm.py:162-178 (loop, final clamp), :117-160 (step), :29-32 (get_sigmas); fp32 scalars.  A draw is
-// consumed only by a step whose sigma_next is positive (:158): adpmpp2s_draws() counts them for the injected-noise check.
-static int adpmpp2s_draws(const float* sig, int nsig, int N) {
-    int k = 0;
-    for (int i = 0; i + 1 < N && i + 1 < nsig; ++i) k += sig[i + 1] > 0.0f;
-    return k;
-}
-int run_adpmpp2s(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const int N = d.num_steps;
-    if (N < 2 || c.nsig < N) return c.count_only ? 1 : fail(c.h, "ADPMPP2SSampler: need at least num_steps (>= 2) sigmas");
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* X2 = c.count_only ? nullptr : p->sb[3];
-    float* DEN = c.count_only ? nullptr : p->sb[5];
-    if (!c.count_only && !p->inj_stage && adpmpp2s_draws(c.sig, c.nsig, N) > 0) return fail(c.h, "ADPMPP2SSampler needs injected_noise (one draw per step with sigma_next > 0)");
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    int k = 0;
-    for (int i = 0; i + 1 < N; ++i) {
-        const float sg = c.sig[i], sn = c.sig[i + 1];
-        const float up_raw = d.eta * sqrtf(sn * sn * (sg * sg - sn * sn) / (sg * sg));
-        const float s_up = sn < up_raw ? sn : up_raw;                          // python min(sigma_next, ...)
-        const float s_down = sqrtf(sn * sn - s_up * s_up);
-        if (c.den(X, sg, DEN)) return 1;
-        if (s_down == 0.0f) {                                                  // Euler step to sigma_down (:136-140)
-            if (!c.count_only && c.ck(launch_dstep(XN, X, X, DEN, sg, s_down - sg, c.n, c.s))) return 1;
-        } else {
-            const float t = -logf(sg), tn = -logf(s_down);
-            const float h = tn - t;
-            const float sm = t + 0.5f * h;
-            const float sig_mid = expf(-sm);
-            if (!c.count_only && c.ck(launch_dpm2m(X2, X, DEN, nullptr, sig_mid / expf(-t), expm1f(-h * 0.5f), 1.f, 0.f, c.n, c.s))) return 1;
-            if (c.den(X2, sig_mid, DEN)) return 1;
-            if (!c.count_only && c.ck(launch_dpm2m(XN, X, DEN, nullptr, expf(-tn) / expf(-t), expm1f(-h), 1.f, 0.f, c.n, c.s))) return 1;
-        }
-        if (sn > 0.0f) {
-            if (!c.count_only && c.ck(launch_churn(X, XN, p->inj_stage + (size_t)k * c.n, s_up, 1.0f, c.n, c.s))) return 1;   // x + sigma_up * randn
-            ++k;
-        } else {
-            std::swap(X, XN);
-        }
-    }
-    if (!c.count_only && c.ck(launch_clamp(X, c.n, c.s))) return 1;
-    *result = X;
-    return 0;
-}
-
-// UniPCSampler.forward (sampler_edm.py:996-1053, variant 'bh2').  Every coefficient depends on the grid only: computed on the host
-// in fp32 in the reference's order of operations (the small solves of :934, :942 by Gaussian elimination with partial pivoting, as
-// LAPACK's gesv does); one launch per predictor / corrector formula.
-static void unipc_solve(int n, float A[3][3], float* b, float* x) {
-    int piv[3] = {0, 1, 2};
-    for (int k = 0; k < n; ++k) {
-        int p = k;
-        for (int i = k + 1; i < n; ++i) if (fabsf(A[piv[i]][k]) > fabsf(A[piv[p]][k])) p = i;
-        std::swap(piv[k], piv[p]);
-        for (int i = k + 1; i < n; ++i) {
-            const float f = A[piv[i]][k] / A[piv[k]][k];
-            for (int j = k; j < n; ++j) A[piv[i]][j] -= f * A[piv[k]][j];
-            b[piv[i]] -= f * b[piv[k]];
-        }
-    }
-    for (int k = n - 1; k >= 0; --k) {
-        float acc = b[piv[k]];
-        for (int j = k + 1; j < n; ++j) acc -= A[piv[k]][j] * x[j];
-        x[k] = acc / A[piv[k]][k];
-    }
-}
-
-int run_unipc(SamplerCtx& c, float** result) {
-    const adf_sampler_desc& d = *c.d;
-    const bool logsp = d.log_time_spacing != 0, eps = d.eps_pred != 0;
-    const int steps = logsp ? d.num_steps : d.num_steps - 1;          // :828
-    const int order = d.order;
-    if (order < 1 || order > 3) return c.count_only ? 1 : fail(c.h, "UniPCSampler: order must be 1, 2 or 3");
-    if (steps < order || c.nsig < 2 || (!logsp && c.nsig < steps + 1)) return c.count_only ? 1 : fail(c.h, "UniPCSampler: not enough steps / sigmas");
-    const DpmGrid G = dpm_grid(c.sig, c.nsig, steps, logsp);
-    Plan* p = c.p;
-    float* X = c.count_only ? nullptr : p->sb[0];
-    float* XN = c.count_only ? nullptr : p->sb[1];
-    float* XT = c.count_only ? nullptr : p->sb[2];
-    float* MB[4] = {c.count_only ? nullptr : p->sb[6], c.count_only ? nullptr : p->sb[7], c.count_only ? nullptr : p->sb[8], c.count_only ? nullptr : p->sb[9]};
-    if (!c.count_only && c.ck(launch_scale(X, p->noise_stage, c.sig[0], c.n, c.s))) return 1;
-    // history, oldest first (as the reference's lists); a free buffer of MB receives the next model value
-    std::vector<float*> ml; std::vector<float> gl;
-    auto free_buf = [&]() -> float* { for (float* b : MB) if (std::find(ml.begin(), ml.end(), b) == ml.end()) return b; return MB[0]; };
-    float* m_first = free_buf();
-    if (c.model(X, G.sig(G.g[0]), m_first)) return 1;
-    ml.push_back(m_first); gl.push_back(G.g[0]);
-    auto update = [&](float g_cur, int ord, bool corr, float** x_io, float** m_out) -> int {
-        const float g0 = gl.back();
-        const float h = G.lam(g_cur) - G.lam(g0);
-        float rks[3]; int K = 0;
-        const float* mk[2] = {nullptr, nullptr};
-        for (int i = 1; i < ord; ++i) { rks[K] = (G.lam(gl[gl.size() - 1 - i]) - G.lam(g0)) / h; mk[K] = ml[ml.size() - 1 - i]; ++K; }
-        rks[K] = 1.0f;
-        const float hh = eps ? h : -h;
-        const float h_phi_1 = expm1f(hh);
-        float h_phi_k = h_phi_1 / hh - 1.0f;
-        const float B_h = expm1f(hh);
-        float R[3][3], bb[3];
-        float fact = 1.0f;
-        for (int i = 1; i <= ord; ++i) {
-            for (int j = 0; j < ord; ++j) R[i - 1][j] = i == 1 ? 1.0f : (i == 2 ? rks[j] : rks[j] * rks[j]);
-            bb[i - 1] = h_phi_k * fact / B_h;
-            fact *= (float)(i + 1);
-            h_phi_k = h_phi_k / hh - 1.0f / fact;
-        }
-        float rhos_p[3] = {0.f, 0.f, 0.f}, rhos_c[3] = {0.f, 0.f, 0.f};
-        if (K > 0) {
-            if (ord == 2) rhos_p[0] = 0.5f;
-            else { float A2[3][3], b2[3]; for (int i = 0; i < ord - 1; ++i) { b2[i] = bb[i]; for (int j = 0; j < ord - 1; ++j) A2[i][j] = R[i][j]; } unipc_solve(ord - 1, A2, b2, rhos_p); }
-        }
-        if (corr) {
-            if (ord == 1) rhos_c[0] = 0.5f;
-            else { float A2[3][3], b2[3]; for (int i = 0; i < ord; ++i) { b2[i] = bb[i]; for (int j = 0; j < ord; ++j) A2[i][j] = R[i][j]; } unipc_solve(ord, A2, b2, rhos_c); }
-        }
-        const float sc = G.sig(g_cur);
-        UniPcArgs u;
-        memset(&u, 0, sizeof(u));
-        u.a = eps ? 1.0f : sc / G.sig(g0);
-        u.hp = eps ? sc * h_phi_1 : h_phi_1;
-        u.sb = eps ? sc * B_h : B_h;
-        u.K = K; u.m0 = ml.back(); u.m[0] = mk[0]; u.m[1] = mk[1];
-        for (int k = 0; k < K; ++k) { u.rk[k] = rks[k]; u.rho[k] = rhos_p[k]; }
-        u.mt = nullptr;
-        float* xin = *x_io;
-        float* xt = corr ? XT : (xin == X ? XN : X);
-        if (!c.count_only && c.ck(launch_unipc(xt, xin, u, c.n, c.s))) return 1;      // predictor (:951-957 / :973-979)
-        *m_out = nullptr;
-        if (corr) {
-            float* mt = free_buf();
-            if (c.model(xt, sc, mt)) return 1;
-            for (int k = 0; k < K; ++k) u.rho[k] = rhos_c[k];
-            u.rho_t = rhos_c[ord - 1]; u.mt = mt;
-            float* xo = xin == X ? XN : X;
-            if (!c.count_only && c.ck(launch_unipc(xo, xin, u, c.n, c.s))) return 1;  // corrector (:959-967 / :981-990)
-            *m_out = mt; *x_io = xo;
-        } else {
-            *x_io = xt;
-        }
-        return 0;
-    };
-    float* x = X;
-    for (int step = 1; step < order; ++step) {                         // :1013-1022
-        float* m = nullptr;
-        if (update(G.g[step], step, true, &x, &m)) return 1;
-        gl.push_back(G.g[step]); ml.push_back(m);
-    }
-    for (int step = order; step <= steps; ++step) {                    // :1025-1051
-        float* m = nullptr;
-        const int so = order < steps + 1 - step ? order : steps + 1 - step;
-        if (update(G.g[step], so, step != steps, &x, &m)) return 1;
-        for (int i = 0; i + 1 < order; ++i) { gl[i] = gl[i + 1]; ml[i] = ml[i + 1]; }
-        gl.back() = G.g[step];
-        if (step < steps) ml.back() = m;
-    }
-    if (!c.count_only && c.ck(launch_clamp(x, c.n, c.s))) return 1;
-    *result = x;
-    return 0;
-}
-
-int run_sampler(SamplerCtx& c, float** result) {
-    switch (c.d->kind) {
-        case ADF_SAMPLER_DPM2: return run_dpm2(c, result);
-        case ADF_SAMPLER_ADPM2: return run_adpm2(c, result);
-        case ADF_SAMPLER_EDM: return run_edm(c, result);
-        case ADF_SAMPLER_EDM_ALPHA: return run_edm_alpha(c, result);
-        case ADF_SAMPLER_DPM_MULTISTEP: return run_dpm(c, result);
-        case ADF_SAMPLER_DPM_SINGLESTEP: return run_dpm_single(c, result);
-        case ADF_SAMPLER_LMS: return run_lms(c, result);
-        case ADF_SAMPLER_DPM2M: return run_dpm2m(c, result);
-        case ADF_SAMPLER_UNIPC: return run_unipc(c, result);
-        case ADF_SAMPLER_ADPMPP2S: return run_adpmpp2s(c, result);
-        default: return c.count_only ? 1 : fail(c.h, "unknown sampler kind");
-    }
-}
-
-}  // namespace
+}  // namespace adf_api
 
 // =====================================================================================================
 // C ABI
@@ -2323,140 +517,5 @@ int adf_debug_tap_copy(adf_handle* h, const char* name, float* out, void* stream
 }
 
 int64_t adf_device_bytes(const adf_handle* h) { return h->bytes; }
-
-// conv = 0: both launches of the block; 1 / 2: only conv1 / conv2 (the other's outputs are zero)
-static int bench_resblock_impl(adf_handle* h, int B, int L, int level, int conv, int iters, float* ms1, float* ms2, double* bytes1,
-                               double* bytes2, double* flops1, double* flops2, int* ncopies, void* stream) {
-    ADF_ON_DEVICE(h);
-    hipStream_t s = (hipStream_t)stream;
-    Plan* p;
-    if (get_plan(h, B, L, s, &p)) return 1;
-    if (p->rbs.empty()) return fail(h, "no resblock recorded; run a forward first");
-    if (level < 0 || level >= (int)p->rbs.size()) return fail(h, "resblock index out of range");
-    if (iters < 1) return fail(h, "bench_resblock: iters must be >= 1");
-    const RbRec& r = p->rbs[level];
-    if (r.g1.nseg == 0) {                                  // fused short-level block: no separate conv launches to replay
-        *ms1 = *ms2 = 0.f; *bytes1 = *bytes2 = *flops1 = *flops2 = 0.0;
-        return 0;
-    }
-    // The replay must cost what the launch costs inside a network pass: (1) the launch is the real one -- GroupNorm table
-    // derived from the input statistics (in the kernel, or by the gn_finalize launch the route needs), statistics of the
-    // output reduced in the epilogue (into a scratch buffer); (2) its operands are NOT served by the 256 MiB Infinity Cache:
-    // every iteration works on another copy of (inputs, residual, output), >= 3 copies and >= 320 MiB in rotation.
-    const size_t esz = (size_t)h->esz;
-    struct Op { const void** ptr; size_t bytes; };
-    auto operands = [&](GemmArgs& g, std::vector<Op>& ops) {
-        for (int k = 0; k < g.nseg; ++k) {
-            if (g.seg[k].src0) ops.push_back({&g.seg[k].src0, (size_t)g.B * g.lin * g.seg[k].c0 * esz});
-            if (g.seg[k].src1) ops.push_back({&g.seg[k].src1, (size_t)g.B * g.lin * g.seg[k].c1 * esz});
-        }
-        if (g.res) ops.push_back({&g.res, (size_t)g.B * g.out_rows * g.out_c * esz});
-        ops.push_back({(const void**)&g.out, (size_t)g.B * g.out_rows * g.out_c * esz});
-    };
-    auto set_bytes = [&](const GemmArgs& gc) {
-        GemmArgs g = gc;
-        std::vector<Op> ops;
-        operands(g, ops);
-        size_t t = 0;
-        for (const Op& o : ops) t += (o.bytes + 255) & ~(size_t)255;
-        return t;
-    };
-    const size_t rot_min = (size_t)320 << 20;
-    auto copies = [&](const GemmArgs& g) { const size_t sb = set_bytes(g); size_t n = (rot_min + sb - 1) / sb; return n < 3 ? (size_t)3 : n; };
-    const size_t stats_bytes = ((size_t)B * h->cfg.resnet_groups * 2 * sizeof(double) + 255) & ~(size_t)255;
-    const size_t need = std::max(set_bytes(r.g1) * copies(r.g1), set_bytes(r.g2) * copies(r.g2)) + stats_bytes;
-    if (p->bench_cap < need) {
-        if (hipStreamSynchronize(s) != hipSuccess) return fail(h, "bench_resblock: stream sync failed");
-        dfree(h, p->bench_buf, p->bench_cap, p);
-        p->bench_buf = (char*)dalloc(h, need, p);
-        p->bench_cap = p->bench_buf ? need : 0;
-        if (!p->bench_buf) return fail(h, "bench_resblock: device allocation failed for the rotating operand copies");
-    }
-    double* scratch_stats = (double*)p->bench_buf;
-    auto run = [&](const GemmArgs& g0, float* ms) -> int {
-        const size_t R = copies(g0);
-        if (ncopies) *ncopies = (int)R;
-        std::vector<GemmArgs> sets(R, g0);
-        char* cur = p->bench_buf + stats_bytes;
-        for (size_t k = 0; k < R; ++k) {
-            std::vector<Op> ops;
-            operands(sets[k], ops);
-            for (Op& o : ops) {
-                const bool is_out = (const void**)&sets[k].out == o.ptr;
-                if (!is_out && hipMemcpyAsync(cur, *o.ptr, o.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "bench_resblock: operand copy failed");
-                *o.ptr = cur;
-                cur += (o.bytes + 255) & ~(size_t)255;
-            }
-            if (sets[k].stats) sets[k].stats = scratch_stats;
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(h, "bench_resblock: hipEventCreate failed");
-        int rc = 0;
-        for (size_t k = 0; k < R && !rc; ++k)
-            if (const char* e = launch_conv_gemm(sets[k], h->bf16, s)) rc = fail(h, e);          // warm-up: code, attributes, TLBs
-        if (!rc && hipEventRecord(e0, s) != hipSuccess) rc = fail(h, "bench_resblock: hipEventRecord failed");
-        for (int i = 0; i < iters && !rc; ++i)
-            if (const char* e = launch_conv_gemm(sets[(size_t)i % R], h->bf16, s)) rc = fail(h, e);
-        if (!rc && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(h, "bench_resblock: event record / sync failed");
-        float t = 0.f;
-        if (!rc && hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = fail(h, "bench_resblock: hipEventElapsedTime failed");
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        *ms = t / (float)iters;
-        return rc;
-    };
-    *ms1 = *ms2 = 0.f;
-    if ((conv != 2 && run(r.g1, ms1)) || (conv != 1 && run(r.g2, ms2))) return 1;
-    const double es = h->esz, BL = (double)B * r.L, ci = r.cin, co = r.cout;
-    // x read for conv1; x read again for the residual; h1 written and re-read; y written; weights once
-    *bytes1 = BL * es * (ci + co) + es * 3.0 * ci * co;
-    *bytes2 = BL * es * (co + ci + co) + es * (3.0 * co * co + (ci != co ? ci * co : 0.0));
-    *flops1 = 2.0 * BL * 3.0 * ci * co;
-    *flops2 = 2.0 * BL * (3.0 * co * co + (ci != co ? ci * co : 0.0));
-    return 0;
-}
-
-int adf_bench_resblock(adf_handle* h, int B, int L, int level, int iters, float* ms1, float* ms2, double* bytes1, double* bytes2,
-                       double* flops1, double* flops2, void* stream) {
-    return bench_resblock_impl(h, B, L, level, 0, iters, ms1, ms2, bytes1, bytes2, flops1, flops2, nullptr, stream);
-}
-
-int adf_bench_layer(adf_handle* h, int B, int L, int level, int conv, int iters, float* ms, double* algo_bytes, double* flops,
-                    int* copies, void* stream) {
-    if (conv != 1 && conv != 2) return fail(h, "adf_bench_layer: conv must be 1 or 2");
-    float m1 = 0.f, m2 = 0.f;
-    double b1 = 0, b2 = 0, f1 = 0, f2 = 0;
-    if (bench_resblock_impl(h, B, L, level, conv, iters, &m1, &m2, &b1, &b2, &f1, &f2, copies, stream)) return 1;
-    *ms = conv == 1 ? m1 : m2; *algo_bytes = conv == 1 ? b1 : b2; *flops = conv == 1 ? f1 : f2;
-    return 0;
-}
-
-int adf_bench_wavenet_layer(adf_handle* h, int B, int T, int layer, int iters, float* ms, double* algo_bytes, double* flops, void* stream) {
-    ADF_ON_DEVICE(h);
-    if (!h->wn) return fail(h, "adf_bench_wavenet_layer: not a WaveNetNoise handle");
-    hipStream_t s = (hipStream_t)stream;
-    Plan* p;
-    if (get_plan(h, B, T, s, &p)) return 1;
-    if (layer < 0 || layer >= (int)p->wn_layers.size()) return fail(h, "adf_bench_wavenet_layer: layer out of range (run a forward first)");
-    if (iters < 1) return fail(h, "adf_bench_wavenet_layer: iters must be positive");
-    const WnLayerArgs& a = p->wn_layers[layer];
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(h, "hipEventCreate failed");
-    const char* err = nullptr;
-    for (int i = 0; i < 2 && !err; ++i) err = launch_wn_layer(p->wn_io, a, s);
-    if (!err && hipEventRecord(e0, s) != hipSuccess) err = "hipEventRecord failed";
-    for (int i = 0; i < iters && !err; ++i) err = launch_wn_layer(p->wn_io, a, s);
-    if (!err && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) err = "event sync failed";
-    float t = 0.f;
-    if (!err && hipEventElapsedTime(&t, e0, e1) != hipSuccess) err = "hipEventElapsedTime failed";
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (err) return fail(h, err);
-    const double C = h->wn->cfg.residual_channels, pos = (double)B * T, esz = h->esz;
-    *ms = t / (float)iters;
-    // per position: read y, write y_next (not for the last layer), skip read-modify-write in fp32 (first layer: write only);
-    // per launch: both weight matrices once.  Flops: the K = 3C and K = C GEMMs onto 2C columns each.
-    *algo_bytes = pos * C * (esz + (a.y_next ? esz : 0.0) + (a.first ? 4.0 : 8.0)) + 8.0 * C * C * esz;
-    *flops = pos * 2.0 * 8.0 * C * C;
-    return 0;
-}
 
 }  // extern "C"

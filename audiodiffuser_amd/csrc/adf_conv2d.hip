@@ -599,15 +599,15 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
     if (tile_route && a.taps == 9 && a.mode != 2 && a.W % 32 == 0 && (long long)a.H * a.W * a.cin < (1ll << 31) && NT_OK(a)) {
         // a workgroup re-reads every weight slab from L2: at 128 pixels per workgroup that stream (16 KB per iteration against 64 MFMAs) runs at
         // the L2 -> CU rate and bounds the kernel; 256 pixels per workgroup halve it
-        static const int big = adf_route_switch("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
+        static const int big = (int)adf_tuning("ADF_CONV2D_TH8", 0);     // measured slower than two 128-pixel workgroups per CU: kept for A/B runs only
         if (big && a.H % 8 == 0 && px / 256 * ny >= 512) return c2_trace("t8x2", a), bf16 ? launch_conv2d_tile<bf16_t, 8, 2>(a, s) : launch_conv2d_tile<float, 8, 2>(a, s);
-        static const int th8w1 = adf_route_switch("ADF_CONV2D_TH8W1", 0); // 8 x 32 pixels on sixteen waves, one workgroup per CU (A/B runs)
+        static const int th8w1 = (int)adf_tuning("ADF_CONV2D_TH8W1", 0); // 8 x 32 pixels on sixteen waves, one workgroup per CU (A/B runs)
         if (th8w1 && a.H % 8 == 0 && px / 256 * ny >= 256) return c2_trace("t8", a), bf16 ? launch_conv2d_tile<bf16_t, 8, 1>(a, s) : launch_conv2d_tile<float, 8, 1>(a, s);
-        static const int wr2 = adf_route_switch("ADF_CONV2D_WR2", 0);     // 64 x 64 wave tiles on four waves (A/B runs)
+        static const int wr2 = (int)adf_tuning("ADF_CONV2D_WR2", 0);     // 64 x 64 wave tiles on four waves (A/B runs)
         if (wr2 && a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4x2", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 2>(a, s) : launch_conv2d_tile<float, 4, 2>(a, s);
         if (a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 1>(a, s) : launch_conv2d_tile<float, 4, 1>(a, s);
         // heights such as 10 (the 80-row mel block three levels down): 160-pixel workgroups instead of 64-pixel ones -- 2.5 x fewer passes over the weights
-        static const int th5 = adf_route_switch("ADF_CONV2D_TH5", 1);
+        static const int th5 = (int)adf_tuning("ADF_CONV2D_TH5", 1);
         if (th5 && a.H % 5 == 0 && px / 160 * ny >= 128) return c2_trace("t5", a), bf16 ? launch_conv2d_tile<bf16_t, 5, 1>(a, s) : launch_conv2d_tile<float, 5, 1>(a, s);
         if (a.H % 2 == 0) return c2_trace("t2", a), bf16 ? launch_conv2d_tile<bf16_t, 2, 1>(a, s) : launch_conv2d_tile<float, 2, 1>(a, s);
     }

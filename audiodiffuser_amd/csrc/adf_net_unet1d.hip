@@ -1,0 +1,163 @@
+// UNet1dBase behind the C ABI: the weight registry in the reference's state_dict order and the network walk that launches the
+// fused kernels (reference: src/models/backbones/unet1d.py:771-816 UNet1d.forward, :441-468 / :542-566 Down / UpsampleBlock1d).
+#include "adf_api_internal.h"
+
+using namespace adf;
+using namespace adf_api;
+
+namespace adf_api {
+
+int build_weights(adf_handle* h) {
+    const adf_net_config& c = h->cfg;
+    Registrar R{h};
+    const int ch = c.channels, tdim = 4 * ch, n = c.num_layers;
+    h->cdim = c.num_classes > 0 ? 4 * ch : 0;
+    const int temb = tdim + h->cdim;     // every FiLM Linear reads cat(time_embed, class_embed) (unet1d.py:272)
+    if (c.num_classes > 0) {             // conditioner.py:64-90, registered before the U-Net
+        h->lab_null = R.reg_f32("label_conditioner.null_classes_emb", ch);
+        h->lab_emb = R.reg_f32("label_conditioner.label_emb.weight", (int64_t)c.num_classes * ch);
+        h->lab_lnw = R.reg_f32("label_conditioner.class_to_cond.0.weight", ch);
+        h->lab_lnb = R.reg_f32("label_conditioner.class_to_cond.0.bias", ch);
+        h->lab_w1 = R.reg_f32("label_conditioner.class_to_cond.1.weight", (int64_t)h->cdim * ch);
+        h->lab_b1 = R.reg_f32("label_conditioner.class_to_cond.1.bias", h->cdim);
+        h->lab_w2 = R.reg_f32("label_conditioner.class_to_cond.3.weight", (int64_t)h->cdim * h->cdim);
+        h->lab_b2 = R.reg_f32("label_conditioner.class_to_cond.3.bias", h->cdim);
+    }
+    h->to_in_w = R.reg_f32("unet.to_in.to_in.weight", (int64_t)c.num_filters * c.in_channels * c.window_length);
+    h->to_out_w = R.reg_f32("unet.to_out.to_out.weight", (int64_t)c.num_filters * c.out_channels * c.window_length);
+    h->fourier = R.reg_f32("unet.to_time.0.0.weights", ch / 2);
+    h->t_w1 = R.reg_f32("unet.to_time.0.1.weight", (int64_t)tdim * (ch + 1));
+    h->t_b1 = R.reg_f32("unet.to_time.0.1.bias", tdim);
+    h->t_w2 = R.reg_f32("unet.to_time.2.weight", (int64_t)tdim * tdim);
+    h->t_b2 = R.reg_f32("unet.to_time.2.bias", tdim);
+    h->downs.resize(n);
+    for (int i = 0; i < n; ++i) {
+        DownW& d = h->downs[i];
+        d.cin = ch * c.multipliers[i]; d.cout = ch * c.multipliers[i + 1]; d.factor = c.factors[i];
+        const std::string pre = "unet.downsamples." + std::to_string(i);
+        R.conv_folded(pre + ".downsample", d.down, d.cout, d.cin, d.factor * c.kernel_multiplier_downsample + 1, d.factor);
+        d.blocks.resize(c.num_blocks[i]);
+        for (int j = 0; j < c.num_blocks[i]; ++j) R.resblock(pre + ".blocks." + std::to_string(j), d.blocks[j], d.cout, d.cout, temb);
+        d.attn = c.attentions[i] != 0;
+        if (d.attn) R.transformer(pre + ".transformer", d.tr, d.cout, c.attention_multiplier);
+    }
+    const int cb = ch * c.multipliers[n];
+    R.resblock("unet.bottleneck.pre_block", h->mid_pre, cb, cb, temb);
+    if (c.use_attention_bottleneck) R.transformer("unet.bottleneck.transformer", h->mid_tr, cb, c.attention_multiplier);
+    R.resblock("unet.bottleneck.post_block", h->mid_post, cb, cb, temb);
+    h->ups.resize(n);
+    for (int u = 0; u < n; ++u) {
+        const int i = n - 1 - u;
+        UpW& up = h->ups[u];
+        up.cin = ch * c.multipliers[i + 1]; up.cout = ch * c.multipliers[i]; up.factor = c.factors[i];
+        const std::string pre = "unet.upsamples." + std::to_string(u);
+        const int nb = c.num_blocks[i] + (c.attentions[i] ? 1 : 0);
+        up.blocks.resize(nb);
+        for (int j = 0; j < nb; ++j) R.resblock(pre + ".blocks." + std::to_string(j), up.blocks[j], 2 * up.cin, up.cin, temb);
+        up.attn = c.attentions[i] != 0;
+        if (up.attn) R.transformer(pre + ".transformer", up.tr, up.cin, c.attention_multiplier);
+        const int f = up.factor;
+        R.reg_pack(pre + ".upsample.weight", up.up, up.cout, up.cin, 2 * f, 0, f * up.cout, true, f);
+        if (h->bf16 && up.up.w && (up.cin == 128 || up.cin == 256) && (up.cout == 64 || up.cout == 128 || up.cout == 256) && (f == 2 || f == 4)) {
+            up.up.wfrag = dalloc(h, (size_t)up.up.nchunk * up.up.taps * up.up.n_pad * kRowBytes);   // fragment-major copy: adf_gemm_up.h
+            if (!up.up.wfrag) R.ok = false;
+            else h->slots[pre + ".upsample.weight"].frag = up.up.wfrag;
+        }
+        up.up.bias = R.reg_f32(pre + ".upsample.bias", up.cout);
+    }
+    // one concatenated FiLM projection for all resblocks
+    h->film_w = (float*)dalloc(h, (size_t)h->film_total * temb * 4);
+    h->film_b = (float*)dalloc(h, (size_t)h->film_total * 4);
+    if (!h->film_w || !h->film_b) R.ok = false;
+    for (const auto& fn : R.film_names) {
+        R.reg_f32(fn.pre + ".to_cond_embedding.1.weight", (int64_t)fn.rows * temb, h->film_w + (size_t)fn.off * temb);
+        R.reg_f32(fn.pre + ".to_cond_embedding.1.bias", fn.rows, h->film_b + fn.off);
+    }
+    return R.ok ? 0 : fail(h, "device allocation failed while building the weight registry");
+}
+
+int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
+    if (!p->dry) ++h->ctr.net_passes;
+    if (h->wn) return wn_forward(h, p, io, s);
+    if (h->adm) return adm_forward(h, p, io, s);
+    const adf_net_config& c = h->cfg;
+    Walker W{h, p, s};
+    W.film2 = io.film2; W.film2_bstride = io.film2_bstride;
+    W.film = io.film_pre ? io.film_pre : p->film;
+    p->arena_off = 0; p->stats_off = 0;
+    p->taps.clear(); p->rbs.clear();
+    const int B = p->B, L = p->L, n = c.num_layers;
+    const int pad = c.window_length / 2 - c.stride / 2;
+    const int tdim = 4 * c.channels;
+    if (!p->dry && p->stats_bytes) {
+        if (hipMemsetAsync(p->stats, 0, p->stats_bytes, s) != hipSuccess) return fail(h, "hipMemsetAsync(stats) failed");
+    }
+    // sigma embedding + every resblock's FiLM projection (unless the sampler computed them for the whole run already)
+    if (W.live() && !io.film_pre) {
+        TimeEmbedArgs te;
+        te.t = io.t; te.t_stride = io.t_stride; te.nb = io.nb; te.ch = c.channels;
+        te.fourier = h->fourier; te.w1 = h->t_w1; te.b1 = h->t_b1; te.w2 = h->t_w2; te.b2 = h->t_b2; te.temb = p->temb;
+        W.check(launch_time_embed(te, s));
+        W.check(launch_film(p->temb, tdim, h->film_w, tdim + h->cdim, 0, h->film_b, p->film, io.nb, h->film_total, s));
+    }
+    Act x = W.new_act(c.num_filters, L / c.stride);
+    if (W.live())
+        W.check(launch_to_in(io.x, h->to_in_w, x.p, h->bf16, B, c.in_channels, L, c.num_filters, c.window_length, c.stride, pad,
+                             io.coef, io.coef_bstride, s));
+    W.tap("to_in", x);
+    std::vector<std::vector<Act>> skips_list;
+    for (int i = 0; i < n; ++i) {
+        const DownW& d = h->downs[i];
+        const int f = d.factor, km = c.kernel_multiplier_downsample;
+        Act y = W.new_act(d.cout, x.L / f);
+        // Downsample1d (unet1d.py:214-225) as a stride-1 conv over the row-folded view [L/f][f*C] (Registrar::conv_folded)
+        if (x.L % f) return fail(h, "downsample: length not divisible by the factor");
+        Act xv = x;
+        xv.C = x.C * f; xv.L = x.L / f; xv.stats = nullptr;
+        GemmArgs g = W.gemm_base(y, xv.L, y.L, d.down);
+        g.seg[0] = Walker::seg_of(xv, nullptr, nullptr, 1.f, 0, km + 1, 1, -(km / 2), 1, d.down);
+        W.run_gemm(g, y, true);
+        W.tap("down" + std::to_string(i) + ".conv", y);
+        x = y;
+        std::vector<Act> skips;
+        for (size_t j = 0; j < d.blocks.size(); ++j) {
+            x = W.resblock("down" + std::to_string(i) + ".block" + std::to_string(j), x, nullptr, d.blocks[j], io.nb);
+            skips.push_back(x);
+        }
+        if (d.attn) {
+            x = W.transformer("down" + std::to_string(i) + ".attn", x, d.tr);
+            skips.push_back(x);
+        }
+        skips_list.push_back(skips);
+    }
+    x = W.resblock("mid.pre", x, nullptr, h->mid_pre, io.nb);
+    if (c.use_attention_bottleneck) x = W.transformer("mid.attn", x, h->mid_tr);
+    x = W.resblock("mid.post", x, nullptr, h->mid_post, io.nb);
+    for (int u = 0; u < n; ++u) {
+        const UpW& up = h->ups[u];
+        std::vector<Act>& skips = skips_list.back();
+        for (size_t j = 0; j < up.blocks.size(); ++j) {
+            if (skips.empty()) { W.check("upsample: skip stack underflow"); break; }
+            Act sk = skips.back();
+            skips.pop_back();
+            x = W.resblock("up" + std::to_string(u) + ".block" + std::to_string(j), x, &sk, up.blocks[j], io.nb);
+        }
+        skips_list.pop_back();
+        if (up.attn) x = W.transformer("up" + std::to_string(u) + ".attn", x, up.tr);
+        const int f = up.factor;
+        Act y = W.new_act(up.cout, x.L * f);
+        GemmArgs g = W.gemm_base(y, x.L, x.L + 1, up.up);
+        g.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, 2, 1, 0, -1, up.up);
+        g.bias_mod = up.cout;
+        g.scatter_f = f; g.scatter_pad = f / 2 + f % 2;
+        W.run_gemm(g, y, u + 1 < n);
+        W.tap("up" + std::to_string(u) + ".conv", y);
+        x = y;
+    }
+    if (W.live())
+        W.check(launch_to_out(x.p, h->to_out_w, io.out, h->bf16, B, c.out_channels, x.L, c.num_filters, c.window_length, c.stride, pad,
+                              io.mode, io.x_noisy, io.coef, io.coef_bstride, s));
+    return W.bad ? 1 : 0;
+}
+
+}  // namespace adf_api

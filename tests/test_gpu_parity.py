@@ -446,6 +446,28 @@ def test_config2_batch8_every_layer_large_tile_routes(dtype, tol):
     assert not bad, bad
 
 
+def test_resblock_dma_kernel_route_matches_the_pipelined_route(tmp_path):
+    """adf_gemm_rb.h (the resblock conv kernel of the long levels: ADF_GEMM_RB=2 takes it at batch 8 too) against the route it
+    replaced (ADF_GEMM_RB=0: adf_gemm_pp.h / weight-stationary kernels) on the same bf16 network and inputs: same K order per tile,
+    so the first resblocks agree to accumulation noise."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "2"):
+        path = str(tmp_path / f"rb{mode}.pt")
+        env = dict(os.environ, ADF_GEMM_RB=mode, B="8")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_pp_check.py"), "save", path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(path)
+    a, b = outs["2"], outs["0"]
+    assert all(bool(torch.isfinite(v).all()) for v in a.values())
+    rel = lambda k: float((a[k] - b[k]).norm() / b[k].norm())
+    assert rel("down0.block0") < 1e-3, rel("down0.block0")
+    assert rel("down1.block1") < 1e-2, rel("down1.block1")
+    assert rel("out") < 3e-2, rel("out")
+
+
 @pytest.mark.parametrize("batch,pp", [(8, "2"), (24, "1")])
 def test_pipelined_dma_gemm_route_matches_plain_routes(tmp_path, batch, pp):
     """The persistent LDS-DMA GEMM kernel (adf_gemm_pp.h) against the other routes (ADF_GEMM_PP=0) on the same bf16
