@@ -222,6 +222,9 @@ __global__ void __launch_bounds__(512) conv_gemm_pp_kernel(const GemmArgs a, int
     // ---- DMA of one weight slab (tap slab at wsrc) into W stage st: 2 pieces per wave ---------------------
     const unsigned wlane = (unsigned)srow * (unsigned)kRowBytes + (unsigned)chunk * 16u;
     auto issue_w = [&](const char* wsrc, int st) __attribute__((always_inline)) {
+#ifdef ADF_PP_KNOCK_W
+        return;               // timing knock-out of a diagnostic build (results wrong by construction): no weight-slab DMA
+#endif
         const unsigned ldsW = (unsigned)(kPpOffW + st * kPpWStage) + (unsigned)wave * 1024u;
         pp_dma16(wsrc, wlane, ldsW);
         pp_dma16(wsrc + 64 * kRowBytes, wlane, ldsW + 8192u);

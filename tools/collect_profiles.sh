@@ -2,13 +2,13 @@
 # Runs ON the GPU box (gpurun): produces the small summaries that get committed under profiles/ (named per round).
 # usage: tools/collect_profiles.sh r01      -> gpurun_out/profiles_r01/*
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 echo "[1/9] bench.py"; timeout -k 10 400 python bench.py --steps 2 --warmup 1 2>/dev/null | tail -1 > $out/${tag}_bench.json || exit 1
 echo "[2/9] kernel trace of bench.py"; rm -rf /tmp/p1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-check --no-pmc > /tmp/p1.log 2>&1 || { tail -5 /tmp/p1.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-check --no-pmc --no-other-workloads > /tmp/p1.log 2>&1 || { tail -5 /tmp/p1.log; exit 1; }
 cp $(ls /tmp/p1/*/*kernel_stats.csv | head -1) $out/${tag}_bench_kernel_stats.csv
 python3 tools/trace_summary.py $(ls /tmp/p1/*/*kernel_trace.csv | head -1) 198 --grid | sed "s#/tmp/p1/[^ ]*#rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-precision-check --no-pmc#" > $out/${tag}_bench_per_nfe_summary.txt
 echo "[3/9] kernel trace of the resblock replay"; rm -rf /tmp/p2
@@ -23,7 +23,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --kernel-include-regex "conv_gemm" --
   echo "# per kernel variant and grid: mean of the last 3 dispatches, KB as reported (gfx950: double FETCH_SIZE for 16 B/lane streaming reads)"
   PMC_MIN_GRID=1 PMC_PAIRS=1 python3 tools/pmc_summary.py /tmp/p3 /tmp/p4; } > $out/${tag}_pmc_fetch_write_summary.txt
 echo "[6/9] per-launch layer table (route lines matched with the kernel trace)"; rm -rf /tmp/lt
-ADF_GEMM_TRACE=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -- python3 bench.py --steps 1 --warmup 0 --num-steps 2 --no-graph --no-cpu-baseline --no-pmc --no-precision-check > /tmp/lt.log 2> /tmp/lt.err || { tail -5 /tmp/lt.err; exit 1; }
+ADF_GEMM_TRACE=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -- python3 bench.py --steps 1 --warmup 0 --num-steps 2 --no-graph --no-cpu-baseline --no-pmc --no-precision-check --no-other-workloads > /tmp/lt.log 2> /tmp/lt.err || { tail -5 /tmp/lt.err; exit 1; }
 { echo "# ADF_GEMM_TRACE=1 rocprofv3 --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --num-steps 2 --no-graph (C2, B = 64, L = 16384, bf16)"
   python3 tools/layer_table.py /tmp/lt /tmp/lt.err; } > $out/${tag}_layer_table.txt || exit 1
 echo "[7/9] SQ counters of the rb kernel (resblock replay)"
@@ -68,4 +68,10 @@ cp $(ls /tmp/p6/*/*kernel_stats.csv | head -1) $out/${tag}_bench_c4_kernel_stats
 rm -rf /tmp/p7
 ( cd /tmp && ADF_C2_TRACE=1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/p7 -- python3 $OLDPWD/tools/adm_pass.py 64 2> /tmp/p7.err > /dev/null ) || { tail -5 /tmp/p7.err; exit 1; }
 python3 tools/adm_layer_table.py /tmp/p7 /tmp/p7.err > $out/${tag}_adm_layer_table.txt
+echo "[12] whole-launch timelines of the resblock conv kernel (diagnostic build) and the SIMD issue microbenchmark"
+if [ -f audiodiffuser_amd/build/variants/libadf_hip_rbtl.so ]; then
+  ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbtl.so timeout -k 10 200 python tools/rb_timeline.py 28 1 2>&1 | grep -v amdgpu.ids > $out/${tag}_rb_launch_timeline.txt
+  ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbtl.so timeout -k 10 200 python tools/rb_timeline.py 4 1 2>&1 | grep -v amdgpu.ids > $out/${tag}_rb_launch_timeline_n256.txt
+fi
+if [ -x tools/micro/bin/role_split ]; then timeout -k 5 100 tools/micro/bin/role_split > $out/${tag}_role_split_microbench_raw.txt 2>&1; fi
 ls -la $out

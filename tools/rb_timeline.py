@@ -65,14 +65,15 @@ for which in (0, 1):
     ntile = 0
     for t in range(4):
         base = 4 + t * 26
-        if not S[0][base + 3]:
+        if not S[0][base + 3] or (t > 0 and not S[0][base]):
             break
         ntile += 1
         if t > 0:
             out_k += phase(f"tile {t}: epilogue of tile {t - 1} (accumulators -> LDS -> 16-byte stores, statistics)", base, base + 1)
         prev = base + 1 if t > 0 else 3
         nsub = 0
-        while nsub < 12 and S[0][base + 3 + 2 * nsub]:
+        single = t == 0 and not S[0][4 + 26 + 3]           # one tile per block (n = 256 launches at L = 1024): its sub-steps may run past 12
+        while nsub < (50 if single else 12) and base + 3 + 2 * nsub < 108 and S[0][base + 3 + 2 * nsub]:
             nsub += 1
         work = [d(S[w][base + 2 + 2 * (nsub - 1) + 1], S[w][prev]) for w in range(8)]
         in_k += max(work)
