@@ -425,20 +425,27 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     };
 
     // Prologue of block dn (stage sn) as per-gap work in the three sub-steps of the block before it.  Parts 0 / 1 take the even /
-    // odd 8-byte halves of the wave's pieces 0-2 (so each needs the (a, b) of 4 channels only), part 2 piece 3 and the two
-    // halves of the halo chunk (wave 0; the other waves run the same instructions on their own piece 0 and do not store).
+    // odd 8-byte halves of the wave's pieces 0-2 (so each needs the (a, b) of 4 channels only), part 2 piece 3 and the
+    // wave's sixteen elements of the halo chunk (one per lane, see halo_e).
     // A half = 4 elements = one GROUP; a group goes through 8 stages of 4 INDEPENDENT instructions each (unpack, affine,
     // exponent, exp2, 1 + t, rcp, product, pack + store): 32 slots per group, 6 slots per MFMA gap.  Measured with per-wave
     // stamps (tools/rb_stamps.py): one element per gap as a dependent chain (unpack -> fma -> fma -> exp2 | add -> rcp -> mul)
     // ran at ~9 cycles per instruction -- with two waves per SIMD nothing hides the latency of a dependent vector instruction
     // -- and the 16 MFMAs of a sub-step took 1700-2100 cycles; four independent elements per stage issue back to back.
     struct Part {
-        u32x2_t raw[4];
+        u32x2_t raw[3];
         float ta[8], tb[8];
         float x[4], u[4];
         u32x2_t pk;
         float ec, ed;          // exponent = ec * v + ed: (-log2 e, 0) with SiLU, (0, -200) without (see silu4)
+        unsigned hraw;         // the lane's ONE element of the halo chunk (part 2), its (a, b) and its chain
+        float ha, hb, hx, hu;
     };
+    // The halo chunk (rows TM, TM + 1 = 128 elements) is spread over all eight waves: element wave * 16 + (lane & 15), one dependent chain of
+    // eight instructions per wave riding one slot per gap next to the four independent slots of a group.  (Round 2 had wave 0's lanes 0-15 take the
+    // whole chunk as two more GROUPS and every other wave run the same 64 slots on a dummy: a fifth of the prologue's vector instructions, and the
+    // kernel is bound by vector issue -- profiles/r03_rb_launch_timeline.txt.)
+    const unsigned halo_e = (unsigned)wave * 16u + ((unsigned)lane & 15u);
     auto half_of = [](int P, int k) constexpr -> int { return P < 2 ? P + 2 * k : 6 + k; };
     auto part_begin = [&](auto partc, const Blk& dn, unsigned sn, Part& p) __attribute__((always_inline)) {
         constexpr int P = decltype(partc)::value;
@@ -455,24 +462,42 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             p.raw[k] = *(const u32x2_t*)(ldsN + (hh >> 1) * 8192 + (hh & 1) * 8);
         }
         if (P == 2) {
-            // the halo chunk (rows TM, TM + 1: lanes 0-15 of wave 0); every other lane re-reads its own piece 0 and drops the result
-            const bool halo = wave == 0 && dn.taps == 3 && lane < 16;
-            const u32x4_t q = *(const u32x4_t*)(halo ? smem + sn + HP * 1024 + lane_lds : ldsN);
-            p.raw[2] = u32x2_t{q.x, q.y};
-            p.raw[3] = u32x2_t{q.z, q.w};
+            // (stale bytes when the next block has one tap: computed, never stored)
+            p.hraw = *(const unsigned short*)(smem + sn + HP * 1024 + halo_e * 2u);
+            if (dn.tab >= 0) {                                            // uniform
+                const f32x2_t t = *(const f32x2_t*)(ldsTab + dn.tab + (halo_e & 63u) * 8u);
+                p.ha = t.x; p.hb = t.y;
+            } else { p.ha = dn.scale; p.hb = 0.f; }
         }
     };
     auto part_gap = [&](auto partc, const Blk& dn, unsigned sn, Part& p, int q) __attribute__((always_inline)) {
         constexpr int P = decltype(partc)::value;
-        constexpr int NG = P < 2 ? 3 : 4;             // groups of the part
-        constexpr int OPG = (P < 2 ? 6 : 8) / NH;     // slots per gap: 16 NH gaps x OPG = NG x 32   (q = 0 .. 16 NH - 1)
+        constexpr int NG = P < 2 ? 3 : 2;             // groups of the part
+        constexpr int OPG = (P < 2 ? 6 : 4) / NH;     // slots per gap: 16 NH gaps x OPG = NG x 32   (q = 0 .. 16 NH - 1)
         char* const ldsN = smem + sn + wave * 1024 + lane_lds;
+        if (P == 2 && q % NH == 0 && q / NH < 8) {    // the halo element's chain: stage q / NH
+            switch (q / NH) {
+                case 0: p.hx = __uint_as_float(p.hraw << 16); break;
+                case 1: p.hx = fmaf(p.hx, p.ha, p.hb); break;
+                case 2: p.hu = fmaf(p.hx, p.ec, p.ed); break;
+                case 3: p.hu = __builtin_amdgcn_exp2f(p.hu); break;
+                case 4: p.hu = p.hu + 1.0f; break;
+                case 5: p.hu = __builtin_amdgcn_rcpf(p.hu); break;
+                case 6: p.hx = p.hx * p.hu; break;
+                default:
+                    // row TM + 1 past the end of the sample is zeroed by wave 0 (zero_fill): its owners (waves 4-7) leave it alone
+                    if (dn.taps == 3 && !((dn.edge & 2) && wave >= 4)) {                      // uniform
+                        if (lane < 16) *(unsigned short*)(smem + sn + HP * 1024 + halo_e * 2u) = (unsigned short)pack_bf16x2(p.hx, p.hx);
+                    }
+                    break;
+            }
+        }
 #pragma unroll
         for (int n = q * OPG; n < (q + 1) * OPG; ++n) {
             const int k = n >> 5, st = (n >> 2) & 7, j = n & 3;
             if (k >= NG) continue;
             // channel of element j of group k inside the lane's 8-channel chunk
-            const int hh = (P == 2 && k >= 2) ? k - 2 : half_of(P, k);
+            const int hh = half_of(P, k);
             const int ch = (hh & 1) * 4 + j;
             switch (st) {
                 case 0: {
@@ -489,19 +514,14 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                 default:
                     if (j == 0) p.pk.x = pack_bf16x2(p.x[0], p.x[1]);
                     else if (j == 1) p.pk.y = pack_bf16x2(p.x[2], p.x[3]);
-                    else if (j == 2) {
-                        if (P == 2 && k >= 2) {
-                            if (wave == 0 && dn.taps == 3 && lane < 16) *(u32x2_t*)(smem + sn + HP * 1024 + lane_lds + (k - 2) * 8) = p.pk;
-                        } else {
-                            *(u32x2_t*)(ldsN + (hh >> 1) * 8192 + (hh & 1) * 8) = p.pk;
-                        }
-                    }
+                    else if (j == 2) *(u32x2_t*)(ldsN + (hh >> 1) * 8192 + (hh & 1) * 8) = p.pk;
                     break;
             }
         }
         // keep the slots of this gap in this gap (IR passes move pure arithmetic across sched_barrier)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(p.x[j])); asm volatile("" : "+v"(p.u[j])); }
+        if (P == 2) { asm volatile("" : "+v"(p.hx)); asm volatile("" : "+v"(p.hu)); }
     };
     // what does not ride in the gaps: the zero padding of an edge tile, after the MFMAs of part 2
     auto part_end = [&](const Blk& dn, unsigned sn) __attribute__((always_inline)) { zero_fill(dn, sn); };

@@ -8,7 +8,8 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/audiodiffuser_amd/build/variants; mkdir -p $out/$name
 objs=""
 for f in adf_api adf_net_unet1d adf_net_wavenet adf_net_adm adf_sampler adf_bench_replay adf_gemm adf_kernels adf_wavenet adf_conv2d; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $root/audiodiffuser_amd/csrc/$f.hip -o $out/$name/$f.o &
+  extra=""; [ $f = adf_gemm ] && [ -z "$ADF_VARIANT_SLP" ] && extra="-fno-slp-vectorize"      # as audiodiffuser_amd/build.py EXTRA_FLAGS
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $extra "$@" -c $root/audiodiffuser_amd/csrc/$f.hip -o $out/$name/$f.o &
   objs="$objs $out/$name/$f.o"
 done
 wait
