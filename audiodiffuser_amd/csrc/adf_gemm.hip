@@ -145,9 +145,9 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     *err = nullptr;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const GemmSeg& g0 = a.seg[0];
-    if (a.scatter_f || a.gelu || a.flat || a.mrows % 256 || a.lin != a.mrows || a.out_rows != a.mrows) return false;
+    if (a.scatter_f || a.gelu || a.flat || a.mrows % 128 || a.lin != a.mrows || a.out_rows != a.mrows) return false;
     if (a.n != a.n_pad || a.out_c != a.n || (a.n != 128 && a.n != 256) || a.bias_mod != a.n) return false;
-    if (!pow2(a.mrows / 256)) return false;
+    if (!pow2(a.mrows / 128)) return false;
     // segment 0: GroupNorm + SiLU with the table derived in the kernel, or raw (the folded down convs)
     const bool raw0 = !g0.gn.gamma && !g0.ab && !g0.act && g0.c1 == 0;
     if (!raw0 && (!g0.gn.gamma || !g0.act)) return false;
@@ -194,14 +194,29 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     (void)ident;
     r.h.nb1 = nb - r.h.nb3;
     r.h.B = a.B; r.h.L = a.mrows;
-    r.h.tm_shift = 0;
-    while ((1 << r.h.tm_shift) < a.mrows / 256) ++r.h.tm_shift;
-    // n = 256: one 256 x 256 tile per 256 rows (the activations are fetched and activated once) when that still gives
-    // every CU a tile, else two 256 x 128 tiles
-    const int nh = (a.n == 256 && (long long)a.B * (a.mrows / 256) >= min_tiles) ? 2 : 1;
+    // Tile shape.  n = 256: one 256 x 256 tile per 256 rows (the activations are fetched and activated once) when that still gives
+    // every CU a tile, else two 256 x 128 tiles; when even those leave CUs idle (L = 256 at batch 64), 128-row tiles.
+    // ADF_RB_M128_NH=2 (A/B): 128 x 256 tiles there -- half as many thread blocks, each activation prepared once.
+    static long long m128_nh = -1;
+    if (m128_nh < 0) m128_nh = adf_tuning("ADF_RB_M128_NH", 1);
+    auto shape = [&](int tm_, int& nh_) -> long long {       // thread-block tiles at tile height tm_ (0: the rows do not divide)
+        if (a.mrows % tm_ || !pow2(a.mrows / tm_)) return 0;
+        const long long tiles_m = (long long)a.B * (a.mrows / tm_);
+        nh_ = (a.n == 256 && tiles_m >= min_tiles) ? 2 : 1;
+        return tiles_m * (a.n / (kPpTN * nh_));
+    };
+    int tm = 256, nh = 1;
+    long long tiles_total = shape(256, nh);
+    bool wide128 = false;
+    if (tiles_total < min_tiles) {
+        tm = 128;
+        tiles_total = shape(128, nh);
+        if (m128_nh == 2 && a.n == 256 && nh == 1 && tiles_total >= min_tiles) { nh = 2; tiles_total /= 2; wide128 = true; }
+    }
+    if (tiles_total > (1 << 22) || tiles_total < (wide128 ? min_tiles / 2 : min_tiles)) return false;     // fewer tiles than CUs even on 128-row tiles: the other routes
     r.h.tiles_n = a.n / (kPpTN * nh);
-    const long long tiles_total = (long long)a.B * (a.mrows / 256) * r.h.tiles_n;
-    if (tiles_total < min_tiles || tiles_total > (1 << 22)) return false;       // fewer tiles than CUs: the 128-row kernel fills the chip better
+    r.h.tm_shift = 0;
+    while ((1 << r.h.tm_shift) < a.mrows / tm) ++r.h.tm_shift;
     r.h.tiles_total = (int)tiles_total;
     r.h.n = a.n;
     r.h.gn = g0.gn;
@@ -217,10 +232,12 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     static int num_cu_dev[kMaxDevices] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_gemm_rb_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) != hipSuccess) {
+        bool ok = true;
+        for (const void* k : {(const void*)conv_gemm_rb_kernel<1, false, 2>, (const void*)conv_gemm_rb_kernel<2, false, 2>, (const void*)conv_gemm_rb_kernel<1, true, 2>,
+                              (const void*)conv_gemm_rb_kernel<2, true, 2>, (const void*)conv_gemm_rb_kernel<1, false, 1>, (const void*)conv_gemm_rb_kernel<2, false, 1>,
+                              (const void*)conv_gemm_rb_kernel<1, true, 1>, (const void*)conv_gemm_rb_kernel<2, true, 1>})
+            ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) == hipSuccess;
+        if (!ok) {
             *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize, rb) failed";
             return true;
         }
@@ -228,10 +245,18 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
         attr_done[dev] = true;
     }
     const long long grid = tiles_total < num_cu_dev[dev] ? tiles_total : num_cu_dev[dev];
-    if (nh == 2 && raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, true>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
-    else if (nh == 2) hipLaunchKernelGGL((conv_gemm_rb_kernel<2, false>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
-    else if (raw0) hipLaunchKernelGGL((conv_gemm_rb_kernel<1, true>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
-    else hipLaunchKernelGGL((conv_gemm_rb_kernel<1, false>), dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kRbLds, stream, r); };
+    if (tm == 256) {
+        if (nh == 2 && raw0) go(conv_gemm_rb_kernel<2, true, 2>);
+        else if (nh == 2) go(conv_gemm_rb_kernel<2, false, 2>);
+        else if (raw0) go(conv_gemm_rb_kernel<1, true, 2>);
+        else go(conv_gemm_rb_kernel<1, false, 2>);
+    } else {
+        if (nh == 2 && raw0) go(conv_gemm_rb_kernel<2, true, 1>);
+        else if (nh == 2) go(conv_gemm_rb_kernel<2, false, 1>);
+        else if (raw0) go(conv_gemm_rb_kernel<1, true, 1>);
+        else go(conv_gemm_rb_kernel<1, false, 1>);
+    }
     if (hipGetLastError() != hipSuccess) *err = "conv_gemm_rb: launch failed";
     return true;
 }

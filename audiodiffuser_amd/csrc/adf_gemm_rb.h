@@ -74,7 +74,7 @@ struct RbBlk {
 struct RbHead {
     int nb3, nb1;             // K blocks of one tile, in order: nb3 three-tap blocks (GroupNorm + SiLU), then nb1 one-tap raw blocks
     int B, L;                 // samples, rows per sample
-    int tm_shift;             // log2(256-row tiles per sample)
+    int tm_shift;             // log2(block tiles (256 or 128 rows) per sample)
     int tiles_n;              // N tiles (1 or 2), N tile index fastest
     int tiles_total;
     int n;                    // output channels (= n_pad = out_c)
@@ -112,10 +112,13 @@ __device__ __forceinline__ void rb_static_for(F&& f) {
 // prologue element and per activation byte -- the vector issue slots and the DMA path are what bound the kernel)
 // RAW: segment 0 has no prologue (the folded strided convs of Downsample1d): its bytes go HBM -> LDS -> MFMA untouched, the gaps
 // stay empty and no table is derived; only the zero padding of the edge tiles is applied.
-template <int NH, bool RAW>
+// MH = 32-row accumulator tiles per wave: 2 -> 256-row block tiles, 1 -> 128-row tiles for the levels whose 256-row tile count leaves CUs idle
+// (L = 256 at batch 64: round 3, these launches ran on adf_gemm_pp.h's 128-row form before -- profiles/r03_pp_launch_timeline_L256.txt).  The
+// LDS layout is the same (a 128-row block uses the first half of a stage, halo piece behind it).
+template <int NH, bool RAW, int MH = 2>
 __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     typedef bf16_t T;
-    constexpr int TM = 256, HP = 32;
+    constexpr int TM = 128 * MH, HP = TM / 8;            // HP: piece index of the halo rows TM, TM + 1 -- they follow row TM - 1 in the stage
     constexpr int TNB = kPpTN * NH;                      // columns of the block tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the argument head and the first three block descriptors: one batch of scalar loads, one wait
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         rb_dma2(d.abase, v0, v + 64u * d.pitch, l, l + 8192u);
     };
     auto issue_a23 = [&](const Blk& d, unsigned st) __attribute__((always_inline)) {
-        if (ADF_RB_KNOCK & 2) return;
+        if ((ADF_RB_KNOCK & 2) || MH == 1) return;
         const unsigned v = (unsigned)(srow + 128) * d.pitch + colbytes;
         const unsigned l = st + (unsigned)wave * 1024u + 16384u;
         rb_dma2(d.abase, v, v + 64u * d.pitch, l, l + 8192u);
@@ -337,7 +340,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             if (d.scale != 1.0f) {                                       // scaled skip channels; else the bytes go to the MFMAs untouched
                 const float sc = d.scale;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2 * MH; ++u) {
                     const u32x4_t q = *(const u32x4_t*)(ldsA + u * 8192);
                     u32x4_t o;
                     o.x = pack_bf16x2(__uint_as_float(q.x << 16) * sc, __uint_as_float(q.x & 0xffff0000u) * sc);
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         float fa[8], fb[8];
         load_ab(d, 0, 8, fa, fb);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2 * MH; ++u) {
             const u32x4_t q = *(const u32x4_t*)(ldsA + u * 8192);
             const u32x2_t lo = silu4(u32x2_t{q.x, q.y}, fa, fb, act), hi = silu4(u32x2_t{q.z, q.w}, fa + 4, fb + 4, act);
             *(u32x4_t*)(ldsA + u * 8192) = u32x4_t{lo.x, lo.y, hi.x, hi.y};
@@ -369,13 +372,13 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     };
 
     // ---- accumulators and fragment addresses ----------------------------------------------------------------------
-    f32x16_t acc[NH][2][2];
+    f32x16_t acc[NH][MH][2];
     // fragment chunk (ks*2 + h) of staged row R sits at byte R*128 + (((ks*2 + h) ^ f) << 4), f = (R >> 1) & 7
     //   = (R*128 + ((h ^ (f & 1)) << 4) + ((f >> 1) << 5)) ^ (ks << 5)
     unsigned abase0[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int row = wm * 64 + r + t, f = (row >> 1) & 7;
+        const int row = wm * 32 * MH + r + t, f = (row >> 1) & 7;
         abase0[t] = (unsigned)(row * kPpRow + ((h ^ (f & 1)) << 4) + ((f >> 1) << 5));
     }
     const int fw = (r >> 1) & 7;
@@ -395,9 +398,9 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         unsigned aadr[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) aadr[ks] = sa_ + (abase0[TAP] ^ (unsigned)(ks << 5));
-        bf16x8_t fa[2][2], fb[2][2];
+        bf16x8_t fa[2][MH], fb[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[0][i] = *(const bf16x8_t*)(smem + aadr[0] + i * 32 * kPpRow);
+        for (int i = 0; i < MH; ++i) fa[0][i] = *(const bf16x8_t*)(smem + aadr[0] + i * 32 * kPpRow);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8_t*)(pw + wadr[0] + j * 32 * kPpRow);
 #pragma unroll
@@ -405,18 +408,18 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < 4) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[nxt][i] = *(const bf16x8_t*)(smem + aadr[ks + 1] + i * 32 * kPpRow);
+                for (int i = 0; i < MH; ++i) fa[nxt][i] = *(const bf16x8_t*)(smem + aadr[ks + 1] + i * 32 * kPpRow);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[nxt][j] = *(const bf16x8_t*)(pw + wadr[ks + 1] + j * 32 * kPpRow);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (!(ADF_RB_KNOCK & 8)) acc[H][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[H][i][j], 0, 0, 0);
                     else { asm volatile("" :: "v"(fa[cur][i]), "v"(fb[cur][j])); }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!(ADF_RB_KNOCK & 1)) work(ks * 4 + i * 2 + j);
+                    if (!(ADF_RB_KNOCK & 1)) work(ks * 2 * MH + i * 2 + j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             mid(ks);
@@ -455,7 +458,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             p.ec = dn.tab >= 0 ? -1.4426950408889634f : 0.0f;
             p.ed = dn.tab >= 0 ? 0.0f : -200.0f;
         } else if (P == 1) load_ab(dn, 4, 4, p.ta + 4, p.tb + 4);
-        constexpr int NOWN = P < 2 ? 3 : 2;
+        constexpr int NOWN = MH == 2 ? (P < 2 ? 3 : 2) : (P < 2 ? 2 : 0);
 #pragma unroll
         for (int k = 0; k < NOWN; ++k) {
             const int hh = half_of(P, k);
@@ -472,8 +475,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     };
     auto part_gap = [&](auto partc, const Blk& dn, unsigned sn, Part& p, int q) __attribute__((always_inline)) {
         constexpr int P = decltype(partc)::value;
-        constexpr int NG = P < 2 ? 3 : 2;             // groups of the part
-        constexpr int OPG = (P < 2 ? 6 : 4) / NH;     // slots per gap: 16 NH gaps x OPG = NG x 32   (q = 0 .. 16 NH - 1)
+        constexpr int NG = MH == 2 ? (P < 2 ? 3 : 2) : (P < 2 ? 2 : 0);      // groups of the part (MH = 1: the four halves of pieces 0-1 in parts 0 / 1)
+        constexpr int OPG = NG * 32 / (8 * MH * NH);  // slots per gap: 8 MH NH gaps x OPG = NG x 32   (q = 0 .. 8 MH NH - 1)
         char* const ldsN = smem + sn + wave * 1024 + lane_lds;
         if (P == 2 && q % NH == 0 && q / NH < 8) {    // the halo element's chain: stage q / NH
             switch (q / NH) {
@@ -539,12 +542,13 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         const bool stats_here = H.stats != nullptr;
         const int gs = stats_here ? H.n / H.stats_groups : 8;
         const int tpg = gs / 8;
-        const int mw0 = g.m0 + wm * 64;
+        const int mw0 = g.m0 + wm * 32 * MH;
         const T* resp = (const T*)H.res;
         const bool has_res = resp != nullptr;                                   // uniform
-        constexpr int P = NH * 8;                                               // passes: (N half, 32-row half, 8-row quarter)
+        constexpr int PH = 4 * MH;                                              // passes per N half
+        constexpr int P = NH * PH;                                              // passes: (N half, 32-row half, 8-row quarter)
         auto res_off = [&](int pass) __attribute__((always_inline)) -> unsigned {
-            const int hf = pass >> 3, q = pass & 7;
+            const int hf = pass / PH, q = pass % PH;
             const int m = mw0 + (q >> 2) * 32 + 8 * (q & 3) + rsub;
             return (unsigned)((g.b0 * H.L + m) * H.n + g.n0 + hf * kPpTN + wn * 64 + cc * 8);
         };
@@ -556,7 +560,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         // accumulators of pass p -> buffer p & 1 (and the next tile's bias into them)
         auto wr = [&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
-            constexpr int hf = p >> 3, i = (p >> 2) & 1, p4 = p & 3;
+            constexpr int hf = p / PH, i = (p >> 2) % MH, p4 = p & 3;
             float* const scw = sc0 + (p & 1) * 512 + (4 * h) * 64 + r;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -610,7 +614,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                 s1v += v2;
                 s2v += v2 * v2;
             }
-            if ((p & 7) == 7) flush_stats(p >> 3);
+            if (p % PH == PH - 1) flush_stats(p / PH);
         };
         Row rows[2];
         wr(std::integral_constant<int, 0>{});
@@ -691,7 +695,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) bias_r[j] = ldsBias[cur_tile.n0 + hf * kPpTN + wn * 64 + j * 32 + r];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MH; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -755,7 +759,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             const std::integral_constant<int, (WP + u) & 1> wstc{};
             const std::integral_constant<int, HF> hfc{};
             if (HF == 0 && !RAW) part_begin(tapc, d1, sa1, part);
-            substep(tapc, wstc, hfc, sa, [&](int q) __attribute__((always_inline)) { if (!RAW) part_gap(tapc, d1, sa1, part, HF * 16 + q); },
+            substep(tapc, wstc, hfc, sa, [&](int q) __attribute__((always_inline)) { if (!RAW) part_gap(tapc, d1, sa1, part, HF * 8 * MH + q); },
                     [&](int ks) __attribute__((always_inline)) {
                         if (ks == 0) {
                             if (u + 1 < U) issue_w(next_slab(u + 1, 3), (WP + u + 1) & 1);
@@ -771,7 +775,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             tl(4 + tseq * 26 + 2 + 2 * tl_sub);
 #endif
             // the next slab has landed; the activation pieces issued in this sub-step (the 2 youngest) may still fly
-            if (u < 2 && has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if ((u == 0 || (MH == 2 && u == 1)) && has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(3 * u + 2);
             if (!RAW && u == 2 && kb == 0 && tseq + 1 < ntiles) {    // first block of a tile: the next tile's sample
@@ -808,7 +812,10 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                     });
             if (u == NH - 1) {
                 // block g+1's activations (issued one block ago) and its first slab have landed; block g+2's may still fly
-                if (has2) { if (wave == 0 && d2.taps == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                if (has2) {
+                    if (MH == 2) { if (wave == 0 && d2.taps == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    else { if (wave == 0 && d2.taps == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (has1) transform_all(d1, sa1);
             } else {

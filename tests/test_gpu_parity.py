@@ -125,6 +125,28 @@ def test_unfused_launches_every_stored_tensor_vs_bf16_oracle():
     assert all(_bf16_tol(k, forced) <= BF16_ATT_TOL for k in forced)          # nothing is left at a multi-stage bound
 
 
+def test_resblock_dma_kernel_on_small_batches_incl_128_row_tiles_every_stored_tensor_vs_bf16_oracle():
+    """adf_gemm_rb.h on every shape it is written for, per launch: ADF_GEMM_RB=2 lets it take the resblock convs at batch 8 too, where
+    the L = 256 level (two 128-row tiles per sample: first-row and last-row zero padding in different tiles, the halo piece behind
+    row 127) runs its 128-row form -- as the bench does at batch 64 -- incl. the raw folded down conv, the identity-residual conv2 and
+    the 1x1-residual K segment.  BASELINE configs[1] net, every stored tensor against the bf16-storage oracle on the device's own inputs.
+    (A route-vs-route comparison alone let a misplaced halo piece through: it only adds to the noise of the levels before it.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADF_GEMM_RB="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_forced_report.py"), "c2", "8", "16384"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    forced = rep["forced"]
+    assert rep["finite"]
+    assert {"down3.conv", "down3.block0.h1", "down3.block1", "up2.block0.h1", "up2.block2"} <= set(forced)
+    bad = {k: (v, _bf16_tol(k, forced)) for k, v in forced.items() if not v < _bf16_tol(k, forced)}
+    assert not bad, bad
+
+
 def test_c3_width_net_vs_reference_golden(golden):
     """The reference's own forward at the 64-channel width / head dim 32 / attentions=[F,F,T,T,T,T] (B = 1, L = 2048)."""
     cfg = A.config_c3()

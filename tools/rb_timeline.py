@@ -14,6 +14,7 @@ from audiodiffuser_amd.weights import generate_weights
 
 rb = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 conv = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+force_single = len(sys.argv) > 4 and sys.argv[4] == "single"      # one tile per thread block with more than 12 sub-steps (the L = 256 launches of adf_gemm_pp.h)
 dev = torch.device("cuda", 0)
 cfg = A.PRESETS["c2"]()
 net = A.UNet1dBase.from_config(cfg, compute_dtype="bf16")
@@ -63,7 +64,7 @@ for which in (0, 1):
     out_k += phase("landed -> first K block activated + barrier", 2, 3)
     in_k = 0
     ntile = 0
-    for t in range(4):
+    for t in range(1 if force_single else 4):
         base = 4 + t * 26
         if not S[0][base + 3] or (t > 0 and not S[0][base]):
             break
@@ -72,7 +73,7 @@ for which in (0, 1):
             out_k += phase(f"tile {t}: epilogue of tile {t - 1} (accumulators -> LDS -> 16-byte stores, statistics)", base, base + 1)
         prev = base + 1 if t > 0 else 3
         nsub = 0
-        single = t == 0 and not S[0][4 + 26 + 3]           # one tile per block (n = 256 launches at L = 1024): its sub-steps may run past 12
+        single = force_single or (t == 0 and not S[0][4 + 26 + 3])           # one tile per block (n = 256 launches at L = 1024): its sub-steps may run past 12
         while nsub < (50 if single else 12) and base + 3 + 2 * nsub < 108 and S[0][base + 3 + 2 * nsub]:
             nsub += 1
         work = [d(S[w][base + 2 + 2 * (nsub - 1) + 1], S[w][prev]) for w in range(8)]
@@ -91,11 +92,12 @@ for which in (0, 1):
     print(f"{'entry after the first wave':40s}" + "".join(f"{d(S[w][0], t0):7d}" for w in range(8)))
     for nm, a, b in (("entry -> DMAs issued + table stored", 0, 1), ("-> landed + barrier", 1, 2), ("-> first block activated", 2, 3)):
         print(f"{nm:40s}" + "".join(f"{d(S[w][b], S[w][a]):7d}" for w in range(8)))
-    base = 4 + 26
-    print(f"{'tile 1: epilogue of tile 0':40s}" + "".join(f"{d(S[w][base + 1], S[w][base]):7d}" for w in range(8)))
-    for u in range(12):
-        prev = base + 1 if u == 0 else base + 3 + 2 * (u - 1)
-        print(f"{'tile 1 sub-step %2d work' % u:40s}" + "".join(f"{d(S[w][base + 2 + 2 * u], S[w][prev]):7d}" for w in range(8)))
+    base = 4 if force_single else 4 + 26
+    if not force_single:
+        print(f"{'tile 1: epilogue of tile 0':40s}" + "".join(f"{d(S[w][base + 1], S[w][base]):7d}" for w in range(8)))
+    for u in range(nsub if force_single else 12):
+        prev = (3 if force_single else base + 1) if u == 0 else base + 3 + 2 * (u - 1)
+        print(f"{'tile %d sub-step %2d work' % (0 if force_single else 1, u):40s}" + "".join(f"{d(S[w][base + 2 + 2 * u], S[w][prev]):7d}" for w in range(8)))
         print(f"{'                   wait + barrier':40s}" + "".join(f"{d(S[w][base + 3 + 2 * u], S[w][base + 2 + 2 * u]):7d}" for w in range(8)))
     if any(S[w][110] for w in range(8)):
         print("fine stamps (role-split kernel): consumers = last epilogue: entry / stores issued / statistics done; producers = tile 1 block 1:")
