@@ -57,6 +57,10 @@ constexpr int kRbMaxBlk = 24;
 #ifndef ADF_RB_KNOCK
 #define ADF_RB_KNOCK 0
 #endif
+// three-stage weight ring: 1 = the 128-row form only (product), 2 = every form, 0 = none (A/B builds)
+#ifndef ADF_RB_W3
+#define ADF_RB_W3 1
+#endif
 
 
 struct RbBlk {
@@ -120,6 +124,12 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     typedef bf16_t T;
     constexpr int TM = 128 * MH, HP = TM / 8;            // HP: piece index of the halo rows TM, TM + 1 -- they follow row TM - 1 in the stage
     constexpr int TNB = kPpTN * NH;                      // columns of the block tile
+    // Weight ring.  256-row tiles: two stages, the slab of sub-step s + 1 fetched during sub-step s, stage = a compile-time parity.
+    // 128-row tiles (W3): THREE stages (the third in the 16 KB this kernel does not use between the ring and the tables), the slab of
+    // sub-step s + 2 fetched during sub-step s: a 128-row sub-step is 8 MFMAs per wave (~500 matrix cycles per SIMD) and a slab takes
+    // 1-1.5 K cycles from L2 -- with one slab in flight the raw K = 3072 launch ran 1.7 K cycles per sub-step with nothing but the wait
+    // in it.  The stage is then a run-time LDS offset (one v_add per K step of fragment reads).
+    constexpr bool W3 = ADF_RB_W3 >= 2 || (ADF_RB_W3 == 1 && MH == 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the argument head and the first three block descriptors: one batch of scalar loads, one wait
     const RbHead H = a.h;
@@ -229,6 +239,11 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     auto issue_w = [&](const char* wsrc, int wst) __attribute__((always_inline)) {
         if (ADF_RB_KNOCK & 4) return;
         const unsigned l = (unsigned)(kPpOffW + wst * kPpWStage) + (unsigned)wave * 1024u;
+        rb_dma2(wsrc, wlane, wlane + 64u * (unsigned)kRowBytes, l, l + 8192u);
+    };
+    auto issue_w_at = [&](const char* wsrc, unsigned wofs) __attribute__((always_inline)) {       // wofs: stage byte offset from kPpOffW
+        if (ADF_RB_KNOCK & 4) return;
+        const unsigned l = (unsigned)kPpOffW + wofs + (unsigned)wave * 1024u;
         rb_dma2(wsrc, wlane, wlane + 64u * (unsigned)kRowBytes, l, l + 8192u);
     };
 
@@ -390,11 +405,12 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     // One sub-step: the 16 MFMAs of tap TAP over the 64 channels of the block in stage `sa_` with the weight slab in stage
     // WST.  `work(q)` (q = 0 .. 15) is emitted after MFMA q: prologue elements of the next block; `mid(ks)` after the four
     // MFMAs of K step ks: the DMA instructions of the step.
+    unsigned ws0 = 0u, ws1 = (unsigned)kPpWStage, ws2 = 2u * (unsigned)kPpWStage;     // W3: stage offsets of sub-steps s, s + 1, s + 2
     auto substep = [&](auto tapc, auto wstc, auto nhc, unsigned sa_, auto work, auto mid) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tapc)::value;
         constexpr int WST = decltype(wstc)::value;
         constexpr int H = decltype(nhc)::value;
-        const char* const pw = smem + WST * kPpWStage;
+        const char* const pw = smem + (W3 ? ws0 : (unsigned)(WST * kPpWStage));
         unsigned aadr[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) aadr[ks] = sa_ + (abase0[TAP] ^ (unsigned)(ks << 5));
@@ -675,6 +691,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     advance();
     issue_a01(dc, 0u); issue_a23(dc, 0u); issue_halo(dc, 0u);
     issue_w(dc.w, 0);
+    if (W3) issue_w(dc.w + (unsigned)(1 / NH) * slab + (unsigned)(1 % NH) * (unsigned)kPpWStage, 1);     // (a tile starts with a 3-tap block: its second sub-step)
     Blk d1 = make_desc_of(e_first[1]);
     advance();
     issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage);
@@ -731,6 +748,34 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     auto next_slab = [&](int u, int taps_) __attribute__((always_inline)) -> const char* {
         return dc.w + (unsigned)(u / NH) * slab + (unsigned)(u % NH) * (unsigned)kPpWStage;
     };
+    // ---- W3: the slab TWO sub-steps ahead, and counted waits ----------------------------------------------------------------------
+    // v = index of that sub-step counted from the first sub-step of the current block (ucur of them), running on into block g+1 and,
+    // behind a one-sub-step block, g+2.  Returns the number of DMA instructions issued (2 or 0).
+    auto slab_of = [&](const Blk& d, int v) __attribute__((always_inline)) -> const char* {
+        return d.w + (unsigned)(v / NH) * slab + (unsigned)(v % NH) * (unsigned)kPpWStage;
+    };
+    auto issue_ahead = [&](int v, int ucur, bool has1, bool has2) __attribute__((always_inline)) -> int {
+        if (v < ucur) { issue_w_at(slab_of(dc, v), ws2); return 2; }
+        v -= ucur;
+        if (!has1) return 0;
+        const int u1 = d1.taps * NH;                               // uniform
+        if (v < u1) { issue_w_at(slab_of(d1, v), ws2); return 2; }
+        if (!has2) return 0;
+        issue_w_at(slab_of(d2, v - u1), ws2);
+        return 2;
+    };
+    // at most n of this wave's DMA instructions -- the youngest -- still in flight (loads return in order: everything older is in LDS)
+    auto wait_n = [&](int n) __attribute__((always_inline)) {
+        if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (n >= 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto w_rotate = [&]() __attribute__((always_inline)) { const unsigned t = ws0; ws0 = ws1; ws1 = ws2; ws2 = t; };
+    int aq_prev = 0;                                   // activation DMAs this wave issued in the previous sub-step (behind its slab)
     // one 3-tap block whose first sub-step reads W stage WP; the prologue of block g+1 (any kind) rides in its gaps
     auto block3 = [&](auto wpc) __attribute__((always_inline)) {
         constexpr int WP = decltype(wpc)::value;
@@ -749,7 +794,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         const bool has1 = remaining > 1, has2 = remaining > 2;
         // after a 1-tap block the activations of block g+1 (issued one sub-step ago) may still be in flight: the prologue
         // parts below read them from the head of this block on
-        if (prev_one) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (prev_one) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); aq_prev = 0; }
         Part part;
         stamp(0);
         rb_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
@@ -759,14 +804,16 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             const std::integral_constant<int, (WP + u) & 1> wstc{};
             const std::integral_constant<int, HF> hfc{};
             if (HF == 0 && !RAW) part_begin(tapc, d1, sa1, part);
+            int wq = 0, aq = 0;                                // W3: DMA instructions of this sub-step: slab / activations
             substep(tapc, wstc, hfc, sa, [&](int q) __attribute__((always_inline)) { if (!RAW) part_gap(tapc, d1, sa1, part, HF * 8 * MH + q); },
                     [&](int ks) __attribute__((always_inline)) {
                         if (ks == 0) {
-                            if (u + 1 < U) issue_w(next_slab(u + 1, 3), (WP + u + 1) & 1);
+                            if (W3) wq = issue_ahead(u + 2, U, has1, has2);
+                            else if (u + 1 < U) issue_w(next_slab(u + 1, 3), (WP + u + 1) & 1);
                             else if (has1) issue_w(d1.w, (WP + u + 1) & 1);
                         } else if (ks == 1 && has2) {
-                            if (u == 0) { issue_halo(d2, sa2); issue_a01(d2, sa2); }
-                            else if (u == 1) issue_a23(d2, sa2);
+                            if (u == 0) { issue_halo(d2, sa2); issue_a01(d2, sa2); aq = (wave == 0 && d2.taps == 3) ? 3 : 2; }
+                            else if (u == 1 && MH == 2) { issue_a23(d2, sa2); aq = 2; }
                         }
                     });
             if (u == U - 1) part_end(d1, sa1);
@@ -775,7 +822,13 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             tl(4 + tseq * 26 + 2 + 2 * tl_sub);
 #endif
             // the next slab has landed; the activation pieces issued in this sub-step (the 2 youngest) may still fly
-            if ((u == 0 || (MH == 2 && u == 1)) && has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (W3) {
+                // in flight behind the next sub-step's slab: the activations that followed it, this sub-step's slab and activations; the block's
+                // last sub-step also ends the flight of block g+2's activations (their prologue starts with the next sub-step)
+                wait_n((u == U - 1 ? 0 : aq_prev) + wq + aq);
+                aq_prev = aq;
+                w_rotate();
+            } else if ((u == 0 || (MH == 2 && u == 1)) && has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(3 * u + 2);
             if (!RAW && u == 2 && kb == 0 && tseq + 1 < ntiles) {    // first block of a tile: the next tile's sample
@@ -801,16 +854,27 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             constexpr int u = decltype(uc)::value;
             const std::integral_constant<int, (WP + u) & 1> wstc{};
             const std::integral_constant<int, u> hfc{};
+            int wq = 0, aq = 0;
             substep(c0, wstc, hfc, sa, [](int) __attribute__((always_inline)) {},
                     [&](int ks) __attribute__((always_inline)) {
                         if (ks == 0) {
-                            if (u + 1 < NH) issue_w(next_slab(u + 1, 1), (WP + u + 1) & 1);
+                            if (W3) wq = issue_ahead(u + 2, NH, has1, has2);
+                            else if (u + 1 < NH) issue_w(next_slab(u + 1, 1), (WP + u + 1) & 1);
                             else if (has1) issue_w(d1.w, (WP + u + 1) & 1);
                         } else if (u == NH - 1 && has2) {
-                            if (ks == 1) issue_a01(d2, sa2); else if (ks == 2) issue_a23(d2, sa2); else issue_halo(d2, sa2);
+                            if (ks == 1) { issue_a01(d2, sa2); aq += 2; }
+                            else if (ks == 2) { issue_a23(d2, sa2); if (MH == 2) aq += 2; }
+                            else { issue_halo(d2, sa2); if (wave == 0 && d2.taps == 3) aq += 1; }
                         }
                     });
-            if (u == NH - 1) {
+            if (W3) {
+                // last sub-step: block g+1's activations (fetched during block g-1, maybe one sub-step ago) are prepared below -- only this
+                // sub-step's own DMAs may still fly; before it: as in a 3-tap block
+                wait_n((u == NH - 1 ? 0 : aq_prev) + wq + aq);
+                aq_prev = aq;
+                w_rotate();
+                if (u == NH - 1 && has1) transform_all(d1, sa1);
+            } else if (u == NH - 1) {
                 // block g+1's activations (issued one block ago) and its first slab have landed; block g+2's may still fly
                 if (has2) {
                     if (MH == 2) { if (wave == 0 && d2.taps == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
