@@ -129,7 +129,12 @@ def roofline(hd, batch, length, dtype, iters, device):
     rows = replay_rows(hd, batch, length, iters, device)
     if not rows:
         return None
-    dom = max(rows, key=lambda r: r["ms"])
+    # The launches of the two biggest blocks (conv1: K = 768 over the concat, 201.5 MB; conv2: K = 640 with the 1x1 residual segment, 268.6 MB) sit
+    # within 2-3 % of each other in time and trade places from run to run: among the launches within 5 % of the longest one the figure is quoted on the
+    # one with the LOWEST bytes / time (the conservative one, and the launch rounds 1-2 reported); the near ties are listed beside it.
+    t_max = max(r["ms"] for r in rows)
+    ties = [r for r in rows if r["ms"] >= 0.95 * t_max]
+    dom = min(ties, key=lambda r: r["bytes"] / r["ms"])
     ai = dom["flops"] / dom["bytes"]
     ridge = MFMA_PEAK_TFLOPS[dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
     gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
@@ -143,8 +148,9 @@ def roofline(hd, batch, length, dtype, iters, device):
     out = {
         "bound": "hbm" if ai < ridge else "mfma",
         "kernel": f"fused resblock implicit-GEMM (resblock {dom['resblock']} conv{dom['kernel']})",
-        "definition": "dominant single launch: SURVEY.md 8(d) algorithmic bytes of that conv / its mean duration, HIP events, "
-                      "in-pass launch form (GroupNorm table + statistics epilogue on), operands rotated over >= 320 MiB",
+        "definition": "dominant single launch (of the launches within 5 % of the longest: the one with the lowest bytes / time): SURVEY.md 8(d) "
+                      "algorithmic bytes of that conv / its mean duration, HIP events, in-pass launch form (GroupNorm table + statistics epilogue on), "
+                      "operands rotated over >= 320 MiB",
         "level": dom["resblock"], "conv": dom["kernel"],
         "ms_per_launch": dom["ms"],
         "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"], "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
@@ -156,6 +162,8 @@ def roofline(hd, batch, length, dtype, iters, device):
                           "hbm_frac": all_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "mfma_TFLOPs": all_flops / (total_ms * 1e-3) / 1e12},
         "traffic": None,
+        "near_ties": [{"resblock": r["resblock"], "conv": r["kernel"], "ms": r["ms"], "algorithmic_bytes": r["bytes"],
+                       "hbm_frac": r["bytes"] / (r["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS} for r in sorted(ties, key=lambda r: -r["ms"])],
     }
     if os.environ.get("ADF_BENCH_VERBOSE"):
         out["rows"] = rows

@@ -72,6 +72,7 @@ echo "[12] whole-launch timelines of the resblock conv kernel (diagnostic build)
 if [ -f audiodiffuser_amd/build/variants/libadf_hip_rbtl.so ]; then
   ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbtl.so timeout -k 10 200 python tools/rb_timeline.py 28 1 2>&1 | grep -v amdgpu.ids > $out/${tag}_rb_launch_timeline.txt
   ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbtl.so timeout -k 10 200 python tools/rb_timeline.py 4 1 2>&1 | grep -v amdgpu.ids > $out/${tag}_rb_launch_timeline_n256.txt
+  ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbtl.so timeout -k 10 200 python tools/rb_timeline.py 20 1 64 single 2>&1 | grep -v amdgpu.ids > $out/${tag}_rb_launch_timeline_L256.txt
 fi
 if [ -x tools/micro/bin/role_split ]; then timeout -k 5 100 tools/micro/bin/role_split > $out/${tag}_role_split_microbench_raw.txt 2>&1; fi
 ls -la $out
