@@ -232,4 +232,14 @@ static inline long long adf_tuning(const char* name, long long dflt) {
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
+// XCD-aware tile order.  Workgroups are handed to the 8 XCDs (each with its own L2) round-robin in linear grid order, so tiles that are neighbours in
+// the grid -- and share halo rows / dilated windows / an activation tile read by two N tiles -- land in eight different L2s.  With this map every XCD
+// works through ONE contiguous range of logical tiles instead: lin = the workgroup's linear id (x fastest), total = workgroups of the grid.
+#ifndef ADF_XCD_ORDER
+#define ADF_XCD_ORDER 1
+#endif
+__device__ __forceinline__ unsigned adf_xcd_tile(unsigned lin, unsigned total) {
+    return (!ADF_XCD_ORDER || total % 8u) ? lin : (lin % 8u) * (total / 8u) + lin / 8u;
+}
+
 }  // namespace adf

@@ -127,8 +127,9 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int HW = a.H * a.W;
-    const long long m0 = (long long)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
+    const unsigned ltile = adf_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);      // (pixel tile, N tile), N tile fastest, XCD order
+    const long long m0 = (long long)(ltile / gridDim.y) * TM;
+    const int n0 = (int)(ltile % gridDim.y) * TN;
     const int Hin = a.mode == 1 ? a.H / 2 : (a.mode == 2 ? a.H * 2 : a.H);
     const int Win = a.mode == 1 ? a.W / 2 : (a.mode == 2 ? a.W * 2 : a.W);
 
@@ -322,11 +323,14 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
-    int bid = blockIdx.x;
+    // logical tile = (spatial tile, N tile) with the N tile fastest, in XCD order: the N tiles of a spatial tile (same halo) and its spatial neighbours
+    // (shared halo rows / columns) run close in time on ONE XCD's L2
+    const unsigned ltile = adf_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    int bid = (int)(ltile / gridDim.y);
     const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
     const int ty0 = (bid % tiles_y) * TH;
     const int b = bid / tiles_y;
-    const int n0 = blockIdx.y * TN;
+    const int n0 = (int)(ltile % gridDim.y) * TN;
     // mode 1 (nearest x2 upsampling fused): the halo keeps its OUTPUT geometry in LDS, each of its pixels is fetched from input pixel (y >> 1, x >> 1)
     // (four halo pixels share a source pixel: the repeats are cache hits), so the taps stay row offsets into the halo
     const int Hin = a.mode == 1 ? a.H >> 1 : a.H, Win = a.mode == 1 ? a.W >> 1 : a.W;

@@ -474,6 +474,8 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_wide_kernel(const bf16_t* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    // (An XCD-contiguous tile order -- adf_xcd_tile, as the conv2d kernels use -- was measured here: 1531 -> 1518 ms per configs[4] step, but the PMC
+    //  traffic of a layer launch went UP, 11.6 -> 12.2 GB; not kept.)
     const int b = blockIdx.y, t0 = blockIdx.x * TM;
     // Global pieces are addressed as a wave-uniform base + a 32-bit per-lane byte offset derived from a freshly pinned thread id
     // in every phase: 64-bit per-lane pointers, which the compiler otherwise computes once for all phases and keeps (or
