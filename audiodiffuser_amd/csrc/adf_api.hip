@@ -205,6 +205,8 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
     hipStream_t s = (hipStream_t)stream;
     if (sl.kind == 0) {
         if (hipMemcpyAsync(sl.dst, dev, (size_t)numel * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "hipMemcpyAsync failed");
+        for (int p = 0; p < (sl.rep ? sl.rep_n : 0); ++p)
+            if (hipMemcpyAsync(sl.rep + (size_t)p * numel, dev, (size_t)numel * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(h, "hipMemcpyAsync failed");
     } else if (sl.kind == 5) {               // qkv bias with the legacy head-major rows -> q | k | v rows
         if (const char* e = launch_permute_qkv_rows(dev, (float*)sl.dst, sl.f, sl.cout / (3 * sl.f), 1, s)) return fail(h, e);
     } else if (sl.kind == 4) {               // qkv weight: permute the rows into a scratch copy, then pack that
@@ -215,6 +217,10 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
         const char* e = launch_pack_weight(dev, sl.dst, h->bf16, sl.kind == 2 ? 1 : (sl.kind == 3 ? 2 : 0), sl.cout, sl.cin, sl.K, sl.f, sl.n_offset,
                                            sl.n_pad, sl.nchunk, s);
         if (e) return fail(h, e);
+        if (sl.kind == 2 && sl.dst3) {
+            e = launch_pack_weight(dev, sl.dst3, h->bf16, 3, sl.cout, sl.cin, sl.K, sl.f, 0, sl.n_pad3, sl.nchunk, s);
+            if (e) return fail(h, e);
+        }
         if (sl.frag) {
             // rows of this tensor: cout (conv / linear) or f * cout phase-major rows (transposed conv)
             e = launch_repack_frag(sl.dst, sl.frag, sl.n_offset, sl.kind == 2 ? sl.f * sl.cout : sl.cout, sl.n_pad, sl.nchunk * sl.taps, s);

@@ -49,12 +49,16 @@ struct TrW {
     ConvW qkv, proj, ff1, ff2;
 };
 struct DownW { ConvW down; std::vector<ResW> blocks; bool attn = false; TrW tr; int factor = 1, cin = 0, cout = 0; };
-struct UpW { std::vector<ResW> blocks; bool attn = false; TrW tr; ConvW up; int factor = 1, cin = 0, cout = 0; };
+// up3: the same transposed conv as a 3-tap stride-1 conv with f * cout output columns (phase-major; [B][f L][cout] IS [B][L][f cout] in memory) -- the shape
+// conv_gemm_rb_kernel<.., RAW> is written for; packed beside `up` when the factor is even and f * cout is 128 or 256 (bf16 mode)
+struct UpW { std::vector<ResW> blocks; bool attn = false; TrW tr; ConvW up; ConvW up3; int factor = 1, cin = 0, cout = 0; };
 
 struct Slot {
     int kind = 0;  // 0 = fp32 copy, 1 = pack conv/linear, 2 = pack transposed conv
     void* dst = nullptr;
     void* frag = nullptr;    // also repacked to ConvW::wfrag after packing
+    void* dst3 = nullptr; int n_pad3 = 0;   // kind 2: also packed in the 3-tap phase form (UpW::up3)
+    float* rep = nullptr; int rep_n = 0;    // kind 0: also copied rep_n times back to back (the bias of that form)
     int64_t numel = 0;
     bool loaded = false;
     int cout = 0, cin = 0, K = 0, f = 0, n_offset = 0, n_pad = 0, nchunk = 0, taps = 0;

@@ -62,6 +62,9 @@ struct GemmArgs {
     void* out;
     int out_rows, out_c;
     int scatter_f, scatter_pad;  // transposed conv: n = phase*out_c + co -> row m*f + phase - pad
+    int phase_c;                 // > 0: a transposed conv in its 3-tap form (n = f * phase_c phase-major columns, out_c = n): the GroupNorm statistics
+                                 // of the output are per group of the phase_c CHANNELS (column n is channel n % phase_c).  Only conv_gemm_rb_kernel
+                                 // takes this form: ask conv_gemm_phase_eligible() before building it
     double* stats;       // optional [B][stats_groups][2] (sum, sumsq) of the produced tensor
     int stats_groups;
 };
@@ -1298,5 +1301,7 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
 
 // host-side launcher (adf_gemm.hip); *stats_fused tells whether the requested statistics were produced
 const char* launch_conv_gemm(const GemmArgs& a, int dtype_bf16, hipStream_t stream, bool* stats_fused = nullptr);
+// would launch_conv_gemm route this phase_c > 0 conv to conv_gemm_rb_kernel (shape, tile count)?  No launch.
+bool conv_gemm_phase_eligible(const GemmArgs& a);
 
 }  // namespace adf

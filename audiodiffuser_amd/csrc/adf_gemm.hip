@@ -141,7 +141,7 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
 
 // Resblock conv kernel (adf_gemm_rb.h): fills the K-block table of one tile and launches one 512-thread block per CU.
 // Returns false (and launches nothing) when the shape is not one the kernel is written for.
-bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hipStream_t stream, const char** err) {
+bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hipStream_t stream, const char** err, bool dry = false) {
     *err = nullptr;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const GemmSeg& g0 = a.seg[0];
@@ -223,11 +223,15 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     r.h.bias0 = a.bias0; r.h.bias1 = a.bias1;
     r.h.out = a.out;
     r.h.stats = nullptr; r.h.stats_groups = 0;
+    if (a.phase_c && (!raw0 || (a.phase_c & (a.phase_c - 1)) || a.phase_c < 64 || a.n % a.phase_c)) return false;
     if (a.stats) {
-        const int gs = a.stats_groups > 0 ? a.out_c / a.stats_groups : 0;
-        if (!(gs > 0 && gs * a.stats_groups == a.out_c && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
+        const int sc = a.phase_c ? a.phase_c : a.out_c;                      // channels the statistics are over
+        const int gs = a.stats_groups > 0 ? sc / a.stats_groups : 0;
+        if (!(gs > 0 && gs * a.stats_groups == sc && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
         r.h.stats = a.stats; r.h.stats_groups = a.stats_groups;
+        r.h.stats_mod = a.phase_c;
     }
+    if (dry) return true;
     static bool attr_done[kMaxDevices] = {};
     static int num_cu_dev[kMaxDevices] = {};
     const int dev = current_device();
@@ -347,9 +351,29 @@ static void trace_route(const char* route, const GemmArgs& a, int tm, int tn) {
             a.flat, tm, tn);
 }
 
+static long long rb_min_tiles() {
+    static int use_rb = -1;
+    if (use_rb < 0) use_rb = adf_route_switch("ADF_GEMM_RB", 1);
+    return use_rb == 0 ? -1 : (use_rb >= 2 ? 32 : 256);        // ADF_GEMM_RB=2: also small batches (tests); 0: the route is off
+}
+bool conv_gemm_phase_eligible(const GemmArgs& a) {
+    const long long mt = rb_min_tiles();
+    if (mt < 0 || !a.phase_c || a.flat) return false;
+    const char* err = nullptr;
+    return try_launch_rb(a, nullptr, mt, nullptr, &err, true);
+}
+
 const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t stream, bool* stats_fused) {
     GemmArgs a = a_in;
     if (stats_fused) *stats_fused = false;
+    if (a.phase_c) {                 // only the resblock conv kernel's raw form knows the phase-major statistics
+        if (!dtype_bf16 || !conv_gemm_phase_eligible(a)) return "conv_gemm: a 3-tap-form transposed conv that conv_gemm_rb_kernel does not take";
+        const char* err = nullptr;
+        (void)try_launch_rb(a, nullptr, rb_min_tiles(), stream, &err);
+        if (stats_fused) *stats_fused = a.stats != nullptr;
+        trace_route("rb", a, 256, 128);
+        return err;
+    }
     if (a.nseg < 1 || a.nseg > 2) return "conv_gemm: nseg must be 1 or 2";
     if (a.n_pad % 32) return "conv_gemm: n_pad must be a multiple of 32";
     const int epc = dtype_bf16 ? 8 : 4;

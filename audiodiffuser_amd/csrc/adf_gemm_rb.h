@@ -87,6 +87,7 @@ struct RbHead {
     void* out;
     const void* res;          // identity residual (same layout as out), added in the epilogue in fp32 before the rounding, or nullptr
     double* stats; int stats_groups;
+    int stats_mod;            // 0, or the channels of one phase of a transposed conv in its 3-tap form: column n is channel n % stats_mod (a power of two >= 64)
 };
 struct RbArgs {
     RbHead h;
@@ -556,7 +557,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         float* const sc0 = (float*)(smem + scr_stage + wave * 4096);          // 2 x [8][64] fp32
         T* out = (T*)H.out;
         const bool stats_here = H.stats != nullptr;
-        const int gs = stats_here ? H.n / H.stats_groups : 8;
+        const int gs = stats_here ? (H.stats_mod ? H.stats_mod : H.n) / H.stats_groups : 8;
         const int tpg = gs / 8;
         const int mw0 = g.m0 + wm * 32 * MH;
         const T* resp = (const T*)H.res;
@@ -601,7 +602,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
         auto flush_stats = [&](int hf) __attribute__((always_inline)) {
             if (stats_here) {
-                const int n = g.n0 + hf * kPpTN + wn * 64 + cc * 8;
+                const int ncol = g.n0 + hf * kPpTN + wn * 64 + cc * 8;
+                const int n = H.stats_mod ? (ncol & (H.stats_mod - 1)) : ncol;          // (several phases add into the same group: atomics)
                 float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
                 for (int o = 1; o < tpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                 for (int o = 8; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }

@@ -1353,6 +1353,12 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
         } else if (ci < cin) {
             if (mode == 0) {
                 v = src[((size_t)nl * cin + ci) * K + tap];
+            } else if (mode == 3) {
+                // ConvTranspose1d(K = 2 f, stride f, padding f / 2) as a 3-tap conv over the input rows, column p * cout + co = output row f j + p:
+                // x[j - 1] carries kernel tap p + 3 f / 2 (p < f / 2), x[j] tap p + f / 2, x[j + 1] tap p - f / 2 (p >= f / 2)
+                const int p = nl / cout, co = nl - p * cout;
+                const int k = tap == 1 ? p + f / 2 : (tap == 0 ? (p < f / 2 ? p + f + f / 2 : -1) : (p >= f / 2 ? p - f / 2 : -1));
+                if (k >= 0) v = src[((size_t)ci * cout + co) * K + k];
             } else {
                 const int p = nl / cout, co = nl - p * cout;
                 v = src[((size_t)ci * cout + co) * K + (p + tap * f)];
@@ -1365,11 +1371,12 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
 
 const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, int cout, int cin, int K, int f,
                                int n_offset, int n_pad, int nchunk, hipStream_t s) {
-    const int taps = mode == 0 ? K : (mode == 2 ? (K - 1) / f + 1 : 2);
-    if (mode == 1 && K != 2 * f) return "pack_weight: transposed conv needs K == 2*factor";
+    const int taps = mode == 0 ? K : (mode == 2 ? (K - 1) / f + 1 : (mode == 3 ? 3 : 2));
+    if ((mode == 1 || mode == 3) && K != 2 * f) return "pack_weight: transposed conv needs K == 2*factor";
+    if (mode == 3 && f % 2) return "pack_weight: the 3-tap form of a transposed conv needs an even factor";
     if (mode == 2 && (f < 1 || (K - 1) % f)) return "pack_weight: folded strided conv needs K == factor*k + 1";
     // only the real rows are written; the destination is zero-initialised at allocation (row / K padding)
-    const int n_rows = mode == 1 ? f * cout : cout;
+    const int n_rows = (mode == 1 || mode == 3) ? f * cout : cout;
     if (n_offset + n_rows > n_pad) return "pack_weight: rows exceed n_pad";
     const int kc = kRowBytesPack / (bf16 ? 2 : 4);
     const long long total = (long long)nchunk * taps * n_rows * kc;

@@ -64,6 +64,21 @@ int build_weights(adf_handle* h) {
             else h->slots[pre + ".upsample.weight"].frag = up.up.wfrag;
         }
         up.up.bias = R.reg_f32(pre + ".upsample.bias", up.cout);
+        if (h->bf16 && up.up.w && f % 2 == 0 && (f * up.cout == 128 || f * up.cout == 256) && up.cin % 128 == 0 && up.cout % 64 == 0) {
+            ConvW& w3 = up.up3;
+            w3.cin = up.cin; w3.K = 2 * f; w3.f = f; w3.taps = 3;
+            w3.n = f * up.cout; w3.n_pad = w3.n; w3.cout = w3.n;
+            w3.nchunk = ceil_div(up.cin, h->kc);
+            w3.w = dalloc(h, ((size_t)w3.nchunk * 3 * w3.n_pad + (size_t)kTapGroup * (w3.n_pad + 128)) * kRowBytes);
+            w3.bias = (float*)dalloc(h, (size_t)w3.n * 4);
+            if (!w3.w || !w3.bias) R.ok = false;
+            else {
+                Slot& sw = h->slots[pre + ".upsample.weight"];
+                sw.dst3 = w3.w; sw.n_pad3 = w3.n_pad;
+                Slot& sb = h->slots[pre + ".upsample.bias"];
+                sb.rep = w3.bias; sb.rep_n = f;
+            }
+        }
     }
     // one concatenated FiLM projection for all resblocks
     h->film_w = (float*)dalloc(h, (size_t)h->film_total * temb * 4);
@@ -146,11 +161,34 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         if (up.attn) x = W.transformer("up" + std::to_string(u) + ".attn", x, up.tr);
         const int f = up.factor;
         Act y = W.new_act(up.cout, x.L * f);
-        GemmArgs g = W.gemm_base(y, x.L, x.L + 1, up.up);
-        g.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, 2, 1, 0, -1, up.up);
-        g.bias_mod = up.cout;
-        g.scatter_f = f; g.scatter_pad = f / 2 + f % 2;
-        W.run_gemm(g, y, u + 1 < n);
+        bool done = false;
+        if (up.up3.w) {
+            // ConvTranspose1d(kernel 2 f, stride f, padding f / 2), f even, as a 3-tap conv over the INPUT rows with f * cout columns: column p * cout + co of
+            // row j is output row f j + p -- the same bytes -- and uses x[j] (tap p + f / 2), x[j - 1] (tap p + 3 f / 2, p < f / 2) or x[j + 1] (tap p - f / 2,
+            // p >= f / 2); the other third of the packed weights is zero.  No scatter, no L + 1-th row: the resblock conv kernel's raw form takes it.
+            Act y3 = y;
+            y3.C = f * up.cout; y3.L = x.L;
+            GemmArgs g3 = W.gemm_base(y3, x.L, x.L, up.up3);
+            g3.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, up.up3);
+            g3.phase_c = up.cout;
+            if (conv_gemm_phase_eligible(g3)) {
+                const bool ask = u + 1 < n && W.can_fuse_stats(up.cout);
+                if (ask) { y.stats = W.alloc_stats(); g3.stats = y.stats; g3.stats_groups = h->cfg.resnet_groups; }
+                if (W.live()) {
+                    bool fused = false;
+                    W.check(launch_conv_gemm(g3, h->bf16, s, &fused));
+                    if (ask && !fused) W.check(launch_gn_stats(y.p, h->bf16, B, y.L, y.C, h->cfg.resnet_groups, y.stats, s));
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            GemmArgs g = W.gemm_base(y, x.L, x.L + 1, up.up);
+            g.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, 2, 1, 0, -1, up.up);
+            g.bias_mod = up.cout;
+            g.scatter_f = f; g.scatter_pad = f / 2 + f % 2;
+            W.run_gemm(g, y, u + 1 < n);
+        }
         W.tap("up" + std::to_string(u) + ".conv", y);
         x = y;
     }
