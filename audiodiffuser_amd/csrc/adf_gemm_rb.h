@@ -57,7 +57,7 @@ constexpr int kRbMaxBlk = 24;
 #ifndef ADF_RB_KNOCK
 #define ADF_RB_KNOCK 0
 #endif
-// three-stage weight ring: 1 = the 128-row form only (product), 2 = every form, 0 = none (A/B builds)
+// three-stage weight ring: 1 = the 128-row forms and the 256-column forms (product), 2 = every form, 3 = the 128-row forms only, 4 = 128-row and 128-column forms, 0 = none (A/B builds)
 #ifndef ADF_RB_W3
 #define ADF_RB_W3 1
 #endif
@@ -125,12 +125,14 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     typedef bf16_t T;
     constexpr int TM = 128 * MH, HP = TM / 8;            // HP: piece index of the halo rows TM, TM + 1 -- they follow row TM - 1 in the stage
     constexpr int TNB = kPpTN * NH;                      // columns of the block tile
-    // Weight ring.  256-row tiles: two stages, the slab of sub-step s + 1 fetched during sub-step s, stage = a compile-time parity.
-    // 128-row tiles (W3): THREE stages (the third in the 16 KB this kernel does not use between the ring and the tables), the slab of
-    // sub-step s + 2 fetched during sub-step s: a 128-row sub-step is 8 MFMAs per wave (~500 matrix cycles per SIMD) and a slab takes
-    // 1-1.5 K cycles from L2 -- with one slab in flight the raw K = 3072 launch ran 1.7 K cycles per sub-step with nothing but the wait
-    // in it.  The stage is then a run-time LDS offset (one v_add per K step of fragment reads).
-    constexpr bool W3 = ADF_RB_W3 >= 2 || (ADF_RB_W3 == 1 && MH == 1);
+    // Weight ring.  256 x 128 tiles: two stages, the slab of sub-step s + 1 fetched during sub-step s, stage = a compile-time parity.
+    // 128-row tiles and 256-column tiles (W3): THREE stages (the third in the 16 KB this kernel does not use between the ring and the tables), the slab of
+    // sub-step s + 2 fetched during sub-step s.  A 128-row sub-step is 8 MFMAs per wave (~500 matrix cycles per SIMD) and a slab takes 1-1.5 K cycles from
+    // L2: with one slab in flight the raw K = 3072 launch ran 1.7 K cycles per sub-step with nothing but the wait in it (50 -> 37 us).  On the 256 x 256 tiles
+    // (a K block = six sub-steps of 1.8 K cycles over ONE staged activation block: half the activation DMAs per slab) it is worth 1.6 % of a step
+    // (234.3 -> 230.5 ms, A/B), on the 256 x 128 tiles nothing (234.3 / 234.9): there the third slab queues in front of the activation pieces.
+    // The stage is then a run-time LDS offset (one v_add per K step of fragment reads).
+    constexpr bool W3 = ADF_RB_W3 == 2 || (ADF_RB_W3 == 1 && (MH == 1 || NH == 2)) || (ADF_RB_W3 == 3 && MH == 1) || (ADF_RB_W3 == 4 && (MH == 1 || NH == 1));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the argument head and the first three block descriptors: one batch of scalar loads, one wait
     const RbHead H = a.h;
