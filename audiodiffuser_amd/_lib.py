@@ -72,7 +72,8 @@ class AdfRunCounters(C.Structure):
                 ("graph_replays", C.c_int64), ("denoise_calls", C.c_int64), ("net_passes", C.c_int64)]
 
 
-ABI_VERSION = 3          # ADF_ABI_VERSION of the header this binding was written against
+FLAG_NEAREST_UPSAMPLE = 2  # ADF_FLAG_NEAREST_UPSAMPLE
+ABI_VERSION = 4          # ADF_ABI_VERSION of the header this binding was written against
 
 EXPORTS = {
     # name: (restype, argtypes)
@@ -155,7 +156,7 @@ def make_config(cfg: UNet1dConfig, dtype: int, flags: int = 0) -> AdfNetConfig:
     c.attention_heads, c.attention_multiplier = cfg.attention_heads, cfg.attention_multiplier
     c.use_skip_scale = 1 if cfg.use_skip_scale else 0
     c.use_attention_bottleneck = 1 if cfg.use_attention_bottleneck else 0
-    c.dtype, c.flags = dtype, flags
+    c.dtype, c.flags = dtype, flags | (FLAG_NEAREST_UPSAMPLE if cfg.use_nearest_upsample else 0)
     c.num_classes = int(cfg.num_classes) if cfg.class_cond else 0
     return c
 

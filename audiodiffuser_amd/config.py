@@ -62,8 +62,8 @@ class UNet1dConfig:
         n = self.num_layers
         if not (len(self.factors) == n and len(self.num_blocks) == n and len(self.attentions) == n):
             raise ValueError("factors / num_blocks / attentions must have len(multipliers)-1 entries")
-        if self.use_nearest_upsample:
-            raise NotImplementedError("use_nearest_upsample=True is outside the hot path (SURVEY.md 8a)")
+        if self.use_nearest_upsample and any(f < 2 for f in self.factors):
+            raise NotImplementedError("use_nearest_upsample=True with a factor of 1 (a plain conv in the reference, unet1d.py:231-234) is not built")
         if self.num_filters != self.channels * self.multipliers[0]:
             raise ValueError("num_filters must equal channels*multipliers[0] (to_in feeds downsamples[0])")
         if self.channels % 2:
@@ -110,7 +110,14 @@ def config_tiny_cc() -> UNet1dConfig:
     return c
 
 
-PRESETS = {"c1": config_c1, "c2": config_c2, "c3": config_c3, "tiny": config_tiny, "tiny_cc": config_tiny_cc}
+def config_tiny_nearest() -> UNet1dConfig:
+    """``config_tiny`` with ``use_nearest_upsample=True`` (reference: unet1d.py:236-246: nearest upsampling, reflection pad, 3-tap conv)."""
+    c = config_tiny()
+    c.use_nearest_upsample = True
+    return c
+
+
+PRESETS = {"c1": config_c1, "c2": config_c2, "c3": config_c3, "tiny": config_tiny, "tiny_cc": config_tiny_cc, "tiny_nearest": config_tiny_nearest}
 
 
 @dataclass

@@ -51,7 +51,7 @@ struct TrW {
 struct DownW { ConvW down; std::vector<ResW> blocks; bool attn = false; TrW tr; int factor = 1, cin = 0, cout = 0; };
 // up3: the same transposed conv as a 3-tap stride-1 conv with f * cout output columns (phase-major; [B][f L][cout] IS [B][L][f cout] in memory) -- the shape
 // conv_gemm_rb_kernel<.., RAW> is written for; packed beside `up` when the factor is even and f * cout is 128 or 256 (bf16 mode)
-struct UpW { std::vector<ResW> blocks; bool attn = false; TrW tr; ConvW up; ConvW up3; int factor = 1, cin = 0, cout = 0; };
+struct UpW { std::vector<ResW> blocks; bool attn = false; TrW tr; ConvW up; ConvW up3; int factor = 1, cin = 0, cout = 0; bool nearest = false; };
 
 struct Slot {
     int kind = 0;  // 0 = fp32 copy, 1 = pack conv/linear, 2 = pack transposed conv

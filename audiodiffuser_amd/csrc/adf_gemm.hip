@@ -407,7 +407,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
     }
     // Tile selection.  Per-sample tiles need (TM-1)*stride + taps staged rows; flat tiles (several whole
     // samples per tile, raw inputs only) need (TM/mrows) * ((mrows-1)*stride + taps).
-    const bool can_flat = raw && !a.scatter_f && (a.mrows & (a.mrows - 1)) == 0;
+    const bool can_flat = raw && !a.scatter_f && a.lin == a.mrows && (a.mrows & (a.mrows - 1)) == 0;
     int tm = 0, flat = 0;
     for (int cand = 128; cand >= 32 && !tm; cand >>= 1) {
         if (can_flat && a.mrows < cand) {

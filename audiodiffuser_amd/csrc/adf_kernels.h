@@ -30,6 +30,9 @@ const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N,
 
 // Input transform Conv1d(in_ch -> nf, k=wl, stride, pad) on the fp32 waveform x[B][in_ch][L], with the
 // EDM c_in scaling fused: out NLC [B][L/stride][nf].  coef may be null (c_in = 1).
+// nn.Upsample(scale_factor = f, mode = "nearest") + nn.ReflectionPad1d(1) of a channels-last [B][L][C] tensor: out [B][f L + 2][C], row i + 1 = x[i / f],
+// row 0 = upsampled row 1, row f L + 1 = upsampled row f L - 2 (unet1d.py:236-239); C a multiple of a 16-byte chunk
+const char* launch_upsample_nearest_pad(const void* x, void* out, int bf16, int B, int L, int C, int f, hipStream_t s);
 const char* launch_to_in(const float* x, const float* w, void* out, int bf16, int B, int in_ch, int L, int nf,
                          int wl, int stride, int pad, const float* coef, int coef_bstride, hipStream_t s);
 

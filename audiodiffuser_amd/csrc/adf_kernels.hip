@@ -1406,4 +1406,27 @@ const char* launch_repack_frag(const void* src, void* dst, int n_offset, int n_r
     return ADF_LAUNCH_CHECK("repack_frag");
 }
 
+__global__ void __launch_bounds__(256) upsample_nearest_pad_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ out, int L, int cpr, int f, long long total) {
+    const int rows = f * L + 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cpr);
+        long long r = i / cpr;
+        const int row = (int)(r % rows);
+        const long long b = r / rows;
+        int ui = row - 1;                                     // row of the upsampled signal; reflection about its first / last sample
+        if (ui < 0) ui = 1;
+        if (ui >= f * L) ui = f * L - 2;
+        out[i] = x[(b * L + ui / f) * cpr + c];
+    }
+}
+const char* launch_upsample_nearest_pad(const void* x, void* out, int bf16, int B, int L, int C, int f, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (C % epc || f < 1 || f * L < 2) return "upsample_nearest_pad: channels must be a multiple of a 16-byte chunk, f * L >= 2";
+    const int cpr = C / epc;
+    const long long total = (long long)B * (f * L + 2) * cpr;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(upsample_nearest_pad_kernel, dim3(grid), dim3(256), 0, s, (const u32x4_t*)x, (u32x4_t*)out, L, cpr, f, total);
+    return ADF_LAUNCH_CHECK("upsample_nearest_pad");
+}
+
 }  // namespace adf

@@ -57,6 +57,11 @@ int build_weights(adf_handle* h) {
         up.attn = c.attentions[i] != 0;
         if (up.attn) R.transformer(pre + ".transformer", up.tr, up.cin, c.attention_multiplier);
         const int f = up.factor;
+        if (c.flags & ADF_FLAG_NEAREST_UPSAMPLE) {          // nn.Sequential(Upsample(nearest), ReflectionPad1d(1), Conv1d(k = 3)): unet1d.py:236-246
+            up.nearest = true;
+            R.conv(pre + ".upsample.2", up.up, up.cout, up.cin, 3, true);
+            continue;
+        }
         R.reg_pack(pre + ".upsample.weight", up.up, up.cout, up.cin, 2 * f, 0, f * up.cout, true, f);
         if (h->bf16 && up.up.w && (up.cin == 128 || up.cin == 256) && (up.cout == 64 || up.cout == 128 || up.cout == 256) && (f == 2 || f == 4)) {
             up.up.wfrag = dalloc(h, (size_t)up.up.nchunk * up.up.taps * up.up.n_pad * kRowBytes);   // fragment-major copy: adf_gemm_up.h
@@ -162,6 +167,16 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         const int f = up.factor;
         Act y = W.new_act(up.cout, x.L * f);
         bool done = false;
+        if (up.nearest) {
+            // the upsampled, reflection-padded rows are written once ([f L + 2][cin]: row i + 1 = x[i / f], rows 0 and f L + 1 the reflected ones), the
+            // 3-tap conv then runs over them without padding (lin = mrows + 2, first tap at the output row)
+            Act u0 = W.new_act(up.cin, x.L * f + 2);
+            if (W.live()) W.check(launch_upsample_nearest_pad(x.p, u0.p, h->bf16, B, x.L, up.cin, f, s));
+            GemmArgs g = W.gemm_base(y, x.L * f + 2, x.L * f, up.up);
+            g.seg[0] = Walker::seg_of(u0, nullptr, nullptr, 1.f, 0, 3, 1, 0, 1, up.up);
+            W.run_gemm(g, y, u + 1 < n);
+            done = true;
+        }
         if (up.up3.w) {
             // ConvTranspose1d(kernel 2 f, stride f, padding f / 2), f even, as a 3-tap conv over the INPUT rows with f * cout columns: column p * cout + co of
             // row j is output row f j + p -- the same bytes -- and uses x[j] (tap p + f / 2), x[j - 1] (tap p + 3 f / 2, p < f / 2) or x[j + 1] (tap p - f / 2,

@@ -103,8 +103,12 @@ def param_specs(cfg: UNet1dConfig) -> "OrderedDict[str, Spec]":
             _resblock_specs(s, f"{pre}.blocks.{j}", 2 * cin, cin, temb)
         if cfg.attentions[i]:
             _transformer_specs(s, f"{pre}.transformer", cin, cfg.attention_multiplier)
-        s[f"{pre}.upsample.weight"] = ((cin, cout, 2 * f), "convT_w")
-        s[f"{pre}.upsample.bias"] = ((cout,), "bias")
+        if cfg.use_nearest_upsample:          # nn.Sequential(Upsample, ReflectionPad1d, Conv1d): the conv is module 2 (unet1d.py:236-246)
+            s[f"{pre}.upsample.2.weight"] = ((cout, cin, 3), "conv_w")
+            s[f"{pre}.upsample.2.bias"] = ((cout,), "bias")
+        else:
+            s[f"{pre}.upsample.weight"] = ((cin, cout, 2 * f), "convT_w")
+            s[f"{pre}.upsample.bias"] = ((cout,), "bias")
     return s
 
 

@@ -43,7 +43,7 @@ extern "C" {
 /* Bumped whenever a struct of this header grows or an entry point's argument list changes; a binding compares it with
  * adf_abi_version() of the library it loaded before the first call (audiodiffuser_amd/_lib.py does; INTEGRATION.md's C example too).
  * 3: adf_sampler_run(n_injected), adf_sampler_desc.reflow, adf_get_counters. */
-#define ADF_ABI_VERSION 3
+#define ADF_ABI_VERSION 4
 int adf_abi_version(void);
 
 #define ADF_MAX_LAYERS 12
@@ -68,6 +68,8 @@ typedef struct adf_net_config {
 } adf_net_config;
 
 #define ADF_FLAG_SEPARATE_GN_STATS 1 /* compute GroupNorm statistics in a separate pass instead of the GEMM epilogue */
+#define ADF_FLAG_NEAREST_UPSAMPLE 2  /* UNet1dBase(use_nearest_upsample=True): Upsample1d = nearest x f -> ReflectionPad1d(1) -> Conv1d(k = 3)
+                                        (unet1d.py:236-246; state-dict keys ...upsample.2.weight / .bias); every factor >= 2 */
 
 #define ADF_SAMPLER_EDM 0       /* EDMSampler: Heun + optional churn      */
 #define ADF_SAMPLER_EDM_ALPHA 1 /* EDMAlphaSampler: generalised RK2        */

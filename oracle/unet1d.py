@@ -191,8 +191,12 @@ def downsample_conv(p: P, pre: str, x: torch.Tensor, factor: int, kmult: int, q:
     return q.r(F.conv1d(x, q.w(p[f"{pre}.weight"]), p[f"{pre}.bias"], stride=factor, padding=factor * (kmult // 2)))
 
 
-def upsample_conv(p: P, pre: str, x: torch.Tensor, factor: int, q: Storage = FP32) -> torch.Tensor:
-    """unet1d.py:248-255: ConvTranspose1d(k = 2f, stride f, pad f//2 + f%2, output_padding f%2)."""
+def upsample_conv(p: P, pre: str, x: torch.Tensor, factor: int, q: Storage = FP32, nearest: bool = False) -> torch.Tensor:
+    """unet1d.py:248-255: ConvTranspose1d(k = 2f, stride f, pad f//2 + f%2, output_padding f%2); with ``nearest`` unet1d.py:236-246:
+    nn.Upsample(scale_factor=f, mode="nearest") -> nn.ReflectionPad1d(1) -> Conv1d(k = 3, padding 0) (the copies round nothing)."""
+    if nearest:
+        u = F.pad(F.interpolate(x, scale_factor=factor, mode="nearest"), (1, 1), mode="reflect")
+        return q.r(F.conv1d(u, q.w(p[f"{pre}.2.weight"]), p[f"{pre}.2.bias"]))
     return q.r(F.conv_transpose1d(x, q.w(p[f"{pre}.weight"]), p[f"{pre}.bias"], stride=factor,
                                   padding=factor // 2 + factor % 2, output_padding=factor % 2))
 
@@ -266,7 +270,7 @@ def unet1d_forward(p: P, cfg: UNet1dConfig, x: torch.Tensor, t: torch.Tensor,
             h = rec(f"up{u}.block{j}", resnet_block(p, f"{pre}.blocks.{j}", hx, temb, g, q, x_raw=hraw, rec_h1=h1rec(f"up{u}.block{j}")))
         if cfg.attentions[i]:
             h = rec(f"up{u}.attn", transformer_block(p, f"{pre}.transformer", h, heads, q, rec=subrec(f"up{u}.attn")))
-        h = rec(f"up{u}.conv", upsample_conv(p, f"{pre}.upsample", h, cfg.factors[i], q))
+        h = rec(f"up{u}.conv", upsample_conv(p, f"{pre}.upsample", h, cfg.factors[i], q, nearest=cfg.use_nearest_upsample))
     # :611-622; the device's bf16 MFMA route (num_filters a multiple of 16, <= 128) rounds the weight as an operand
     w_out = p["unet.to_out.to_out.weight"]
     if q.bf16 and cfg.num_filters % 16 == 0 and cfg.num_filters <= 128:

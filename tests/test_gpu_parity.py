@@ -147,6 +147,27 @@ def test_resblock_dma_kernel_on_small_batches_incl_128_row_tiles_every_stored_te
     assert not bad, bad
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_nearest_upsample_net_vs_reference_golden_and_oracle(dtype):
+    """UNet1dBase(use_nearest_upsample=True) (ADF_FLAG_NEAREST_UPSAMPLE; unet1d.py:236-246): fp32 against the reference's own forward (fixture of
+    oracle/gen_golden_nearest.py) and every tap against the oracle, at the fixture's shape and at one where the levels are long enough
+    for the tiled GEMM routes (L = 4096: 2048 / 512 / 128 rows, ragged against 128-row tiles with the two extra input rows); bf16 per launch
+    against the bf16-storage oracle."""
+    from audiodiffuser_amd.config import config_tiny_nearest
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nearest_golden.npz"))
+    cfg = config_tiny_nearest()
+    x, t = T(g["net_x"]), T(g["net_t"])
+    if dtype == "fp32":
+        net, _ = make_net(cfg, "fp32")
+        assert rel_err(net(x.cuda(), t.cuda()).cpu(), T(g["net_y"])) < FP32_TIGHT
+        for xx, tt in ((x, t), (generate_noise(5, 3, 4096) * 0.7, torch.tensor([-0.9, 0.35, 0.0]))):
+            errs, _, _ = tap_errors(cfg, xx, tt, "fp32", 0)
+            bad = {k: v for k, v in errs.items() if not v < FP32_TIGHT}
+            assert not bad and {"up0.conv", "up1.conv", "up2.conv"} <= set(errs), bad
+    else:
+        _assert_bf16_parity(cfg, generate_noise(5, 3, 4096) * 0.7, torch.tensor([-0.9, 0.35, 0.0]))
+
+
 def test_c3_width_net_vs_reference_golden(golden):
     """The reference's own forward at the 64-channel width / head dim 32 / attentions=[F,F,T,T,T,T] (B = 1, L = 2048)."""
     cfg = A.config_c3()

@@ -356,3 +356,20 @@ def test_singlestep_order_patterns():
     assert S.dpm_singlestep_orders(4, 1) == [1, 1, 1, 1]
     with pytest.raises(ValueError):
         S.dpm_singlestep_orders(4, 4)
+
+
+def test_nearest_upsample_net_vs_reference_golden():
+    """UNet1dBase(use_nearest_upsample=True) (unet1d.py:236-246: nearest x f -> ReflectionPad1d(1) -> Conv1d(k = 3)): the oracle against the
+    reference's own forward and its three upsample outputs (fixture of oracle/gen_golden_nearest.py), and the state-dict layout."""
+    from audiodiffuser_amd.config import config_tiny_nearest
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nearest_golden.npz"))
+    cfg = config_tiny_nearest()
+    w = generate_weights(cfg, seed=0)
+    assert "unet.upsamples.0.upsample.2.weight" in w and "unet.upsamples.0.upsample.weight" not in w
+    assert tuple(w["unet.upsamples.2.upsample.2.weight"].shape) == (16, 32, 3)
+    taps = {}
+    with torch.no_grad():
+        y = O.unet1d_forward(w, cfg, T(g["net_x"]), T(g["net_t"]), taps=taps)
+    assert rel(y, T(g["net_y"])) < 2e-6
+    for u in range(3):
+        assert rel(taps[f"up{u}.conv"].reshape(2, -1)[:, ::7], T(g[f"net_tap_up{u}.conv"])) < 2e-6, u
