@@ -394,6 +394,24 @@ def test_config2_sampler_at_batch64_bf16_is_batch_independent_through_the_whole_
     assert c["graph_replays"] >= 2 and c["graph_captures"] >= 2 and c["sampler_evals"] >= 30, c
 
 
+def test_config2_forward_at_batch96_bf16_is_batch_independent():
+    """A batch between the bench's 64 and 128: the L = 256 level then has 384 tiles of 128 rows for 256 persistent thread blocks -- uneven tile ranges,
+    thread blocks whose second tile belongs to the next sample (GroupNorm table refilled under the three-stage weight ring) -- and the levels above
+    it 1.5 tiles of 256 rows per block.  Samples 5 / 41 / 77 / 95 of the batch against the same inputs run as a batch of 4 (other routes: equal to
+    bf16 rounding noise), every sample finite."""
+    cfg = A.config_c2()
+    net, _ = make_net(cfg, "bf16")
+    x = (generate_noise(300, 96, 16384) * 0.7).cuda()
+    t = torch.linspace(-1.0, 0.5, 96).cuda()
+    y = net(x, t)
+    assert y.shape == x.shape and torch.isfinite(y).all()
+    idx = [5, 41, 77, 95]
+    y4 = net(x[idx].contiguous(), t[idx].contiguous())
+    assert rel_l2(y[idx].cpu(), y4.cpu()) < 2e-2, rel_l2(y[idx].cpu(), y4.cpu())
+    for i in idx:
+        assert rel_l2(y[i:i + 1].cpu(), y4[idx.index(i):idx.index(i) + 1].cpu()) < 3e-2, i
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TIGHT), ("bf16", BF16_TOL)])
 def test_config3_every_layer_short(dtype, tol):
     """64-channel net with attention at N = 256 / 64 / 16 / 4 tokens (head dim 32: the MFMA attention kernel in
