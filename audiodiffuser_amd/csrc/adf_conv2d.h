@@ -25,6 +25,7 @@ struct Conv2dArgs {
     int mode;
     const void* w; int nchunk;
     const float* bias;
+    const float* bias_b; int bias_bstride;   // optional per-SAMPLE addend to the bias: bias_b[b * bias_bstride + co] (ResBlock's additive conditioning, unet2d_oai.py:268-270)
     const void* res;        // optional, same layout / type as out
     void* out;
     double* stats;          // optional [B][stats_groups][2]: (sum, sumsq) of the STORED output (after bias and residual) per GroupNorm group,

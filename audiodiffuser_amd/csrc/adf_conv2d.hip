@@ -269,7 +269,8 @@ __global__ void __launch_bounds__(TM * 4) conv2d_gemm_kernel(const Conv2dArgs a)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lc = wn * 64 + j * 32 + r;
-        const float bias = (a.bias && n0 + lc < a.cout) ? a.bias[n0 + lc] : 0.f;
+        float bias = (a.bias && n0 + lc < a.cout) ? a.bias[n0 + lc] : 0.f;
+        if (a.bias_b && n0 + lc < a.cout) bias += a.bias_b[(size_t)(m0 / HW) * a.bias_bstride + n0 + lc];       // (a tile lies inside one image)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -540,7 +541,8 @@ __global__ void __launch_bounds__(TH / WR * 128) conv2d_tile_kernel(const Conv2d
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lc = wn * 64 + j * 32 + r;
-        const float bias = (a.bias && n0 + lc < a.cout) ? a.bias[n0 + lc] : 0.f;
+        float bias = (a.bias && n0 + lc < a.cout) ? a.bias[n0 + lc] : 0.f;
+        if (a.bias_b && n0 + lc < a.cout) bias += a.bias_b[(size_t)b * a.bias_bstride + n0 + lc];
 #pragma unroll
         for (int i = 0; i < WR; ++i)
 #pragma unroll

@@ -15,7 +15,7 @@ int adm_build_weights(adf_handle* h) {
     auto has_att = [&](int ds) { for (int i = 0; i < c.n_attention_ds; ++i) if (c.attention_ds[i] == ds) return true; return false; };
     auto heads_of = [&](int ch) { return c.num_head_channels == -1 ? c.num_heads : ch / c.num_head_channels; };
     // pass 1: structure
-    auto new_res = [&](int cin, int cout) { AdmRes r; r.cin = cin; r.cout = cout; r.has_skip = cin != cout; r.film_off = h->film_total; h->film_total += 2 * cout;
+    auto new_res = [&](int cin, int cout) { AdmRes r; r.cin = cin; r.cout = cout; r.has_skip = cin != cout; r.film_off = h->film_total; h->film_total += (c.use_scale_shift_norm ? 2 : 1) * cout;
                                             a.res.push_back(r); return AdmLayer{1, (int)a.res.size() - 1}; };
     auto new_attn = [&](int ch) { AdmAttn t; t.c = ch; t.heads = heads_of(ch); a.attn.push_back(t); return AdmLayer{2, (int)a.attn.size() - 1}; };
     int ch = a.input_ch = c.channel_mult[0] * mc;
@@ -95,8 +95,9 @@ int adm_build_weights(adf_handle* h) {
             r.g1w = R.reg_f32(pre + ".in_layers.0.weight", r.cin);
             r.g1b = R.reg_f32(pre + ".in_layers.0.bias", r.cin);
             R.conv(pre + ".in_layers.2", r.c1, r.cout, r.cin, 9, true);
-            R.reg_f32(pre + ".emb_layers.1.weight", (int64_t)2 * r.cout * ted, h->film_w + (size_t)r.film_off * ted);
-            R.reg_f32(pre + ".emb_layers.1.bias", 2 * r.cout, h->film_b + r.film_off);
+            const int ew = (c.use_scale_shift_norm ? 2 : 1) * r.cout;             // Linear(4 mc, 2 cout) or, additive conditioning, Linear(4 mc, cout) (:214-220)
+            R.reg_f32(pre + ".emb_layers.1.weight", (int64_t)ew * ted, h->film_w + (size_t)r.film_off * ted);
+            R.reg_f32(pre + ".emb_layers.1.bias", ew, h->film_b + r.film_off);
             r.g2w = R.reg_f32(pre + ".out_layers.0.weight", r.cout);
             r.g2b = R.reg_f32(pre + ".out_layers.0.bias", r.cout);
             R.conv(pre + ".out_layers.3", r.c2, r.cout, r.cout, 9, true);
@@ -195,7 +196,7 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         return ab;
     };
     // stats: also reduce the (fine) GroupNorm statistics of the output in the epilogue (where a GroupNorm reads this tensor next)
-    auto conv = [&](const T2& x, const ConvW& w, const float* ab, int act, int mode, const void* res, bool stats) -> T2 {
+    auto conv = [&](const T2& x, const ConvW& w, const float* ab, int act, int mode, const void* res, bool stats, const float* bias_b = nullptr) -> T2 {
         T2 y;
         if (stats && w.cout % fg == 0 && (w.cout <= 128 || w.cout % 128 == 0)) y.st = alloc_fine(w.cout);
         y.H = mode == 1 ? x.H * 2 : (mode == 2 ? x.H / 2 : x.H);
@@ -206,6 +207,7 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
             g.x = x.t.p; g.x1 = x.t1.C ? x.t1.p : nullptr; g.c0 = x.t.C;
             g.ab = ab; g.act = act; g.B = B; g.H = y.H; g.W = y.W; g.cin = x.t.C + x.t1.C; g.cout = w.cout; g.n_pad = w.n_pad;
             g.taps = w.taps; g.mode = mode; g.w = w.w; g.nchunk = w.nchunk; g.bias = w.bias; g.res = res; g.out = y.t.p;
+            g.bias_b = bias_b; g.bias_bstride = film_bs;
             g.stats = y.st; g.stats_groups = w.cout / fg;
             W.check(launch_conv2d(g, h->bf16, s));
         }
@@ -223,12 +225,15 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
                 if (W.live()) W.check(launch_conv2d_in(io.x, a.in_w, a.in_b, y.t.p, h->bf16, B, c.in_channels, x.H, x.W, a.input_ch, io.coef, io.coef_bstride, y.st, fg, s));
                 x = y;
                 W.tap(ln, x.t);
-            } else if (l.kind == 1) {                                  // ResBlock._forward, :248-272 (scale-shift form)
+            } else if (l.kind == 1) {                                  // ResBlock._forward, :248-272
                 const AdmRes& r = a.res[l.idx];
                 const float* ab1 = gn_table(x, r.g1w, r.g1b, nullptr);
-                T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr, true);
+                // scale-shift form (:262-267): the embedding enters the out_norm table; additive form (:268-270, h = out_norm(h + emb_out)): it is a
+                // per-sample addend to conv1's bias, so that the stored tensor (and the statistics reduced from it) is h + emb_out
+                const bool ss = c.use_scale_shift_norm != 0;
+                T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr, true, ss ? nullptr : film + r.film_off);
                 W.tap(ln + ".h1", hh.t);
-                const float* ab2 = gn_table(hh, r.g2w, r.g2b, film + r.film_off);
+                const float* ab2 = gn_table(hh, r.g2w, r.g2b, ss ? film + r.film_off : nullptr);
                 const void* skip = x.t.p;
                 if (r.has_skip) { T2 sk2 = conv(x, r.skip, nullptr, 0, 0, nullptr, false); W.tap(ln + ".skip", sk2.t); skip = sk2.t.p; }
                 x = conv(hh, r.c2, ab2, 1, 0, skip, true);

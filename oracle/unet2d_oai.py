@@ -75,13 +75,17 @@ def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: 
     ``rec(suffix, tensor)`` records / forces the stored tensors of the device path (``.h1``, ``.skip``)."""
     pre = l.pre
     rec = rec or (lambda _n, v: v)
-    if q.bf16:                              # the device configuration only (scale-shift norm, no resampling inside the block)
-        assert scale_shift and not (l.up or l.down)
+    if q.bf16:                              # the device configurations only (no resampling inside the block)
+        assert not (l.up or l.down)
         h = q.r(F.silu(group_norm32(p, f"{pre}.in_layers.0", x)))
-        h = rec(".h1", q.r(conv2d(p, f"{pre}.in_layers.2", h, q=q)))
         e = F.linear(F.silu(emb), p[f"{pre}.emb_layers.1.weight"], p[f"{pre}.emb_layers.1.bias"])[:, :, None, None]
-        scale, shift = torch.chunk(e, 2, dim=1)
-        h2 = q.r(F.silu(group_norm32(p, f"{pre}.out_layers.0", h) * (1 + scale) + shift))
+        if scale_shift:
+            h = rec(".h1", q.r(conv2d(p, f"{pre}.in_layers.2", h, q=q)))
+            scale, shift = torch.chunk(e, 2, dim=1)
+            h2 = q.r(F.silu(group_norm32(p, f"{pre}.out_layers.0", h) * (1 + scale) + shift))
+        else:                               # the device stores conv1 + emb_out (one rounding) and normalises that tensor
+            h = rec(".h1", q.r(conv2d(p, f"{pre}.in_layers.2", h, q=q) + e))
+            h2 = q.r(F.silu(group_norm32(p, f"{pre}.out_layers.0", h)))
         skip = rec(".skip", q.r(conv2d(p, f"{pre}.skip_connection", x, q=q))) if l.cin != l.cout else x
         return q.r(q.r(conv2d(p, f"{pre}.out_layers.3", h2, q=q)) + skip)
     h = F.silu(group_norm32(p, f"{pre}.in_layers.0", x))

@@ -48,7 +48,9 @@ def test_plugin_state_dict_contract_and_refusals():
     assert float(sd["out.2.weight"].abs().max()) == 0.0 and float(sd["middle_block.1.proj_out.weight"].abs().max()) == 0.0   # zero_module
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 1, 16, 32), torch.zeros(1))
-    for kw in ({"class_embed_dim": 8}, {"resblock_updown": True}, {"use_scale_shift_norm": False}, {"conv_resample": False}):
+    add = A.UNetModel(use_scale_shift_norm=False, in_channels=1, out_channels=1)        # additive conditioning: Linear(4 mc, cout), not 2 cout
+    assert tuple(add.state_dict()["input_blocks.1.0.emb_layers.1.weight"].shape) == (128, 512)
+    for kw in ({"class_embed_dim": 8}, {"resblock_updown": True}, {"conv_resample": False}):
         with pytest.raises(NotImplementedError):
             A.UNetModel(**kw)
     with pytest.raises(ValueError, match="multiple of 64 channels: input_blocks.1.0"):    # the bf16 routes' constraint is reported at construction
@@ -179,6 +181,44 @@ def test_bf16_every_stored_tensor_vs_bf16_storage_oracle():
         assert e < (BF16_ATT_TOL if k.endswith(".att") else BF16_CONV_TOL), (k, e, worst, errs[worst])
     assert O.rel_l2(y, y_f) < BF16_CONV_TOL, O.rel_l2(y, y_f)         # the last conv from the device's last block output
     assert O.rel_l2(y, y_32) < 5e-2, O.rel_l2(y, y_32)               # free-running bf16 vs the fp32 reference arithmetic: storage precision
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_additive_conditioning_vs_reference_golden_and_oracle(dtype):
+    """UNetModel(use_scale_shift_norm=False) (unet2d_oai.py:268-270: h = out_norm(h + emb_out)): on the device the embedding is a per-sample addend to
+    conv1's bias.  fp32 against the reference's own outputs (fixture of oracle/gen_golden_adm_add.py: network output and the nine block outputs);
+    bf16 teacher-forced per stored tensor against the bf16-storage oracle (64-channel widths for the bf16 conv routes)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "adm_add_golden.npz"))
+    if dtype == "fp32":
+        cfg = O.ADMConfig(**{**O.config_c4_small().to_kwargs(), "use_scale_shift_norm": False})
+        net, w = make(cfg)
+        net = net.cuda()
+        x, t = T(g["x"]), T(g["t"])
+        y = net(x.cuda(), t.cuda()).cpu()
+        assert rel(y, T(g["y"])) < FP32_TIGHT
+        hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+        names = [k[4:] for k in g.files if k.startswith("tap_")]
+        assert len(names) == 9
+        for k in names:
+            got = hd.tap(k, 2, torch.device("cuda")).cpu()
+            assert rel(got.reshape(2, -1)[:, ::16], T(g[f"tap_{k}"])) < FP32_TIGHT, k
+        return
+    cfg = O.ADMConfig(**{**O.config_c4_small().to_kwargs(), "use_scale_shift_norm": False, "model_channels": 64})
+    net, w = make(cfg, "bf16", seed=5)
+    gen = torch.Generator().manual_seed(21)
+    x, t = torch.randn(2, cfg.in_channels, 16, 32, generator=gen), torch.tensor([-0.9, 0.4])
+    net = net.cuda()
+    y = net(x.cuda(), t.cuda()).cpu()
+    hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+    taps = {k: hd.tap(k, 2, torch.device("cuda")).cpu() for k in hd.tap_names()}
+    errs = {}
+    with torch.no_grad():
+        y_f = O.unet2d_forward(w, cfg, x, t, storage="bf16", force=taps, errs=errs)
+    assert set(errs) == set(taps) and any(k.endswith(".h1") for k in errs)
+    for k, e in errs.items():
+        assert e < (BF16_ATT_TOL if k.endswith(".att") else BF16_CONV_TOL), (k, e)
+    assert O.rel_l2(y, y_f) < BF16_CONV_TOL
 
 
 @pytest.mark.gpu

@@ -234,3 +234,19 @@ def test_wavenet_adapter_feeds_the_edm_wrapper():
     assert d.shape == x.shape and float(d.abs().max()) <= 1.0
     c_skip, c_out = 0.25 / (1.5 ** 2 + 0.25), 1.5 * 0.5 * (0.25 + 1.5 ** 2) ** -0.5
     assert rel(d, (c_skip * x + c_out * ref).clamp(-1, 1)) < 1e-5
+
+
+def test_adm_additive_conditioning_alone_vs_reference():
+    """use_scale_shift_norm=False without resblock_updown (the form the device serves too): fixture of oracle/gen_golden_adm_add.py."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "adm_add_golden.npz"))
+    cfg = A.ADMConfig(**{**A.config_c4_small().to_kwargs(), "use_scale_shift_norm": False})
+    w = A.generate_weights(cfg, seed=3)
+    assert tuple(w["input_blocks.1.0.emb_layers.1.weight"].shape) == (32, 128)
+    taps = {}
+    with torch.no_grad():
+        y = A.unet2d_forward(w, cfg, T(g["x"]), T(g["t"]), taps=taps)
+    assert rel(y, T(g["y"])) < TOL
+    names = [k[4:] for k in g.files if k.startswith("tap_")]
+    assert len(names) == 9
+    for k in names:
+        assert rel(sub(taps[k], 16), T(g[f"tap_{k}"])) < TOL, k
