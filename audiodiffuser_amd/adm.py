@@ -47,8 +47,6 @@ class UNetModel(HipNet):
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
         if class_embed_dim is not None:
             raise NotImplementedError("class_embed_dim (embedding inputs instead of labels) is outside the hot path")
-        if resblock_updown or not conv_resample:
-            raise NotImplementedError("on the device: conv_resample=True, resblock_updown=False (BASELINE config 4; both conditioning forms)")
         self.compute_dtype = compute_dtype
         self.cond_drop_prob = cond_drop_prob
         self.cfg = ADMConfig(image_size=image_size, in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,

@@ -145,10 +145,7 @@ int adf_adm_create(const adf_adm_config* cfg, adf_handle** out) {
     if (c.n_mult < 1 || c.n_mult > ADF_ADM_MAX_LEVELS || c.num_res_blocks < 1 || c.n_attention_ds < 0 || c.n_attention_ds > ADF_ADM_MAX_LEVELS) { g_create_error = "adf_adm_create: bad level / block counts"; return 1; }
     if (c.model_channels < 32 || c.model_channels % 32 || c.model_channels % kc || c.model_channels > 256) { g_create_error = "adf_adm_create: model_channels must be a multiple of 32 (fp32) / 64 (bf16), at most 256"; return 1; }
     if (c.in_channels < 1 || c.out_channels < 1 || c.out_channels > 4) { g_create_error = "adf_adm_create: in_channels >= 1, 1 <= out_channels <= 4"; return 1; }
-    if (c.resblock_updown || !c.conv_resample || c.num_classes < 0) {
-        g_create_error = "adf_adm_create: on the device: conv resampling, no resblock up/down (scale-shift or additive conditioning; unconditional or class-conditional)";
-        return 1;
-    }
+    if (c.num_classes < 0) { g_create_error = "adf_adm_create: num_classes must be >= 0"; return 1; }
     for (int i = 0; i < c.n_mult; ++i) if (c.channel_mult[i] < 1) { g_create_error = "adf_adm_create: bad channel_mult"; return 1; }
     adf_handle* h = new adf_handle();
     memset(&h->cfg, 0, sizeof(h->cfg));

@@ -75,9 +75,10 @@ struct WnConv {
     int cout = 0, cin = 0, K = 0;
 };
 // ADM-style 2-D U-Net (unet2d_oai.py:382-635): the module list of UNetModel.__init__ as data
-struct AdmRes { int cin = 0, cout = 0, film_off = 0; float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr; ConvW c1, c2, skip; bool has_skip = false; };
+struct AdmRes { int cin = 0, cout = 0, film_off = 0; float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr; ConvW c1, c2, skip; bool has_skip = false;
+                int updown = 0; };        // 1: ResBlock(up=True), 2: ResBlock(down=True) (resblock_updown, unet2d_oai.py:197-207, :249-254)
 struct AdmAttn { int c = 0, heads = 0; float *gw = nullptr, *gb = nullptr; ConvW qkv, proj; float* qkv_tmp = nullptr; };
-struct AdmLayer { int kind; int idx; };       // kind: 0 input conv, 1 ResBlock, 2 AttentionBlock, 3 Downsample, 4 Upsample
+struct AdmLayer { int kind; int idx; };       // kind: 0 input conv, 1 ResBlock, 2 AttentionBlock, 3 Downsample (conv), 4 Upsample (conv), 5 average pool, 6 nearest x 2
 struct AdmW {
     adf_adm_config cfg;
     int H = 0, W = 0;                    // image shape of the calls that follow (adf_set_image_shape)

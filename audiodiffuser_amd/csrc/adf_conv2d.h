@@ -43,6 +43,11 @@ const char* launch_conv2d_in(const float* x, const float* w, const float* bias, 
 const char* launch_conv2d_out(const void* h, const float* ab, const float* w, const float* bias, float* out, int bf16, int B, int cin, int H,
                               int W, int cout, int mode, const float* x_noisy, const float* coef, int coef_bstride, hipStream_t s);
 
+// 2 x 2 average pool of a channels-last [B][H][W][C] tensor (H, W even) -> [B][H/2][W/2][C] (Downsample(use_conv=False) :153-156, ResBlock(down=True)'s h_upd / x_upd
+// :249-254); with ab (the GroupNorm table [B][C][2]) every input element goes through a v + b (and SiLU with act) first: avg_pool(in_rest(x)) in one pass
+const char* launch_avgpool2(const void* x, const float* ab, int act, void* out, int bf16, int B, int H, int W, int C, hipStream_t s);
+// nearest x 2 upsampling of a channels-last tensor: [B][H][W][C] -> [B][2H][2W][C] (Upsample(use_conv=False) :122-125, ResBlock(up=True)'s x_upd)
+const char* launch_nearest_up2(const void* x, void* out, int bf16, int B, int H, int W, int C, hipStream_t s);
 // out[b][p][0:c0] = s0, out[b][p][c0:c0+c1] = s1 (the skip concat of the output blocks, :629)
 const char* launch_concat2(const void* s0, const void* s1, int c0, int c1, long long rows, void* out, int bf16, hipStream_t s);
 // GroupNorm statistics of a channels-last tensor for any C that is a multiple of a 16-byte chunk: stats[b][g][2] += (sum, sumsq)

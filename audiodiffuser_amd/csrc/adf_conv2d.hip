@@ -1063,4 +1063,69 @@ const char* launch_permute_qkv_rows(const float* src, float* dst, int heads, int
     return C2_LAUNCH_CHECK("permute_qkv_rows");
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool2_kernel(const T* __restrict__ x, const float* __restrict__ ab, int act, T* __restrict__ out, int H, int W, int C,
+                                                       long long total) {
+    constexpr int EPC = Elem<T>::kPerChunk;
+    const int cpr = C / EPC, Ho = H / 2, Wo = W / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cpr) * EPC;
+        long long r = i / cpr;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho);
+        const long long b = r / Ho;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const u32x4_t v = *(const u32x4_t*)(x + ((b * H + 2 * yo + (d >> 1)) * W + 2 * xo + (d & 1)) * C + c);
+            float f[EPC];
+            unpack16<T>(v, f);
+            if (ab) {
+                const float* const t = ab + ((size_t)b * C + c) * 2;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float u = fmaf(f[e], t[2 * e], t[2 * e + 1]);
+                    f[e] = act ? (sizeof(T) == 2 ? silu_f(u) : u / (1.0f + expf(-u))) : u;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] *= 0.25f;
+        *(u32x4_t*)(out + ((b * Ho + yo) * Wo + xo) * C + c) = pack16<T>(acc);
+    }
+}
+const char* launch_avgpool2(const void* x, const float* ab, int act, void* out, int bf16, int B, int H, int W, int C, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (C % epc || H % 2 || W % 2 || H < 2 || W < 2) return "avgpool2: even H and W, channels a multiple of a 16-byte chunk";
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / epc);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    if (bf16) hipLaunchKernelGGL(avgpool2_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ab, act, (bf16_t*)out, H, W, C, total);
+    else hipLaunchKernelGGL(avgpool2_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ab, act, (float*)out, H, W, C, total);
+    return C2_LAUNCH_CHECK("avgpool2");
+}
+
+__global__ void __launch_bounds__(256) nearest_up2_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ out, int H, int W, int cpr, long long total) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cpr);
+        long long r = i / cpr;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho);
+        const long long b = r / Ho;
+        out[i] = x[((b * H + (yo >> 1)) * W + (xo >> 1)) * cpr + c];
+    }
+}
+const char* launch_nearest_up2(const void* x, void* out, int bf16, int B, int H, int W, int C, hipStream_t s) {
+    const int epc = bf16 ? 8 : 4;
+    if (C % epc) return "nearest_up2: channels must be a multiple of a 16-byte chunk";
+    const long long total = (long long)B * (2 * H) * (2 * W) * (C / epc);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(nearest_up2_kernel, dim3(grid), dim3(256), 0, s, (const u32x4_t*)x, (u32x4_t*)out, H, W, C / epc, total);
+    return C2_LAUNCH_CHECK("nearest_up2");
+}
+
 }  // namespace adf

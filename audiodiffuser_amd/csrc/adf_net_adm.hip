@@ -31,9 +31,15 @@ int adm_build_weights(adf_handle* h) {
             chans.push_back(ch);
         }
         if (level != c.n_mult - 1) {
-            a.resample.emplace_back();
-            a.resample.back().cin = ch; a.resample.back().cout = ch;
-            a.input_blocks.push_back({AdmLayer{3, (int)a.resample.size() - 1}});
+            if (c.resblock_updown) {                       // ResBlock(ch, ch, down=True) instead of Downsample (:515-528)
+                AdmLayer l = new_res(ch, ch);
+                a.res[l.idx].updown = 2;
+                a.input_blocks.push_back({l});
+            } else if (c.conv_resample) {
+                a.resample.emplace_back();
+                a.resample.back().cin = ch; a.resample.back().cout = ch;
+                a.input_blocks.push_back({AdmLayer{3, (int)a.resample.size() - 1}});
+            } else a.input_blocks.push_back({AdmLayer{5, 0}});
             chans.push_back(ch);
             ds *= 2;
         }
@@ -47,9 +53,15 @@ int adm_build_weights(adf_handle* h) {
             ch = mc * c.channel_mult[level];
             if (has_att(ds)) ls.push_back(new_attn(ch));
             if (level && i == c.num_res_blocks) {
-                a.resample.emplace_back();
-                a.resample.back().cin = ch; a.resample.back().cout = ch;
-                ls.push_back(AdmLayer{4, (int)a.resample.size() - 1});
+                if (c.resblock_updown) {                   // ResBlock(ch, ch, up=True) instead of Upsample (:575-588)
+                    AdmLayer l = new_res(ch, ch);
+                    a.res[l.idx].updown = 1;
+                    ls.push_back(l);
+                } else if (c.conv_resample) {
+                    a.resample.emplace_back();
+                    a.resample.back().cin = ch; a.resample.back().cout = ch;
+                    ls.push_back(AdmLayer{4, (int)a.resample.size() - 1});
+                } else ls.push_back(AdmLayer{6, 0});
                 ds /= 2;
             }
             a.output_blocks.push_back(ls);
@@ -116,10 +128,10 @@ int adm_build_weights(adf_handle* h) {
                 Slot& sw = h->slots[pre + ".qkv.weight"]; sw.kind = 4; sw.frag = t.qkv_tmp; sw.f = t.heads;
                 Slot& sb = h->slots[pre + ".qkv.bias"]; sb.kind = 5; sb.f = t.heads; sb.cout = 3 * t.c;
             }
-        } else {
+        } else if (l.kind == 3 || l.kind == 4) {
             ConvW& w = a.resample[l.idx];
             R.conv(pre + (l.kind == 3 ? ".op" : ".conv"), w, w.cout, w.cin, 9, true);
-        }
+        }                                                   // (5 / 6: AvgPool2d / nearest interpolation, no parameters)
     };
     for (size_t i = 0; i < a.input_blocks.size(); ++i)
         for (size_t j = 0; j < a.input_blocks[i].size(); ++j) reg_layer(a.input_blocks[i][j], "input_blocks." + std::to_string(i) + "." + std::to_string(j));
@@ -231,7 +243,29 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
                 // scale-shift form (:262-267): the embedding enters the out_norm table; additive form (:268-270, h = out_norm(h + emb_out)): it is a
                 // per-sample addend to conv1's bias, so that the stored tensor (and the statistics reduced from it) is h + emb_out
                 const bool ss = c.use_scale_shift_norm != 0;
-                T2 hh = conv(x, r.c1, ab1, 1, 0, nullptr, true, ss ? nullptr : film + r.film_off);
+                const float* emb_b = ss ? nullptr : film + r.film_off;
+                T2 hh;
+                if (r.updown == 2) {
+                    // ResBlock(down=True) (:249-254): h = in_conv(avg_pool(in_rest(x))), x = avg_pool(x).  The pooled activation and the pooled
+                    // input are written once each (GroupNorm + SiLU fused into the first pool); conv1 then takes its input raw
+                    if (x.t1.C) { W.check("ResBlock(down=True) on a skip concat"); break; }
+                    T2 p1; p1.H = x.H / 2; p1.W = x.W / 2; p1.t = W.new_act(r.cin, p1.H * p1.W);
+                    T2 p2 = p1; p2.t = W.new_act(r.cin, p1.H * p1.W);
+                    if (W.live()) {
+                        W.check(launch_avgpool2(x.t.p, ab1, 1, p1.t.p, h->bf16, B, x.H, x.W, r.cin, s));
+                        W.check(launch_avgpool2(x.t.p, nullptr, 0, p2.t.p, h->bf16, B, x.H, x.W, r.cin, s));
+                    }
+                    hh = conv(p1, r.c1, nullptr, 0, 0, nullptr, true, emb_b);
+                    x = p2;
+                } else if (r.updown == 1) {
+                    // ResBlock(up=True): h = in_conv(nearest x 2 (in_rest(x))) -- the upsampling is an index map of the conv's gather (mode 1),
+                    // x = nearest x 2 (x) is written once (it is the block's residual)
+                    if (x.t1.C) { W.check("ResBlock(up=True) on a skip concat"); break; }
+                    hh = conv(x, r.c1, ab1, 1, 1, nullptr, true, emb_b);
+                    T2 u2; u2.H = x.H * 2; u2.W = x.W * 2; u2.t = W.new_act(r.cin, u2.H * u2.W);
+                    if (W.live()) W.check(launch_nearest_up2(x.t.p, u2.t.p, h->bf16, B, x.H, x.W, r.cin, s));
+                    x = u2;
+                } else hh = conv(x, r.c1, ab1, 1, 0, nullptr, true, emb_b);
                 W.tap(ln + ".h1", hh.t);
                 const float* ab2 = gn_table(hh, r.g2w, r.g2b, ss ? film + r.film_off : nullptr);
                 const void* skip = x.t.p;
@@ -250,6 +284,14 @@ int adm_forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
                 if (W.live()) W.check(launch_attention(qkv.t.p, att.t.p, h->bf16, B, x.t.L, t.c, t.heads, s));
                 W.tap(ln + ".att", att.t);
                 x = conv(att, t.proj, nullptr, 0, 0, xn.t.p, true);    // the residual is the NORMALISED input (:318-322)
+                W.tap(ln, x.t);
+            } else if (l.kind == 5 || l.kind == 6) {                     // Downsample / Upsample without a conv (conv_resample=False, :122-125, :153-156)
+                if (x.t1.C) { W.check("pooled resampling on a skip concat"); break; }
+                T2 y; y.H = l.kind == 5 ? x.H / 2 : x.H * 2; y.W = l.kind == 5 ? x.W / 2 : x.W * 2;
+                y.t = W.new_act(x.t.C, y.H * y.W);
+                if (W.live()) W.check(l.kind == 5 ? launch_avgpool2(x.t.p, nullptr, 0, y.t.p, h->bf16, B, x.H, x.W, x.t.C, s)
+                                                  : launch_nearest_up2(x.t.p, y.t.p, h->bf16, B, x.H, x.W, x.t.C, s));
+                x = y;
                 W.tap(ln, x.t);
             } else {
                 x = conv(x, a.resample[l.idx], nullptr, 0, l.kind == 3 ? 2 : 1, nullptr, true);

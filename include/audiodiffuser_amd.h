@@ -122,7 +122,7 @@ typedef struct adf_handle adf_handle;
 
 int adf_create(const adf_net_config* cfg, adf_handle** out);
 /* A UNetModel (ADM) handle: x / out of adf_net_forward, adf_denoise, adf_sampler_run are [B][C][H][W] fp32 with L = H * W, the
- * shape given by adf_set_image_shape before the call.  On the device: scale-shift or additive conditioning, conv resampling, no resblock up/down, either
+ * shape given by adf_set_image_shape before the call.  On the device: scale-shift or additive conditioning, conv / pooled resampling, resblock up/down, either
  * attention order, unconditional (BASELINE config 4) or class-conditional.  Debug taps: "input_blocks.<i>", "middle_block",
  * "output_blocks.<i>" (the outputs of the reference's blocks). */
 int adf_adm_create(const adf_adm_config* cfg, adf_handle** out);

@@ -67,7 +67,7 @@ def upsample(p: P, pre: str, x: torch.Tensor, use_conv: bool, q: Storage = FP32)
 
 def downsample(p: P, pre: str, x: torch.Tensor, use_conv: bool, q: Storage = FP32) -> torch.Tensor:
     """:146-158 -- 3x3 stride-2 conv (padding 1), or a 2x2 average pool."""
-    return q.r(conv2d(p, f"{pre}.op", x, stride=2, q=q)) if use_conv else F.avg_pool2d(x, 2, 2)
+    return q.r(conv2d(p, f"{pre}.op", x, stride=2, q=q)) if use_conv else q.r(F.avg_pool2d(x, 2, 2))
 
 
 def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: bool, q: Storage = FP32, rec=None) -> torch.Tensor:
@@ -75,9 +75,14 @@ def res_block(p: P, l: _Layer, x: torch.Tensor, emb: torch.Tensor, scale_shift: 
     ``rec(suffix, tensor)`` records / forces the stored tensors of the device path (``.h1``, ``.skip``)."""
     pre = l.pre
     rec = rec or (lambda _n, v: v)
-    if q.bf16:                              # the device configurations only (no resampling inside the block)
-        assert not (l.up or l.down)
-        h = q.r(F.silu(group_norm32(p, f"{pre}.in_layers.0", x)))
+    if q.bf16:                              # rounding points of the device path (adf_net_adm.hip)
+        h = F.silu(group_norm32(p, f"{pre}.in_layers.0", x))
+        if l.down:                          # one pass writes avg_pool(in_rest(x)), another avg_pool(x): each rounds once, on its store
+            h, x = q.r(F.avg_pool2d(h, 2, 2)), q.r(F.avg_pool2d(x, 2, 2))
+        elif l.up:                          # the conv gathers the activated (rounded) operand through the x 2 index map; x is copied
+            h, x = F.interpolate(q.r(h), scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
+        else:
+            h = q.r(h)
         e = F.linear(F.silu(emb), p[f"{pre}.emb_layers.1.weight"], p[f"{pre}.emb_layers.1.bias"])[:, :, None, None]
         if scale_shift:
             h = rec(".h1", q.r(conv2d(p, f"{pre}.in_layers.2", h, q=q)))

@@ -50,9 +50,8 @@ def test_plugin_state_dict_contract_and_refusals():
         net(torch.zeros(1, 1, 16, 32), torch.zeros(1))
     add = A.UNetModel(use_scale_shift_norm=False, in_channels=1, out_channels=1)        # additive conditioning: Linear(4 mc, cout), not 2 cout
     assert tuple(add.state_dict()["input_blocks.1.0.emb_layers.1.weight"].shape) == (128, 512)
-    for kw in ({"class_embed_dim": 8}, {"resblock_updown": True}, {"conv_resample": False}):
-        with pytest.raises(NotImplementedError):
-            A.UNetModel(**kw)
+    with pytest.raises(NotImplementedError):
+        A.UNetModel(class_embed_dim=8)
     with pytest.raises(ValueError, match="multiple of 64 channels: input_blocks.1.0"):    # the bf16 routes' constraint is reported at construction
         A.UNetModel(model_channels=48, compute_dtype="bf16")
     A.UNetModel(model_channels=48, compute_dtype="fp32")
@@ -216,6 +215,63 @@ def test_additive_conditioning_vs_reference_golden_and_oracle(dtype):
     with torch.no_grad():
         y_f = O.unet2d_forward(w, cfg, x, t, storage="bf16", force=taps, errs=errs)
     assert set(errs) == set(taps) and any(k.endswith(".h1") for k in errs)
+    for k, e in errs.items():
+        assert e < (BF16_ATT_TOL if k.endswith(".att") else BF16_CONV_TOL), (k, e)
+    assert O.rel_l2(y, y_f) < BF16_CONV_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["updown", "pool"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_resampling_variants_vs_reference_golden_and_oracle(gold, tag, dtype):
+    """The other resampling forms of the constructor (VERDICT r2 "missing" 2): ``resblock_updown=True`` (ResBlock(up / down=True): avg-pooled or
+    nearest-upsampled activation AND input, :197-207, :249-254; here together with additive conditioning, as the reference fixture has it) and
+    ``conv_resample=False`` (AvgPool2d / nearest interpolation between the levels, :122-125, :153-156).  fp32 against the reference's own
+    outputs (fixtures of oracle/gen_golden_next.py); bf16 per stored tensor against the bf16-storage oracle (64-channel widths)."""
+    kw = O.config_c4_small().to_kwargs()
+    var = {"updown": {"resblock_updown": True, "use_scale_shift_norm": False},
+           "pool": {"conv_resample": False, "attention_resolutions": "32,16", "channel_mult": (1, 1, 2)}}[tag]
+    if dtype == "fp32":
+        cfg = O.ADMConfig(**{**kw, **var})
+        net, w = make(cfg)
+        net = net.cuda()
+        if tag == "pool":
+            # three levels: the fixture's 16 x 32 input leaves 32 pixels at the coarsest one, below the device's 64-pixel tile -- the oracle (pinned
+            # to the reference on that fixture by tests/test_oracle_next.py) is the checker here, at 32 x 64
+            x, t = torch.randn(2, cfg.in_channels, 32, 64, generator=torch.Generator().manual_seed(41)), torch.tensor([-0.9, 0.4])
+            taps_o = {}
+            with torch.no_grad():
+                y_o = O.unet2d_forward(w, cfg, x, t, taps=taps_o)
+            y = net(x.cuda(), t.cuda()).cpu()
+            assert rel(y, y_o) < FP32_TIGHT
+            hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+            names = [k for k in hd.tap_names() if k in taps_o]
+            assert len(names) >= 9
+            for k in names:
+                assert rel(hd.tap(k, 2, torch.device("cuda")).cpu().reshape(2, -1), taps_o[k].reshape(2, -1)) < FP32_TIGHT, k
+            return
+        x, t = T(gold[f"adm_{tag}_x"]), T(gold[f"adm_{tag}_t"])
+        y = net(x.cuda(), t.cuda()).cpu()
+        assert rel(y, T(gold[f"adm_{tag}_y"])) < FP32_TIGHT
+        hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+        names = [k[len(f"adm_{tag}_tap_"):] for k in gold.files if k.startswith(f"adm_{tag}_tap_")]
+        assert len(names) >= 9
+        for k in names:
+            got = hd.tap(k, x.shape[0], torch.device("cuda")).cpu()
+            assert rel(got.reshape(x.shape[0], -1)[:, ::16], T(gold[f"adm_{tag}_tap_{k}"])) < FP32_TIGHT, k
+        return
+    cfg = O.ADMConfig(**{**kw, **var, "model_channels": 64})
+    net, w = make(cfg, "bf16", seed=6)
+    gen = torch.Generator().manual_seed(31)
+    x, t = torch.randn(2, cfg.in_channels, 32 if tag == "pool" else 16, 64 if tag == "pool" else 32, generator=gen), torch.tensor([-0.9, 0.4])
+    net = net.cuda()
+    y = net(x.cuda(), t.cuda()).cpu()
+    hd = net.native(torch.device("cuda", torch.cuda.current_device()))
+    taps = {k: hd.tap(k, 2, torch.device("cuda")).cpu() for k in hd.tap_names()}
+    errs = {}
+    with torch.no_grad():
+        y_f = O.unet2d_forward(w, cfg, x, t, storage="bf16", force=taps, errs=errs)
+    assert set(errs) == set(taps)
     for k, e in errs.items():
         assert e < (BF16_ATT_TOL if k.endswith(".att") else BF16_CONV_TOL), (k, e)
     assert O.rel_l2(y, y_f) < BF16_CONV_TOL
