@@ -116,7 +116,7 @@ int adf_wavenet_create(const adf_wavenet_config* cfg, adf_handle** out) {
     if (c.residual_layers < 1 || c.residual_layers > 1024 || c.dilation_cycle < 1 || c.dilation_cycle > 24) { g_create_error = "adf_wavenet_create: bad residual_layers / dilation_cycle"; return 1; }
     if (c.dim_in < 4 || c.dim_in % 2 || c.dim_in > 1024 || c.dim_mid < 1 || c.dim_mid > 1024 || c.dim_out < 4 || c.dim_out % 4 || c.dim_out > 1024) { g_create_error = "adf_wavenet_create: bad embedding widths"; return 1; }
     if (c.dtype != ADF_DTYPE_F32 && c.dtype != ADF_DTYPE_BF16) { g_create_error = "adf_wavenet_create: bad dtype"; return 1; }
-    if (c.dtype == ADF_DTYPE_BF16 && c.residual_channels != 256) { g_create_error = "adf_wavenet_create: the bf16 (MFMA) kernels are built for residual_channels = 256; use ADF_DTYPE_F32 for other widths"; return 1; }
+    if (c.dtype == ADF_DTYPE_BF16 && c.residual_channels != 256 && c.residual_channels != 128 && c.residual_channels != 64) { g_create_error = "adf_wavenet_create: the bf16 (MFMA) kernels are built for residual_channels = 64, 128 or 256; use ADF_DTYPE_F32 for other widths"; return 1; }
     adf_handle* h = new adf_handle();
     memset(&h->cfg, 0, sizeof(h->cfg));
     // the fields of the U-Net config the shared plan / sampler code reads: one waveform channel in and out, no length

@@ -459,14 +459,14 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
 // replaces tap 0 once every wave has left the first two taps; the gated tile then replaces tap 1; after GEMM 2 both buffers
 // together are the fp32 exchange tile through which the residual and the skip accumulators reach 16-byte global pieces.
 template <int C, int TM>
-__global__ void __launch_bounds__(512) wn_layer_bf16_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ y_next, float* __restrict__ skip,
+__global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ y_next, float* __restrict__ skip,
                                                                  const void* __restrict__ w1, const float* __restrict__ b1,
                                                                  const void* __restrict__ w2, const float* __restrict__ b2,
                                                                  const float* __restrict__ e, int e_bstride, int n, int dil, int first, int Tn) {
     using Tl = WnTile<C, TM>;
     constexpr int PA = Tl::PA, MT = Tl::MT, SPT = Tl::SPT;
-    constexpr int NT = 512;                                // threads
-    static_assert(C == 256 && TM == 128, "8 waves x 32 gate columns; two 128-row buffers");
+    constexpr int NT = 2 * C;                              // threads: C / 32 waves, each 32 gate columns and the 32 matching filter columns
+    static_assert((C == 256 || C == 128 || C == 64) && TM == 128, "a wave per 32 gate columns (2 / 4 / 8 waves); two 128-row buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const bufX = smem;                               // [TM][PA]: tap 0, then tap 2
     char* const bufG = smem + TM * PA;                     // [TM][PA]: tap 1, then the gated activation
@@ -700,7 +700,26 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_wide_kernel(const bf16_t* _
 const char* launch_wn_layer(const WnIO& io, const WnLayerArgs& a, hipStream_t s) {
     if (io.bf16) {
         constexpr int C = 256, TM = 64, TMW = 128;
-        if (io.C != C) return "WaveNet bf16 mode: the MFMA layer kernel is built for residual_channels = 256 (use fp32 for other widths)";
+        if (io.C == 128 || io.C == 64) {                   // other widths: the 128-position kernel with C / 32 waves
+            static bool attr_n[kMaxDevices] = {};
+            bool& an = attr_n[current_device()];
+            if (!an) {
+                if (hipFuncSetAttribute((const void*)wn_layer_bf16_wide_kernel<128, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)wn_layer_bf16_wide_kernel<64, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return "wn_layer: hipFuncSetAttribute failed";
+                an = true;
+            }
+            const dim3 grid(ceil_div(io.T, TMW), io.B);
+            constexpr size_t lds128 = (size_t)2 * TMW * (128 * 2 + 16) + 6 * 128 * 4, lds64 = (size_t)2 * TMW * (64 * 2 + 16) + 6 * 64 * 4;
+            if (io.C == 128)
+                hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<128, TMW>), grid, dim3(256), lds128, s, (const bf16_t*)a.y,
+                                   (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+            else
+                hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<64, TMW>), grid, dim3(128), lds64, s, (const bf16_t*)a.y,
+                                   (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+            return WN_LAUNCH_CHECK("wn_layer_bf16_wide");
+        }
+        if (io.C != C) return "WaveNet bf16 mode: the MFMA layer kernels are built for residual_channels = 64, 128 or 256 (use fp32 for other widths)";
         const size_t lds = (size_t)4 * TM * WnTile<C, TM>::PA + 6 * C * 4;
         static bool attr_done[kMaxDevices] = {};
         bool& attr = attr_done[current_device()];
@@ -785,24 +804,25 @@ __global__ void __launch_bounds__(512) wn_final_f32_kernel(const float* __restri
 }
 
 template <int C, int TM>
-__global__ void __launch_bounds__(512) wn_final_bf16_kernel(const float* __restrict__ skip, float scale, const void* __restrict__ w_sp,
+__global__ void __launch_bounds__(2 * C) wn_final_bf16_kernel(const float* __restrict__ skip, float scale, const void* __restrict__ w_sp,
                                                             const float* __restrict__ b_sp, const float* __restrict__ w_out,
                                                             const float* __restrict__ b_out, float* __restrict__ out, int mode,
                                                             const float* __restrict__ x_noisy, const float* __restrict__ coef,
                                                             int coef_bstride, int Tn) {
     using Tl = WnTile<C, TM>;
     constexpr int PA = Tl::PA, MT = Tl::MT;
-    static_assert(C == 256, "8 waves x 32 columns");
+    static_assert(C == 256 || C == 128 || C == 64, "a wave per 32 columns");
+    constexpr int NT = 2 * C, NW = C / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const bufA = smem;                               // [TM][PA]: bf16(skip * scale)
     float* const prm = (float*)(bufA + TM * PA);           // b_sp (C) | w_out (C)
-    float* const red = prm + 2 * C;                        // [8][TM] per-wave partial dot products
+    float* const red = prm + 2 * C;                        // [NW][TM] per-wave partial dot products
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * TM;
     constexpr int CPR = C / 8;
-    for (int idx = tid; idx < TM * CPR; idx += 512) {
+    for (int idx = tid; idx < TM * CPR; idx += NT) {
         const int i = idx / CPR, cc = idx - i * CPR;
         const bool in = t0 + i < Tn;
         const float* src = skip + ((size_t)b * Tn + (in ? t0 + i : 0)) * C + cc * 8;
@@ -813,7 +833,7 @@ __global__ void __launch_bounds__(512) wn_final_bf16_kernel(const float* __restr
         for (int k = 0; k < 8; ++k) f[k] = in ? f[k] * scale : 0.0f;
         *(u32x4_t*)(bufA + (size_t)i * PA + cc * 16) = pack16<bf16_t>(f);
     }
-    for (int i = tid; i < 2 * C; i += 512) prm[i] = i < C ? b_sp[i] : w_out[i - C];
+    for (int i = tid; i < 2 * C; i += NT) prm[i] = i < C ? b_sp[i] : w_out[i - C];
     __syncthreads();
     const int col = wave * 32 + r;
     const int nb1[1] = {wave * 32};
@@ -822,7 +842,7 @@ __global__ void __launch_bounds__(512) wn_final_bf16_kernel(const float* __restr
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[0][i][q] = 0.f;
-    wn_gemm<C, TM, C, 1, 1>(bufA, w_sp, nb1, acc, r, hh);
+    wn_gemm<C, TM, C, 1, 1, (C >= 128 ? 8 : 4)>(bufA, w_sp, nb1, acc, r, hh);
     const float bs = prm[col], wo = prm[C + col];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -834,10 +854,11 @@ __global__ void __launch_bounds__(512) wn_final_bf16_kernel(const float* __restr
             if (r == 0) red[wave * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh] = v;
         }
     __syncthreads();
+    static_assert(TM <= NT, "one thread per position in the last step");
     if (tid < TM && t0 + tid < Tn) {
         float F = b_out[0];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) F += red[w * TM + tid];
+        for (int w = 0; w < NW; ++w) F += red[w * TM + tid];
         const size_t o = (size_t)b * Tn + t0 + tid;
         out[o] = wn_edm_out(F, mode, x_noisy, coef, coef_bstride, b, o);
     }
@@ -846,7 +867,26 @@ __global__ void __launch_bounds__(512) wn_final_bf16_kernel(const float* __restr
 const char* launch_wn_final(const WnIO& io, const WnFinalArgs& a, hipStream_t s) {
     if (io.bf16) {
         constexpr int C = 256, TM = 64;
-        if (io.C != C) return "WaveNet bf16 mode: built for residual_channels = 256";
+        if (io.C == 128 || io.C == 64) {
+            static bool attr_n[kMaxDevices] = {};
+            bool& an = attr_n[current_device()];
+            if (!an) {
+                if (hipFuncSetAttribute((const void*)wn_final_bf16_kernel<128, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)wn_final_bf16_kernel<64, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return "wn_final: hipFuncSetAttribute failed";
+                an = true;
+            }
+            const dim3 grid(ceil_div(io.T, TM), io.B);
+            constexpr size_t lds128 = (size_t)TM * (128 * 2 + 16) + (2 * 128 + 4 * TM) * 4, lds64 = (size_t)TM * (64 * 2 + 16) + (2 * 64 + 2 * TM) * 4;
+            if (io.C == 128)
+                hipLaunchKernelGGL((wn_final_bf16_kernel<128, TM>), grid, dim3(256), lds128, s, a.skip, a.skip_scale, a.w_sp,
+                                   a.b_sp, a.w_out, a.b_out, a.out, a.mode, a.x_noisy, a.coef, a.coef_bstride, io.T);
+            else
+                hipLaunchKernelGGL((wn_final_bf16_kernel<64, TM>), grid, dim3(128), lds64, s, a.skip, a.skip_scale, a.w_sp,
+                                   a.b_sp, a.w_out, a.b_out, a.out, a.mode, a.x_noisy, a.coef, a.coef_bstride, io.T);
+            return WN_LAUNCH_CHECK("wn_final_bf16");
+        }
+        if (io.C != C) return "WaveNet bf16 mode: built for residual_channels = 64, 128 or 256";
         const size_t lds = (size_t)TM * WnTile<C, TM>::PA + (2 * C + 8 * TM) * 4;
         static bool attr_done[kMaxDevices] = {};
         bool& attr = attr_done[current_device()];

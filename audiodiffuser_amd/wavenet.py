@@ -50,8 +50,8 @@ class WaveNetNoise(HipNet):
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
         if residual_channels % 32 or not 32 <= residual_channels <= 512:
             raise ValueError("residual_channels must be a multiple of 32 in [32, 512]")
-        if _DTYPES[compute_dtype] == _DTYPES["bf16"] and residual_channels != 256:
-            raise ValueError("the bf16 (MFMA) kernels are built for residual_channels=256; use compute_dtype='fp32' otherwise")
+        if _DTYPES[compute_dtype] == _DTYPES["bf16"] and residual_channels not in (64, 128, 256):
+            raise ValueError("the bf16 (MFMA) kernels are built for residual_channels = 64, 128 or 256; use compute_dtype='fp32' otherwise")
         self.compute_dtype = compute_dtype
         self.cfg = WaveNetConfig(residual_channels=residual_channels, residual_layers=residual_layers, dilation_cycle=dilation_cycle)
         specs = wavenet_param_specs(self.cfg)

@@ -103,7 +103,7 @@ typedef struct adf_sampler_desc {
 typedef struct adf_wavenet_config {
     int32_t residual_channels, residual_layers, dilation_cycle;
     int32_t dim_in, dim_mid, dim_out;
-    int32_t dtype;                          /* ADF_DTYPE_*; BF16 (MFMA kernels) needs residual_channels = 256 */
+    int32_t dtype;                          /* ADF_DTYPE_*; BF16 (MFMA kernels) needs residual_channels = 64, 128 or 256 */
 } adf_wavenet_config;
 
 /* Hyper-parameters of the ADM-style UNetModel (unet2d_oai.py:410-430).  attention_ds holds the downsample factors at which
