@@ -126,9 +126,16 @@ def replay_rows(hd, batch, length, iters, device, only_level=-1, only_conv=0):
 def roofline(hd, batch, length, dtype, iters, device):
     """Replay every resblock's two GEMM launches (as the network pass issues them, rotating operand copies) with HIP events
     on the launch stream and report the launch that dominates the pass (largest time)."""
+    # three batches of `iters` launches per layer, per launch the fastest batch mean: single batches of one layer in a loop sometimes run in a slower
+    # power state (the same launch 80 and 94 us in back-to-back bench runs on one box, with the step time unchanged); the in-pass durations of the
+    # rocprofv3 traces under profiles/ agree with the fast figure
     rows = replay_rows(hd, batch, length, iters, device)
     if not rows:
         return None
+    for _ in range(2):
+        again = {(r["resblock"], r["kernel"]): r["ms"] for r in replay_rows(hd, batch, length, iters, device)}
+        for r in rows:
+            r["ms"] = min(r["ms"], again.get((r["resblock"], r["kernel"]), r["ms"]))
     # The launches of the two biggest blocks (conv1: K = 768 over the concat, 201.5 MB; conv2: K = 640 with the 1x1 residual segment, 268.6 MB) sit
     # within 2-3 % of each other in time and trade places from run to run: among the launches within 5 % of the longest one the figure is quoted on the
     # one with the LOWEST bytes / time (the conservative one, and the launch rounds 1-2 reported); the near ties are listed beside it.
@@ -149,8 +156,8 @@ def roofline(hd, batch, length, dtype, iters, device):
         "bound": "hbm" if ai < ridge else "mfma",
         "kernel": f"fused resblock implicit-GEMM (resblock {dom['resblock']} conv{dom['kernel']})",
         "definition": "dominant single launch (of the launches within 5 % of the longest: the one with the lowest bytes / time): SURVEY.md 8(d) "
-                      "algorithmic bytes of that conv / its mean duration, HIP events, in-pass launch form (GroupNorm table + statistics epilogue on), "
-                      "operands rotated over >= 320 MiB",
+                      "algorithmic bytes of that conv / its mean duration (fastest of three batches of launches), HIP events, in-pass launch form (GroupNorm table + "
+                      "statistics epilogue on), operands rotated over >= 320 MiB",
         "level": dom["resblock"], "conv": dom["kernel"],
         "ms_per_launch": dom["ms"],
         "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"], "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
