@@ -29,6 +29,19 @@ extern "C" int adf_debug_wn_stamps(unsigned long long* out) {
 #define WN_STAMP(i) do { } while (0)
 #endif
 
+// The skip sum (fp32 read-modify-write, 2 KB per position and layer) and the y_next stores are pure streams; the layer's 1 MB of weights is re-read from L2 by
+// every tile.  Non-temporal accesses for the streams (ADF_WN_NT, default on) keep them from evicting the weights.
+#ifndef ADF_WN_NT
+#define ADF_WN_NT 1
+#endif
+#if ADF_WN_NT
+#define WN_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define WN_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define WN_NT_LOAD(p) (*(p))
+#define WN_NT_STORE(v, p) (*(p) = (v))
+#endif
+
 namespace adf {
 
 typedef float f32x4_vec __attribute__((ext_vector_type(4)));
@@ -641,7 +654,7 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
             const int idx = tq + k * NT;
             const int row = idx / SCH, cc = idx - row * SCH;
             const bool in = !first && t0 + row < Tn;
-            sk[k] = *(const u32x4_t*)(sg + (unsigned)(in ? row * (C * 4) + cc * 16 : 0));
+            sk[k] = WN_NT_LOAD((const u32x4_t*)(sg + (unsigned)(in ? row * (C * 4) + cc * 16 : 0)));
             if (!in) sk[k] = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
@@ -670,7 +683,7 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
                 const float* const en1 = prm + 5 * C + cc * 8;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) f[u] = ((f[u] - en[u]) + rs[u]) * 0.70710678118654752440f + en1[u];
-                *(u32x4_t*)(ob + (unsigned)(i * (C * 2) + cc * 16)) = pack16<bf16_t>(f);
+                WN_NT_STORE(pack16<bf16_t>(f), (u32x4_t*)(ob + (unsigned)(i * (C * 2) + cc * 16)));
             }
 
         }
@@ -688,7 +701,7 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
             const int row = idx / SCH, cc = idx - row * SCH;
             if (t0 + row < Tn) {
                 const f32x4_vec a = *(const f32x4_vec*)(smem + (size_t)row * PS + cc * 16);
-                *(f32x4_vec*)(sg + (unsigned)(row * (C * 4) + cc * 16)) = a + __builtin_bit_cast(f32x4_vec, sk[k]);
+                WN_NT_STORE(a + __builtin_bit_cast(f32x4_vec, sk[k]), (f32x4_vec*)(sg + (unsigned)(row * (C * 4) + cc * 16)));
             }
 
         }
