@@ -23,6 +23,18 @@ extern "C" int adf_debug_c2_stamps(unsigned long long* out) {
 #define C2_STAMP(i) do { } while (0)
 #endif
 
+// output stores and residual loads are pure streams; the weights (re-read by every tile) and the halos (shared by neighbouring tiles) are what L2 should keep
+#ifndef ADF_C2_NT
+#define ADF_C2_NT 1
+#endif
+#if ADF_C2_NT
+#define C2_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define C2_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define C2_NT_LOAD(p) (*(p))
+#define C2_NT_STORE(v, p) (*(p) = (v))
+#endif
+
 namespace adf {
 
 #define C2_LAUNCH_CHECK(name) (hipGetLastError() == hipSuccess ? nullptr : "launch failed: " name)
@@ -49,7 +61,7 @@ __device__ __forceinline__ void c2_res_prefetch(const Conv2dArgs& a, int tid, in
 #pragma unroll
     for (int k = 0; k < TM * PPR / NT; ++k) {
         const int row = tid / PPR + k * (NT / PPR);
-        r.v[k] = (rg && col < a.cout) ? *(const u32x4_t*)(rg + pix(row) * a.cout + col) : u32x4_t{0u, 0u, 0u, 0u};
+        r.v[k] = (rg && col < a.cout) ? C2_NT_LOAD((const u32x4_t*)(rg + pix(row) * a.cout + col)) : u32x4_t{0u, 0u, 0u, 0u};
     }
 }
 
@@ -79,7 +91,7 @@ __device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, in
                 for (int e = 0; e < EPC; ++e) f[e] += g[e];
             }
             v = pack16_stored<T>(f);
-            *(u32x4_t*)(og + o) = v;
+            C2_NT_STORE(v, (u32x4_t*)(og + o));
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { s1[e] += f[e]; s2[e] = fmaf(f[e], f[e], s2[e]); }
         }
