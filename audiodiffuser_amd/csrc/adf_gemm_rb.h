@@ -57,6 +57,12 @@ constexpr int kRbMaxBlk = 24;
 #ifndef ADF_RB_KNOCK
 #define ADF_RB_KNOCK 0
 #endif
+// non-temporal epilogue accesses (A/B builds): 1 = output stores, 2 = residual loads.  Measured (round 3): in the isolated replay of bench.py (operands
+// rotated, no consumer) the resblock launches get 6.5 % faster with them (1.458 -> 1.36 ms per pass), end to end nothing moves (236.8 / 237.3 / 236.8 ms per
+// step): the consumer of a tensor then reads from HBM what it found in L2 / the memory-side cache before.  Off in the product.
+#ifndef ADF_RB_NT
+#define ADF_RB_NT 0
+#endif
 // three-stage weight ring: 1 = the 128-row forms and the 256-column forms (product), 2 = every form, 3 = the 128-row forms only, 4 = 128-row and 128-column forms, 0 = none (A/B builds)
 #ifndef ADF_RB_W3
 #define ADF_RB_W3 1
@@ -597,7 +603,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             const float* const scr = sc0 + (p & 1) * 512 + rsub * 64 + cc * 8;
             rw.q0 = *(const float4*)(scr);
             rw.q1 = *(const float4*)(scr + 4);
-            if (has_res) rw.res = *(const u32x4_t*)(resp + res_off(p));
+            if (has_res) rw.res = (ADF_RB_NT & 2) ? __builtin_nontemporal_load((const u32x4_t*)(resp + res_off(p))) : *(const u32x4_t*)(resp + res_off(p));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
@@ -627,7 +633,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rf[e];
             }
-            *(u32x4_t*)(out + res_off(p)) = pack16_stored<T>(v);
+            if (ADF_RB_NT & 1) __builtin_nontemporal_store(pack16_stored<T>(v), (u32x4_t*)(out + res_off(p)));
+            else *(u32x4_t*)(out + res_off(p)) = pack16_stored<T>(v);
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 const f32x2_t v2 = {v[e], v[e + 1]};
