@@ -31,6 +31,9 @@ extern "C" int adf_debug_wn_stamps(unsigned long long* out) {
 
 // The skip sum (fp32 read-modify-write, 2 KB per position and layer) and the y_next stores are pure streams; the layer's 1 MB of weights is re-read from L2 by
 // every tile.  Non-temporal accesses for the streams (ADF_WN_NT, default on) keep them from evicting the weights.
+#ifndef ADF_WN_XCD
+#define ADF_WN_XCD 1
+#endif
 #ifndef ADF_WN_NT
 #define ADF_WN_NT 1
 #endif
@@ -487,9 +490,15 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    // (An XCD-contiguous tile order -- adf_xcd_tile, as the conv2d kernels use -- was measured here: 1531 -> 1518 ms per configs[4] step, but the PMC
-    //  traffic of a layer launch went UP, 11.6 -> 12.2 GB; not kept.)
+    // XCD-contiguous tile order (adf_xcd_tile, as the conv2d kernels): an XCD's L2 sees a run of consecutive tiles of the same samples, whose dilated
+    // windows are each other's centre rows.  Measured twice: before the non-temporal streams 1531 -> 1518 ms per configs[4] step with the PMC traffic of a
+    // launch UP (11.6 -> 12.2 GB: not kept then); with them 1499.6 -> 1486.4 ms (three A/B pairs) and 10.8 GB per launch (11.1 without): kept.
+#if ADF_WN_XCD
+    const unsigned ltile = adf_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int b = (int)(ltile / gridDim.x), t0 = (int)(ltile % gridDim.x) * TM;
+#else
     const int b = blockIdx.y, t0 = blockIdx.x * TM;
+#endif
     // Global pieces are addressed as a wave-uniform base + a 32-bit per-lane byte offset derived from a freshly pinned thread id
     // in every phase: 64-bit per-lane pointers, which the compiler otherwise computes once for all phases and keeps (or
     // spills), would take ~200 of the 256 vector registers of this kernel.
