@@ -529,8 +529,9 @@ def other_workloads(a):
     released with its process, and a failure of one cannot take the headline line with it."""
     out = {}
     for name, argv in (("c3", ["--config", "c3", "--sampler", "dpm"]), ("c4", ["--config", "c4"]), ("c5", ["--config", "c5"])):
-        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc",
-                                                                       "--no-precision-check", "--no-other-workloads", "--roofline-iters", "10"]
+        # (configs[3] / [4] also collect their PMC traffic -- two rocprofv3 passes each, ~30 s -- so that the figure rides in the driver's line)
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + (["--no-pmc"] if name == "c3" else []) + [
+               "--no-precision-check", "--no-other-workloads", "--roofline-iters", "10"]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -543,7 +544,7 @@ def other_workloads(a):
             out[name] = {"workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
                          "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "finite": j["finite"], "clamped": j["clamped"],
                          "waveforms_per_s": j["waveforms_per_s"], "nfe_per_waveform": j["nfe_per_waveform"],
-                         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms_per_launch", "pass_ms")},
+                         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms_per_launch", "pass_ms", "traffic", "algorithmic_bytes")},
                          "wall_s_incl_setup": time.perf_counter() - t0}
         except subprocess.TimeoutExpired:
             out[name] = {"error": "timed out after 300 s"}
