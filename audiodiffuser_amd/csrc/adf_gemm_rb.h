@@ -57,6 +57,10 @@ constexpr int kRbMaxBlk = 24;
 #ifndef ADF_RB_KNOCK
 #define ADF_RB_KNOCK 0
 #endif
+// GroupNorm statistics of the stored tile by v_dot2c_f32_bf16 on the packed pairs instead of unpack + packed-fp32 add / fma
+#ifndef ADF_RB_DOT2
+#define ADF_RB_DOT2 1
+#endif
 // non-temporal epilogue accesses (A/B builds): 1 = output stores, 2 = residual loads.  Measured (round 3): in the isolated replay of bench.py (operands
 // rotated, no consumer) the resblock launches get 6.5 % faster with them (1.458 -> 1.36 ms per pass), end to end nothing moves (236.8 / 237.3 / 236.8 ms per
 // step): the consumer of a tensor then reads from HBM what it found in L2 / the memory-side cache before.  Off in the product.
@@ -633,6 +637,24 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rf[e];
             }
+#if ADF_RB_DOT2
+            // statistics of the STORED values straight from the packed pairs: v_dot2c_f32_bf16 (exact products of the bf16 pair, fp32 accumulate) against (1, 1)
+            // and against itself -- no unpacking of the rounded values, no packed-fp32 adds / fmas
+            const u32x4_t pk = pack16<T>(v);
+            if (ADF_RB_NT & 1) __builtin_nontemporal_store(pk, (u32x4_t*)(out + res_off(p)));
+            else *(u32x4_t*)(out + res_off(p)) = pk;
+            {
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+                const bf2_t one2 = __builtin_bit_cast(bf2_t, 0x3f803f80u);
+                const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf2_t q2 = __builtin_bit_cast(bf2_t, w4[e]);
+                    if (e & 1) { s1v.y = __builtin_amdgcn_fdot2_f32_bf16(q2, one2, s1v.y, false); s2v.y = __builtin_amdgcn_fdot2_f32_bf16(q2, q2, s2v.y, false); }
+                    else { s1v.x = __builtin_amdgcn_fdot2_f32_bf16(q2, one2, s1v.x, false); s2v.x = __builtin_amdgcn_fdot2_f32_bf16(q2, q2, s2v.x, false); }
+                }
+            }
+#else
             if (ADF_RB_NT & 1) __builtin_nontemporal_store(pack16_stored<T>(v), (u32x4_t*)(out + res_off(p)));
             else *(u32x4_t*)(out + res_off(p)) = pack16_stored<T>(v);
 #pragma unroll
@@ -641,6 +663,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                 s1v += v2;
                 s2v += v2 * v2;
             }
+#endif
             if (p % PH == PH - 1) flush_stats(p / PH);
         };
         Row rows[2];
