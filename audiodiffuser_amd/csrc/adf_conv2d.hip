@@ -76,6 +76,7 @@ __device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, in
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const bool pairs = sizeof(T) == 2 && a.stats && a.stats_groups > 0 && ((a.cout / a.stats_groups) & 1) == 0;       // uniform
     if (col < a.cout) {
 #pragma unroll
         for (int k = 0; k < TM * PPR / NT; ++k) {
@@ -90,6 +91,24 @@ __device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, in
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) f[e] += g[e];
             }
+            if constexpr (sizeof(T) == 2) {
+                if (pairs) {
+                    // statistics of the stored values from the packed pairs (v_dot2c_f32_bf16: exact products, fp32 accumulate): the pair sum goes to the
+                    // even channel's slot, the odd one stays 0 -- every statistics group holds whole pairs (even group size)
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+                    v = pack16<T>(f);
+                    C2_NT_STORE(v, (u32x4_t*)(og + o));
+                    const bf2_t one2 = __builtin_bit_cast(bf2_t, 0x3f803f80u);
+                    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf2_t q2 = __builtin_bit_cast(bf2_t, w4[e]);
+                        s1[2 * e] = __builtin_amdgcn_fdot2_f32_bf16(q2, one2, s1[2 * e], false);
+                        s2[2 * e] = __builtin_amdgcn_fdot2_f32_bf16(q2, q2, s2[2 * e], false);
+                    }
+                    continue;
+                }
+            }
             v = pack16_stored<T>(f);
             C2_NT_STORE(v, (u32x4_t*)(og + o));
 #pragma unroll
@@ -98,9 +117,11 @@ __device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, in
     }
     if (!a.stats) return;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e)
+    for (int e = 0; e < EPC; ++e) {
+        if (pairs && (e & 1)) continue;                // (pair sums live in the even slots)
 #pragma unroll
         for (int o = PPR; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+    }
     __syncthreads();                                   // every thread has read its rows of the tile: LDS is free
     float* const c1 = (float*)lds;                     // [TN] sums, [TN] sums of squares
     float* const c2 = c1 + TN;
@@ -108,7 +129,7 @@ __device__ __forceinline__ void c2_store_tile(const Conv2dArgs& a, char* lds, in
     __syncthreads();
     if ((tid & 63) < PPR) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { atomicAdd(&c1[pc * EPC + e], s1[e]); atomicAdd(&c2[pc * EPC + e], s2[e]); }
+        for (int e = 0; e < EPC; ++e) { if (pairs && (e & 1)) continue; atomicAdd(&c1[pc * EPC + e], s1[e]); atomicAdd(&c2[pc * EPC + e], s2[e]); }
     }
     __syncthreads();
     const int gs = a.cout / a.stats_groups;
