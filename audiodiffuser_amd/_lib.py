@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # builds can be timed inside one gpurun call; there is no non-HIP implementation to point it at.
 LIB_PATH = os.environ.get("ADF_HIP_LIB") or os.path.join(HERE, "libadf_hip.so")
 ADF_MAX_LAYERS = 12
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F32X3 = 0, 1, 2
 FLAG_SEPARATE_GN_STATS = 1
 SAMPLER_EDM, SAMPLER_EDM_ALPHA, SAMPLER_DPM_MULTISTEP, SAMPLER_DPM2, SAMPLER_ADPM2 = 0, 1, 2, 3, 4
 SAMPLER_LMS, SAMPLER_DPM_SINGLESTEP, SAMPLER_DPM2M, SAMPLER_UNIPC, SAMPLER_ADPMPP2S = 5, 6, 7, 8, 9
@@ -73,7 +73,7 @@ class AdfRunCounters(C.Structure):
 
 
 FLAG_NEAREST_UPSAMPLE = 2  # ADF_FLAG_NEAREST_UPSAMPLE
-ABI_VERSION = 4          # ADF_ABI_VERSION of the header this binding was written against
+ABI_VERSION = 5          # ADF_ABI_VERSION of the header this binding was written against
 
 EXPORTS = {
     # name: (restype, argtypes)

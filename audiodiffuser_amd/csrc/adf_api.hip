@@ -94,11 +94,12 @@ int adf_create(const adf_net_config* cfg, adf_handle** out) {
     if (c.num_layers < 1 || c.num_layers > ADF_MAX_LAYERS) { g_create_error = "adf_create: bad num_layers"; return 1; }
     if (c.num_filters != c.channels * c.multipliers[0]) { g_create_error = "adf_create: num_filters must equal channels*multipliers[0]"; return 1; }
     if (c.channels % 2 || c.channels < 2) { g_create_error = "adf_create: channels must be even"; return 1; }
-    if (c.dtype != ADF_DTYPE_F32 && c.dtype != ADF_DTYPE_BF16) { g_create_error = "adf_create: bad dtype"; return 1; }
+    if (c.dtype != ADF_DTYPE_F32 && c.dtype != ADF_DTYPE_BF16 && c.dtype != ADF_DTYPE_F32X3) { g_create_error = "adf_create: bad dtype"; return 1; }
     adf_handle* h = new adf_handle();
     h->cfg = c;
     if (hipGetDevice(&h->device) != hipSuccess) { g_create_error = "adf_create: hipGetDevice failed"; delete h; return 1; }
     h->bf16 = c.dtype == ADF_DTYPE_BF16;
+    h->x3 = c.dtype == ADF_DTYPE_F32X3;             // fp32 storage (esz 4, 32 K elements per row) with split-bf16 GEMM operands
     h->esz = h->bf16 ? 2 : 4;
     h->kc = kRowBytes / h->esz;
     if (build_weights(h)) { g_create_error = h->err; adf_destroy(h); return 1; }
@@ -208,14 +209,14 @@ int adf_load_weight(adf_handle* h, const char* name, const float* dev, int64_t n
         if (const char* e = launch_permute_qkv_rows(dev, (float*)sl.dst, sl.f, sl.cout / (3 * sl.f), 1, s)) return fail(h, e);
     } else if (sl.kind == 4) {               // qkv weight: permute the rows into a scratch copy, then pack that
         if (const char* e = launch_permute_qkv_rows(dev, (float*)sl.frag, sl.f, sl.cout / (3 * sl.f), sl.cin, s)) return fail(h, e);
-        if (const char* e = launch_pack_weight((const float*)sl.frag, sl.dst, h->bf16, 0, sl.cout, sl.cin, sl.K, 0, sl.n_offset, sl.n_pad, sl.nchunk, s))
+        if (const char* e = launch_pack_weight((const float*)sl.frag, sl.dst, h->gemm_dtype(), 0, sl.cout, sl.cin, sl.K, 0, sl.n_offset, sl.n_pad, sl.nchunk, s))
             return fail(h, e);
     } else {
-        const char* e = launch_pack_weight(dev, sl.dst, h->bf16, sl.kind == 2 ? 1 : (sl.kind == 3 ? 2 : 0), sl.cout, sl.cin, sl.K, sl.f, sl.n_offset,
+        const char* e = launch_pack_weight(dev, sl.dst, h->gemm_dtype(), sl.kind == 2 ? 1 : (sl.kind == 3 ? 2 : 0), sl.cout, sl.cin, sl.K, sl.f, sl.n_offset,
                                            sl.n_pad, sl.nchunk, s);
         if (e) return fail(h, e);
         if (sl.kind == 2 && sl.dst3) {
-            e = launch_pack_weight(dev, sl.dst3, h->bf16, 3, sl.cout, sl.cin, sl.K, sl.f, 0, sl.n_pad3, sl.nchunk, s);
+            e = launch_pack_weight(dev, sl.dst3, h->gemm_dtype(), 3, sl.cout, sl.cin, sl.K, sl.f, 0, sl.n_pad3, sl.nchunk, s);
             if (e) return fail(h, e);
         }
         if (sl.frag) {

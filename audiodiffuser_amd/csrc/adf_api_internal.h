@@ -145,6 +145,8 @@ struct adf_handle {
     int device = 0;                     // the device that was current at adf_create: every entry point runs on it
     unsigned long long use_clock = 0;
     bool bf16 = false;
+    bool x3 = false;                    // ADF_DTYPE_F32X3: storage and every non-GEMM kernel as fp32 (bf16 == false), GEMM operands split into bf16 hi + lo
+    int gemm_dtype() const { return bf16 ? 1 : (x3 ? 2 : 0); }      // the `dtype` of launch_conv_gemm / launch_pack_weight
     int esz = 4, kc = 32;
     std::string err;
     std::vector<void*> allocs;
@@ -416,7 +418,7 @@ struct Walker {
         }
         if (live()) {
             bool fused = false;
-            check(launch_conv_gemm(g, h->bf16, s, &fused));
+            check(launch_conv_gemm(g, h->gemm_dtype(), s, &fused));
             // the launcher may decline (tile shape / group size): fill the same buffer with the separate pass
             if (ask && !fused) check(launch_gn_stats(out.p, h->bf16, p->B, out.L, out.C, h->cfg.resnet_groups, out.stats, s));
         }

@@ -76,10 +76,10 @@ static int bench_resblock_impl(adf_handle* h, int B, int L, int level, int conv,
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(h, "bench_resblock: hipEventCreate failed");
         int rc = 0;
         for (size_t k = 0; k < R && !rc; ++k)
-            if (const char* e = launch_conv_gemm(sets[k], h->bf16, s)) rc = fail(h, e);          // warm-up: code, attributes, TLBs
+            if (const char* e = launch_conv_gemm(sets[k], h->gemm_dtype(), s)) rc = fail(h, e);          // warm-up: code, attributes, TLBs
         if (!rc && hipEventRecord(e0, s) != hipSuccess) rc = fail(h, "bench_resblock: hipEventRecord failed");
         for (int i = 0; i < iters && !rc; ++i)
-            if (const char* e = launch_conv_gemm(sets[(size_t)i % R], h->bf16, s)) rc = fail(h, e);
+            if (const char* e = launch_conv_gemm(sets[(size_t)i % R], h->gemm_dtype(), s)) rc = fail(h, e);
         if (!rc && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(h, "bench_resblock: event record / sync failed");
         float t = 0.f;
         if (!rc && hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = fail(h, "bench_resblock: hipEventElapsedTime failed");

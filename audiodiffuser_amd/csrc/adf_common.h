@@ -68,6 +68,31 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
     return q;
 }
 
+// ---- split-bf16 ("f32x3") mode -------------------------------------------------------------------------------------------------------
+// Storage is fp32 exactly as in the parity mode (Elem / unpack16 / pack16 below are the float ones); only the GEMM OPERANDS differ: a value x is staged
+// as hi = rn_bf16(x) and lo = rn_bf16(x - hi) (x = hi + lo up to 2^-17 |x|) and a product a * b is taken as a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA
+// with fp32 accumulation (the dropped a_lo b_lo term is 2^-18 of the product): ~1e-5 relative per dot product against the exact-fp32 chain, at a third of
+// the bf16 MFMA rate instead of the sixteenth that v_mfma_f32_32x32x2f32 runs at.  A 128-byte K row of 32 fp32 becomes 64 B of hi + 64 B of lo:
+// 16-byte slot s < 4 holds the hi parts of K = 8 s .. 8 s + 7 (the MFMA fragment of K step s >> 1, lane half s & 1), slot 4 + s the lo parts -- the
+// SAME row pitch, LDS footprint and staging loop as the fp32 rows.  Weights are split once, at pack time (pack_weight_kernel<f32x3_t>).
+struct f32x3_t { float v; };
+template <> struct Elem<f32x3_t> {
+    static constexpr int kPerChunk = 4;
+    __device__ static __forceinline__ float ld(const f32x3_t* p) { return p->v; }
+    __device__ static __forceinline__ void st(f32x3_t* p, float v) { p->v = v; }
+};
+template <> __device__ __forceinline__ void unpack16<f32x3_t>(const u32x4_t& q, float* f) { unpack16<float>(q, f); }
+template <> __device__ __forceinline__ u32x4_t pack16<f32x3_t>(const float* f) { return pack16<float>(f); }
+template <typename T> struct IsX3 { static constexpr bool value = false; };
+template <> struct IsX3<f32x3_t> { static constexpr bool value = true; };
+// four fp32 -> their hi parts (8 B) and lo parts (8 B)
+__device__ __forceinline__ void split_bf16x4(const float* f, u32x2_t& hi, u32x2_t& lo) {
+    hi.x = pack_bf16x2(f[0], f[1]);
+    hi.y = pack_bf16x2(f[2], f[3]);
+    lo.x = pack_bf16x2(f[0] - __uint_as_float(hi.x << 16), f[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack_bf16x2(f[2] - __uint_as_float(hi.y << 16), f[3] - __uint_as_float(hi.y & 0xffff0000u));
+}
+
 // Pack a chunk for storing AND leave in f[] the values the tensor then holds: the GroupNorm statistics of a produced tensor are
 // reduced from the STORED (bf16-rounded) values, i.e. they are the statistics of the tensor the next layer reads -- what the
 // reference's GroupNorm computes on its input -- not of the fp32 accumulators behind it.  fp32 storage: values unchanged.

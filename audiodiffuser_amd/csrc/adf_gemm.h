@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
     constexpr int A_CH = (kARows * 8 + NTHR - 1) / NTHR;
     constexpr int W_CH = (kTapGroup * TN * 8 + NTHR - 1) / NTHR;
     constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr bool kX3 = IsX3<T>::value;              // fp32 storage, operands staged as bf16 hi | lo (adf_common.h)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsA = smem;
     char* ldsW = smem + kARows * kLdsPitch;
@@ -324,7 +325,17 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
                         }
                         q = pack16<T>(f);
                     }
-                    *(u32x4_t*)(ldsA + lds_swz(row, c16)) = q;
+                    if constexpr (kX3) {
+                        // split-bf16 operand: the chunk's four values as hi | lo halves of the fragment slots c16 >> 1 and 4 + (c16 >> 1) (adf_common.h)
+                        float f4[4];
+                        unpack16<float>(q, f4);
+                        u32x2_t hi, lo;
+                        split_bf16x4(f4, hi, lo);
+                        *(u32x2_t*)(ldsA + lds_swz(row, c16 >> 1) + (c16 & 1) * 8) = hi;
+                        *(u32x2_t*)(ldsA + lds_swz(row, 4 + (c16 >> 1)) + (c16 & 1) * 8) = lo;
+                    } else {
+                        *(u32x4_t*)(ldsA + lds_swz(row, c16)) = q;
+                    }
                 }
             }
         }
@@ -373,6 +384,29 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const GemmArgs 
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
+                }
+            } else if constexpr (kX3) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8_t ah_[MT], al_[MT], bh_[NT], bl_[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        ah_[i] = *(const bf16x8_t*)(ldsA + lds_swz(arow[i], ks * 2 + h));
+                        al_[i] = *(const bf16x8_t*)(ldsA + lds_swz(arow[i], 4 + ks * 2 + h));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        bh_[j] = *(const bf16x8_t*)(ldsW + lds_swz(wrow[j], ks * 2 + h));
+                        bl_[j] = *(const bf16x8_t*)(ldsW + lds_swz(wrow[j], 4 + ks * 2 + h));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_[i], bh_[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_[i], bl_[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_[i], bh_[j], acc[i][j], 0, 0, 0);
+                        }
                 }
             } else {
 #pragma unroll
@@ -992,6 +1026,7 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
     constexpr int A_CH = (kKsARows * 8) / NW;              // 5 / 9
     constexpr int W_CH = (kTapGroup * TN * 8) / NW;        // 12 / 24
     constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr bool kX3 = IsX3<T>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -1121,7 +1156,16 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
                     }
                     qv = pack16<T>(f);
                 }
-                *(u32x4_t*)(ldsA + lds_swz(row, c16)) = qv;
+                if constexpr (kX3) {
+                    float f4[4];
+                    unpack16<float>(qv, f4);
+                    u32x2_t hi, lo;
+                    split_bf16x4(f4, hi, lo);
+                    *(u32x2_t*)(ldsA + lds_swz(row, c16 >> 1) + (c16 & 1) * 8) = hi;
+                    *(u32x2_t*)(ldsA + lds_swz(row, 4 + (c16 >> 1)) + (c16 & 1) * 8) = lo;
+                } else {
+                    *(u32x4_t*)(ldsA + lds_swz(row, c16)) = qv;
+                }
             }
         }
 #pragma unroll
@@ -1157,6 +1201,29 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
+                }
+            } else if constexpr (kX3) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8_t ah_[MT], al_[MT], bh_[NT], bl_[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        ah_[i] = *(const bf16x8_t*)(ldsA + lds_swz(abase[i] + aoff, ks * 2 + h));
+                        al_[i] = *(const bf16x8_t*)(ldsA + lds_swz(abase[i] + aoff, 4 + ks * 2 + h));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        bh_[j] = *(const bf16x8_t*)(ldsW + lds_swz(tap * TN + j * 32 + r, ks * 2 + h));
+                        bl_[j] = *(const bf16x8_t*)(ldsW + lds_swz(tap * TN + j * 32 + r, 4 + ks * 2 + h));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_[i], bh_[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_[i], bl_[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_[i], bh_[j], acc[i][j], 0, 0, 0);
+                        }
                 }
             } else {
 #pragma unroll
@@ -1300,7 +1367,8 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
 }
 
 // host-side launcher (adf_gemm.hip); *stats_fused tells whether the requested statistics were produced
-const char* launch_conv_gemm(const GemmArgs& a, int dtype_bf16, hipStream_t stream, bool* stats_fused = nullptr);
+// dtype: 0 = fp32 (exact-fp32 MFMA), 1 = bf16 storage, 2 = fp32 storage with split-bf16 operands (f32x3_t, adf_common.h)
+const char* launch_conv_gemm(const GemmArgs& a, int dtype, hipStream_t stream, bool* stats_fused = nullptr);
 // would launch_conv_gemm route this phase_c > 0 conv to conv_gemm_rb_kernel (shape, tile count)?  No launch.
 bool conv_gemm_phase_eligible(const GemmArgs& a);
 

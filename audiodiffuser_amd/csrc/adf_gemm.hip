@@ -363,13 +363,20 @@ bool conv_gemm_phase_eligible(const GemmArgs& a) {
     return try_launch_rb(a, nullptr, mt, nullptr, &err, true);
 }
 
-const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t stream, bool* stats_fused) {
+const char* launch_conv_gemm(const GemmArgs& a_in, int dtype, hipStream_t stream, bool* stats_fused) {
+    // dtype: 0 = fp32 storage + exact-fp32 MFMA, 1 = bf16 storage, 2 = fp32 storage + split-bf16 operands (f32x3_t: the generic and split-K kernels only)
+    const bool dtype_bf16 = dtype == 1, x3 = dtype == 2;
     GemmArgs a = a_in;
     if (stats_fused) *stats_fused = false;
     if (a.phase_c) {                 // only the resblock conv kernel's raw form knows the phase-major statistics
-        if (!dtype_bf16 || !conv_gemm_phase_eligible(a)) return "conv_gemm: a 3-tap-form transposed conv that conv_gemm_rb_kernel does not take";
+        // what try_launch_rb accepts drives the answer: declined with a statistics request (group size), it is asked again without one and the caller
+        // runs the separate statistics pass (stats_fused stays false)
+        const long long mt = rb_min_tiles();
+        if (!dtype_bf16 || mt < 0 || a.flat) return "conv_gemm: a 3-tap-form transposed conv that conv_gemm_rb_kernel does not take";
         const char* err = nullptr;
-        (void)try_launch_rb(a, nullptr, rb_min_tiles(), stream, &err);
+        bool taken = try_launch_rb(a, nullptr, mt, stream, &err);
+        if (!taken && a.stats) { a.stats = nullptr; taken = try_launch_rb(a, nullptr, mt, stream, &err); }
+        if (!taken) return "conv_gemm: a 3-tap-form transposed conv that conv_gemm_rb_kernel does not take";
         if (stats_fused) *stats_fused = a.stats != nullptr;
         trace_route("rb", a, 256, 128);
         return err;
@@ -517,8 +524,8 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
             }
             if (const char* e = settle_gn(false)) return e;
             trace_route("ksplit", a, tile, tile);
-            if (big) return dtype_bf16 ? launch_ksplit<bf16_t, 2, 2>(a, stream) : launch_ksplit<float, 2, 2>(a, stream);
-            return dtype_bf16 ? launch_ksplit<bf16_t, 1, 1>(a, stream) : launch_ksplit<float, 1, 1>(a, stream);
+            if (big) return dtype_bf16 ? launch_ksplit<bf16_t, 2, 2>(a, stream) : (x3 ? launch_ksplit<f32x3_t, 2, 2>(a, stream) : launch_ksplit<float, 2, 2>(a, stream));
+            return dtype_bf16 ? launch_ksplit<bf16_t, 1, 1>(a, stream) : (x3 ? launch_ksplit<f32x3_t, 1, 1>(a, stream) : launch_ksplit<float, 1, 1>(a, stream));
         }
     }
     {
@@ -591,7 +598,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
         // large stride-1 layers: weight-stationary persistent kernel when the weights of an N tile fit in LDS
         static int use_ws = -1;
         if (use_ws < 0) use_ws = adf_route_switch("ADF_GEMM_WS", 1);
-        bool ws_ok = use_ws && !flat && tm == 128 && a.n_pad >= 64;
+        bool ws_ok = use_ws && !x3 && !flat && tm == 128 && a.n_pad >= 64;
         for (int s = 0; s < a.nseg; ++s)
             if (a.seg[s].stride != 1 || 127 + a.seg[s].taps > kWsARows) ws_ok = false;
         const long long tiles_m_total = (long long)((a.mrows + 127) / 128) * a.B;
@@ -622,7 +629,7 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype_bf16, hipStream_t s
     }
     if (const char* e = settle_gn(false)) return e;
     trace_route("plain", a, tm, tn);
-    return dtype_bf16 ? dispatch<bf16_t>(a, tm, tn, stream) : dispatch<float>(a, tm, tn, stream);
+    return dtype_bf16 ? dispatch<bf16_t>(a, tm, tn, stream) : (x3 ? dispatch<f32x3_t>(a, tm, tn, stream) : dispatch<float>(a, tm, tn, stream));
 }
 
 }  // namespace adf

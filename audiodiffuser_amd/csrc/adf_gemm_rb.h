@@ -711,6 +711,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     auto tl = [&](int) __attribute__((always_inline)) {};
 #endif
     kstamp(11);
+    tl(110);                                           // (fine start-up stamps 110-114 of the diagnostic build: argument head here)
     // ---- start-up: bias vector, the first sample's table, first DMAs -------------------------------------------------
     // (all start-up loads unconditional -- absent tensors through a dummy pointer, lanes past the end on a clamped index: two bias loads and the
     //  table loads under conditions were seven serialised round trips ahead of the first DMA)
@@ -720,6 +721,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     const float b0v = (hb0 ? H.bias0 : dummy_f)[bidx_l], b1v = (hb1 ? H.bias1 : dummy_f)[bidx_l];
     GnLoaded gl = {};
     if constexpr (!RAW) gl = gn_load(b_first, tid < ctot0 ? tid : ctot0 - 1);
+    tl(111);                                           // statistics / parameter loads issued
     // (blocks 0, 1 and 2 mod nb of the first tile -- or, with two blocks per tile, block 0 of the next one -- from the preloaded entries)
     Blk dc = make_desc_of(e_first[0]);
     advance();
@@ -731,6 +733,11 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage);
     Blk d2 = make_desc_of(d_k == 0 ? e_first[0] : e_first[2]);
     advance();
+    tl(112);                                           // first DMAs issued
+#ifdef ADF_RB_TL
+    asm volatile("" :: "v"(gl.gamma), "v"(gl.beta), "v"(gl.f1s), "v"(gl.f1h), "v"(gl.f2s), "v"(gl.f2h), "v"(gl.s0), "v"(gl.q0), "v"(gl.s1), "v"(gl.q1), "v"(b0v), "v"(b1v));
+    tl(113);                                           // their values are here
+#endif
     if (tid < H.n) ldsBias[tid] = (hb0 ? b0v : 0.f) + (hb1 ? b1v : 0.f);
     if (!RAW && tid < ctot0) gn_store(tid, gl, 0);
     kstamp(12);

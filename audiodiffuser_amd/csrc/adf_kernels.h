@@ -113,7 +113,7 @@ const char* launch_nlc_to_ncl_f32(const void* x, float* y, int bf16, int B, int 
 // mode 0: Conv1d / Linear weight (Cout, Cin, K) ; mode 1: ConvTranspose1d weight (Cin, Cout, K=2f) as 2-tap phases
 // bf16 1x1 weights of the transformer blocks: second copy in MFMA-fragment order (rows [n_offset, n_offset + n_rows) of a packed buffer)
 const char* launch_repack_frag(const void* src_packed, void* dst, int n_offset, int n_rows, int n_pad, int nchunk, hipStream_t s);
-const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, int cout, int cin, int K, int f,
+const char* launch_pack_weight(const float* src, void* dst, int dtype, int mode, int cout, int cin, int K, int f,
                                int n_offset, int n_pad, int nchunk, hipStream_t s);
 
 }  // namespace adf

@@ -1365,12 +1365,22 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
             }
         }
         const size_t o = (((size_t)chunk * taps + tap) * n_pad + n_offset + nl) * KC + kc;
-        Elem<T>::st(dst + o, v);
+        if constexpr (IsX3<T>::value) {
+            // split-bf16 row (adf_common.h): hi part of K element kc at bf16 index kc of the row, lo part at 32 + kc (slots kc >> 3 and 4 + (kc >> 3))
+            unsigned short* row = (unsigned short*)(dst + (o - kc));
+            const unsigned short hi = f32_to_bf16_hw(v);
+            row[kc] = hi;
+            row[32 + kc] = f32_to_bf16_hw(v - bf16_to_f32(hi));
+        } else {
+            Elem<T>::st(dst + o, v);
+        }
     }
 }
 
-const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, int cout, int cin, int K, int f,
+// dtype: 0 = fp32 rows, 1 = bf16 rows, 2 = split-bf16 rows (hi | lo halves of a 32-element fp32 row, f32x3_t)
+const char* launch_pack_weight(const float* src, void* dst, int dtype, int mode, int cout, int cin, int K, int f,
                                int n_offset, int n_pad, int nchunk, hipStream_t s) {
+    const int bf16 = dtype == 1;
     const int taps = mode == 0 ? K : (mode == 2 ? (K - 1) / f + 1 : (mode == 3 ? 3 : 2));
     if ((mode == 1 || mode == 3) && K != 2 * f) return "pack_weight: transposed conv needs K == 2*factor";
     if (mode == 3 && f % 2) return "pack_weight: the 3-tap form of a transposed conv needs an even factor";
@@ -1382,6 +1392,7 @@ const char* launch_pack_weight(const float* src, void* dst, int bf16, int mode, 
     const long long total = (long long)nchunk * taps * n_rows * kc;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     if (bf16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, mode, cout, cin, K, f, n_offset, n_rows, n_pad, nchunk, taps);
+    else if (dtype == 2) hipLaunchKernelGGL(pack_weight_kernel<f32x3_t>, dim3(grid), dim3(256), 0, s, src, (f32x3_t*)dst, mode, cout, cin, K, f, n_offset, n_rows, n_pad, nchunk, taps);
     else hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, mode, cout, cin, K, f, n_offset, n_rows, n_pad, nchunk, taps);
     return ADF_LAUNCH_CHECK("pack_weight");
 }

@@ -187,12 +187,19 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
             GemmArgs g3 = W.gemm_base(y3, x.L, x.L, up.up3);
             g3.seg[0] = Walker::seg_of(x, nullptr, nullptr, 1.f, 0, 3, 1, -1, 1, up.up3);
             g3.phase_c = up.cout;
-            if (conv_gemm_phase_eligible(g3)) {
-                const bool ask = u + 1 < n && W.can_fuse_stats(up.cout);
-                if (ask) { y.stats = W.alloc_stats(); g3.stats = y.stats; g3.stats_groups = h->cfg.resnet_groups; }
+            // (eligibility is asked with the statistics request attached -- the launcher's shape checks include the group size the epilogue can
+            //  reduce -- and, if that is what it declines, again without: the statistics then come from the separate pass.  ADVICE r3: asked without
+            //  and launched with, a group size outside 8 .. 64 channels was a hard error instead of the fallback every other route has.)
+            const bool ask = u + 1 < n && W.can_fuse_stats(up.cout);
+            g3.stats = ask ? (double*)(uintptr_t)256 : nullptr;                 // (a dry check: never dereferenced)
+            g3.stats_groups = ask ? h->cfg.resnet_groups : 0;
+            bool elig = conv_gemm_phase_eligible(g3);
+            if (!elig && ask) { g3.stats = nullptr; g3.stats_groups = 0; elig = conv_gemm_phase_eligible(g3); }
+            if (elig) {
+                if (ask) { y.stats = W.alloc_stats(); if (g3.stats) g3.stats = y.stats; }
                 if (W.live()) {
                     bool fused = false;
-                    W.check(launch_conv_gemm(g3, h->bf16, s, &fused));
+                    W.check(launch_conv_gemm(g3, h->gemm_dtype(), s, &fused));
                     if (ask && !fused) W.check(launch_gn_stats(y.p, h->bf16, B, y.L, y.C, h->cfg.resnet_groups, y.stats, s));
                 }
                 done = true;

@@ -25,7 +25,8 @@ from .adm_config import ADMConfig
 from .config import UNet1dConfig, WaveNetConfig
 from .weights import param_specs
 
-_DTYPES = {"fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16}
+_DTYPES = {"fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16,
+           "f32x3": _lib.DTYPE_F32X3}      # split-bf16 (UNet1dBase only): fp32 storage, bf16 hi + lo operands, 3 MFMAs per product
 
 
 def _stream_ptr(device: torch.device) -> int:

@@ -42,14 +42,20 @@ extern "C" {
 
 /* Bumped whenever a struct of this header grows or an entry point's argument list changes; a binding compares it with
  * adf_abi_version() of the library it loaded before the first call (audiodiffuser_amd/_lib.py does; INTEGRATION.md's C example too).
- * 3: adf_sampler_run(n_injected), adf_sampler_desc.reflow, adf_get_counters. */
-#define ADF_ABI_VERSION 4
+ * 3: adf_sampler_run(n_injected), adf_sampler_desc.reflow, adf_get_counters.
+ * 4: ADF_FLAG_NEAREST_UPSAMPLE (adf_net_config.flags bit 1; state-dict keys ...upsample.2.weight / .bias), WaveNetNoise in bf16 at 64 / 128
+ *    residual channels, adf_debug_tap on a WaveNet handle keeps every layer while all of them fit 512 MiB (256 MiB before).
+ * 5: ADF_DTYPE_F32X3 (a third value of adf_net_config.dtype: fp32 storage, every GEMM operand split into bf16 hi + lo, three bf16 MFMAs per product). */
+#define ADF_ABI_VERSION 5
 int adf_abi_version(void);
 
 #define ADF_MAX_LAYERS 12
 
 #define ADF_DTYPE_F32 0  /* parity mode: fp32 storage, exact-fp32 MFMA */
 #define ADF_DTYPE_BF16 1 /* throughput mode: bf16 storage, fp32 accumulate */
+#define ADF_DTYPE_F32X3 2 /* split-bf16 mode (UNet1dBase only): fp32 storage as ADF_DTYPE_F32; a GEMM operand x is staged as bf16 hi = rn(x) and
+                             lo = rn(x - hi) (x = hi + lo to 2^-17) and a product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation:
+                             ~1e-5 relative per layer against the exact-fp32 mode, inside the 1e-3 bar of the reference comparison, at the bf16 MFMA rate / 3 */
 
 /* Hyper-parameters of UNet1dBase; same meaning as the reference kwargs. */
 typedef struct adf_net_config {

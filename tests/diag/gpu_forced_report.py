@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_parity.py::test_unfused_launches_every_stored_tensor_vs_bf16_oracle: runs the bf16 device path with
 whatever ADF_* route switches the environment holds (they are read once per process) and prints the teacher-forced relative-L2
 deviation of every recorded activation from the bf16-storage oracle as one JSON line.
-usage: gpu_forced_report.py <preset> <batch> <length>"""
+usage: gpu_forced_report.py <preset> <batch> <length> [resnet_groups]"""
 import json
 import os
 import sys
@@ -17,6 +17,8 @@ from gpu_helpers import tap_errors_bf16  # noqa: E402
 
 preset, B, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 cfg = A.PRESETS[preset]()
+if len(sys.argv) > 4:
+    cfg.resnet_groups = int(sys.argv[4])
 x = generate_noise(0, B, L) * 0.7
 t = torch.linspace(-0.9, 0.35, B)
 forced, chain, y, yf, yc = tap_errors_bf16(cfg, x, t, chained=False)

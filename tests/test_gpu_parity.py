@@ -68,6 +68,24 @@ def test_every_layer_fp32(tag, mk, flags):
     assert not bad, bad
 
 
+F32X3_TOL = 2e-4      # split-bf16 mode per recorded tensor, free-running, max-norm relative (operands carry 16 mantissa bits: ~1e-5 per layer)
+
+
+@pytest.mark.parametrize("tag,mk", CASES + [("c3short", A.config_c3)])
+def test_every_layer_f32x3(tag, mk):
+    """ADF_DTYPE_F32X3 (fp32 storage, every GEMM operand split into bf16 hi + lo, three bf16 MFMAs per product): every recorded tensor of the net
+    against the fp32 oracle, free-running.  Routes: the generic implicit-GEMM kernel and the split-K kernel (the only two that take the mode)."""
+    if tag == "c3short":
+        x, t = generate_noise(5, 2, 4096) * 0.7, torch.tensor([-0.6, 0.4])
+    else:
+        x, t = golden_inputs(tag)
+    errs, y, yo = tap_errors(mk(), x, t, "f32x3", 0)
+    assert len(errs) > 10
+    bad = {k: v for k, v in errs.items() if not v < F32X3_TOL}
+    assert not bad, bad
+    assert max(errs.values()) > 1e-7          # (not silently the exact-fp32 route)
+
+
 def _assert_bf16_parity(cfg, x, t, chained=True, flags=0):
     """bf16 device path vs the bf16-storage oracle: every layer teacher-forced, and (chained) free-running."""
     forced, chain, y, y_f, y_c = tap_errors_bf16(cfg, x, t, flags=flags, chained=chained)
@@ -143,6 +161,28 @@ def test_resblock_dma_kernel_on_small_batches_incl_128_row_tiles_every_stored_te
     forced = rep["forced"]
     assert rep["finite"]
     assert {"down3.conv", "down3.block0.h1", "down3.block1", "up2.block0.h1", "up2.block2"} <= set(forced)
+    bad = {k: (v, _bf16_tol(k, forced)) for k, v in forced.items() if not v < _bf16_tol(k, forced)}
+    assert not bad, bad
+
+
+def test_transposed_conv_3tap_form_with_a_group_size_its_epilogue_does_not_reduce():
+    """the f = 2 transposed convs in their 3-tap form on conv_gemm_rb_kernel reduce GroupNorm statistics in the epilogue for group
+    sizes of 8 .. 64 channels only.  resnet_groups = 32 gives the 128 -> 64 level groups of 2 channels (and the 128-channel levels groups of 4): the
+    launcher has to take the launch WITHOUT the statistics and the walker run the separate pass -- it was a hard error.  C2 widths, batch 4 with
+    ADF_GEMM_RB=2 (the route at small batches), every stored tensor against the bf16-storage oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADF_GEMM_RB="2", ADF_GEMM_TRACE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_forced_report.py"), "c2", "4", "16384", "32"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    forced = rep["forced"]
+    assert rep["finite"]
+    # the three f = 2 levels went through the rb kernel's raw form (3 taps, K = 3 * cin, n = 2 * cout)
+    assert sum(("[adf gemm] rb" in l and "taps=3" in l and "ab=0 act=0" in l and "n=128/128" in l and "seg0(c=128+0" in l) for l in r.stderr.splitlines()) >= 1, r.stderr[-3000:]
     bad = {k: (v, _bf16_tol(k, forced)) for k, v in forced.items() if not v < _bf16_tol(k, forced)}
     assert not bad, bad
 
@@ -351,6 +391,31 @@ def test_config1_full_sampler_vs_oracle():
     with torch.no_grad():
         yo = S.edm_sampler(noise, E.make_denoiser(w, cfg, 0.2), sig, 18, s_churn=0.0, s_noise=1.0)
     assert rel_err(y.cpu(), yo) < FP32_TOL
+
+
+C2_SAMPLER_MODES = ["fp32", "f32x3"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", C2_SAMPLER_MODES)
+def test_config2_full_sampler_fp32_vs_oracle(dtype):
+    """BASELINE configs[1] -- the configuration the bench times -- through its OWN sampler in the parity-grade modes: the C2 net
+    (64 ch), two 16384-sample waveforms, 50-step Heun = 99 evaluations (sampler_edm.py:371-397), eager and graph-replayed, against
+    oracle.samplers.edm_sampler on the CPU.  north_star bar: <= 1e-3 relative.  ``f32x3`` is the split-bf16 mode (fp32 storage,
+    every GEMM operand as bf16 hi + lo, three bf16 MFMAs per product)."""
+    from oracle import edm as E, samplers as S
+    cfg = A.config_c2()
+    net, w = make_net(cfg, dtype)
+    d = A.EluDiffusion(sigma_data=0.2)
+    sig = A.KarrasSchedule(0.002, 80.0, 7.0, 50)()
+    noise = generate_noise(2024, 2, 16384)
+    with torch.no_grad():
+        yo = S.edm_sampler(noise, E.make_denoiser(w, cfg, 0.2), sig, 50, s_churn=0.0, s_noise=1.0)
+    for graph in (False, True):
+        y = A.EDMSampler(s_churn=0.0, s_noise=1.0, num_steps=50, use_graph=graph)(noise.cuda(), fn=d.denoise_fn, net=net, sigmas=sig).cpu()
+        assert torch.isfinite(y).all()
+        assert rel_err(y, yo) < FP32_TOL, (dtype, graph, rel_err(y, yo))
+        assert rel_l2(y, yo) < FP32_TOL, (dtype, graph, rel_l2(y, yo))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -38,6 +38,24 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), "ctypes binding table and header disagree"
 
 
+def test_abi_version_agrees_across_header_binding_library_and_docs():
+    """INTEGRATION.md asserted version 3 while header and binding said 4 -- the documented binding refused the shipped library."""
+    hdr = open(os.path.join(ROOT, "include", "audiodiffuser_amd.h")).read()
+    ver = int(re.search(r"#define ADF_ABI_VERSION (\d+)", hdr).group(1))
+    assert ver == _lib.ABI_VERSION == _lib.load_library().adf_abi_version()
+    # the header's changelog has a line for every version since 3
+    for v in range(3, ver + 1):
+        assert re.search(rf"^ \* {v}: ", hdr, flags=re.M), f"no changelog entry '{v}:' in the header comment"
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    # any literal the docs compare adf_abi_version() with must be the current one; the example reads it from the header instead
+    for lit in re.findall(r"adf_abi_version\(\)\s*==\s*(\d+)", doc):
+        assert int(lit) == ver, f"INTEGRATION.md asserts ABI version {lit}, the header says {ver}"
+    assert "adf_abi_version() == ADF_ABI_VERSION" in doc
+    for lit in re.findall(r"ADF_ABI_VERSION[^\n]*#\s*(\d+) in this tree", doc):
+        assert int(lit) == ver
+    assert _lib.DTYPE_F32X3 == int(re.search(r"#define ADF_DTYPE_F32X3 (\d+)", hdr).group(1))
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AdfNetConfig) == 4 * (9 + 13 + 12 * 3 + 4 + 2 + 1)
     assert C.sizeof(_lib.AdfSamplerDesc) == 4 * 16

@@ -99,7 +99,11 @@ for which in (0, 1):
         prev = (3 if force_single else base + 1) if u == 0 else base + 3 + 2 * (u - 1)
         print(f"{'tile %d sub-step %2d work' % (0 if force_single else 1, u):40s}" + "".join(f"{d(S[w][base + 2 + 2 * u], S[w][prev]):7d}" for w in range(8)))
         print(f"{'                   wait + barrier':40s}" + "".join(f"{d(S[w][base + 3 + 2 * u], S[w][base + 2 + 2 * u]):7d}" for w in range(8)))
-    if any(S[w][110] for w in range(8)):
+    if any(S[w][113] for w in range(8)) and not any(S[w][114] for w in range(8)):
+        print("start-up, fine (cycles from the wave's entry): argument head used / statistics + parameter loads issued / first DMAs issued / loaded values there / table stored")
+        for w in range(8):
+            print(f"   w{w}: " + " / ".join(str(d(S[w][i], S[w][0])) for i in (110, 111, 112, 113, 1)))
+    elif any(S[w][110] for w in range(8)):
         print("fine stamps (role-split kernel): consumers = last epilogue: entry / stores issued / statistics done; producers = tile 1 block 1:")
         print("   per sub-step u: DMAs issued / prologue done / slab wait done      (cycles from the sub-step's start = previous barrier)")
         for w in range(8):
