@@ -71,6 +71,12 @@ constexpr int kRbMaxBlk = 24;
 #ifndef ADF_RB_W3
 #define ADF_RB_W3 1
 #endif
+// wave priorities (A/B builds; round 4).  The two waves of a SIMD (w and w + 4) are arbitrated by age: per-wave stamps show waves 0-3 finishing a sub-step's
+// work in ~1500 cycles and waves 4-7 in ~2150, the older four then waiting at the barrier.  1 = the younger four at priority 1 throughout;
+// 2 = the younger four at priority 2 for the second half (K steps 2-3) of every sub-step, 0 again at its barrier; 3 = as 2 with the first half instead
+#ifndef ADF_RB_PRIO
+#define ADF_RB_PRIO 0
+#endif
 
 
 struct RbBlk {
@@ -162,6 +168,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     const int srow = wave * 8 + lrow;                                            // staged row of this lane in unit 0 (+64 per unit)
     const unsigned lane_lds = (unsigned)lane * 16u;
 
+    if (ADF_RB_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (ADF_RB_PRIO == 3 && wave >= 4) __builtin_amdgcn_s_setprio(2);
     const int nblk_grid = (int)gridDim.x, bidx = (int)blockIdx.x;
     // (tiles_total <= 2^22 and the grid <= 256 blocks: the products fit 32 bits)
     const int t_lo = (int)((unsigned)bidx * (unsigned)H.tiles_total / (unsigned)nblk_grid);
@@ -452,8 +460,12 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             mid(ks);
+            if (ADF_RB_PRIO == 2 && ks == 1 && wave >= 4) __builtin_amdgcn_s_setprio(2);
+            if (ADF_RB_PRIO == 3 && ks == 1 && wave >= 4) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (ADF_RB_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
+        if (ADF_RB_PRIO == 3 && wave >= 4) __builtin_amdgcn_s_setprio(2);
     };
 
     // Prologue of block dn (stage sn) as per-gap work in the three sub-steps of the block before it.  Parts 0 / 1 take the even /
