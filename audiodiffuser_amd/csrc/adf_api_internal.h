@@ -578,7 +578,8 @@ struct Walker {
         Act qkv = linear(xn, t.qkv, nullptr, 0, false);
         tap(name + ".qkv", qkv);
         Act att = new_act(t.c, x.L);
-        if (live()) check(launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
+        if (live()) check(h->x3 ? launch_attention_x3(qkv.p, att.p, p->B, x.L, t.c, h->cfg.attention_heads, s)
+                                : launch_attention(qkv.p, att.p, h->bf16, p->B, x.L, t.c, h->cfg.attention_heads, s));
         tap(name + ".att", att);
         Act x1 = linear(att, t.proj, x.p, 0, false);
         tap(name + ".x1", x1);

@@ -14,6 +14,7 @@ struct bf16_t { uint16_t v; };
 // native 16-byte vector (HIP's uint4 struct defeats SROA in unrolled staging arrays -> scratch)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_hw_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {

@@ -71,11 +71,26 @@ constexpr int kRbMaxBlk = 24;
 #ifndef ADF_RB_W3
 #define ADF_RB_W3 1
 #endif
-// wave priorities (A/B builds; round 4).  The two waves of a SIMD (w and w + 4) are arbitrated by age: per-wave stamps show waves 0-3 finishing a sub-step's
+// wave priorities (round 4; product = 4: progress-based, 229.2 / 230.4 -> 227.5 / 229.1 ms per step in two A/B pairs; tools/micro/rb_floor.hip: the sub-step's
+// instruction mix with no data dependencies 1901 -> 1786 cycles; 1-3 measured neutral).  The two waves of a SIMD (w and w + 4) are arbitrated by age: per-wave stamps show waves 0-3 finishing a sub-step's
 // work in ~1500 cycles and waves 4-7 in ~2150, the older four then waiting at the barrier.  1 = the younger four at priority 1 throughout;
-// 2 = the younger four at priority 2 for the second half (K steps 2-3) of every sub-step, 0 again at its barrier; 3 = as 2 with the first half instead
+// 2 = the younger four at priority 2 for the second half (K steps 2-3) of every sub-step, 0 again at its barrier; 3 = as 2 with the first half instead;
+// 4 = progress-based: every wave at priority 3 - (K step) inside a sub-step (3 - quarter inside an epilogue), so the wave that is behind wins
 #ifndef ADF_RB_PRIO
-#define ADF_RB_PRIO 0
+#define ADF_RB_PRIO 4
+#endif
+// start-up fill in two parts (1, product): block 0 + its first slab are issued and waited for, the second slab and block 1 go out behind that wait; 0 = the whole
+// fill before the first barrier (A/B builds)
+#ifndef ADF_RB_FILL2
+#define ADF_RB_FILL2 1
+#endif
+// tile boundary (1, product): the slab of the new tile's second sub-step is issued BEFORE the epilogue of the finished tile (two-stage rings; the three-stage
+// rings have it in flight anyway) and the wait at the end of the new tile's first sub-step counts the epilogue's own vector-memory instructions (stores,
+// residual loads, statistics atomics) as "may still fly": vmcnt retires in issue order, so with vmcnt(2) there the first sub-step of every tile waited for the
+// epilogue's stores and fp64 atomics to be acknowledged (an atomic stays counted for ~2.8 K cycles with every CU issuing) -- the "first sub-step after an
+// epilogue costs twice a steady one" of profiles/r03_rb_launch_timeline_final.txt.  0 = as before (A/B builds)
+#ifndef ADF_RB_PRESLAB
+#define ADF_RB_PRESLAB 1
 #endif
 
 
@@ -168,6 +183,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     const int srow = wave * 8 + lrow;                                            // staged row of this lane in unit 0 (+64 per unit)
     const unsigned lane_lds = (unsigned)lane * 16u;
 
+    if (ADF_RB_PRIO == 4) __builtin_amdgcn_s_setprio(3);
     if (ADF_RB_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if (ADF_RB_PRIO == 3 && wave >= 4) __builtin_amdgcn_s_setprio(2);
     const int nblk_grid = (int)gridDim.x, bidx = (int)blockIdx.x;
@@ -460,12 +476,18 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             mid(ks);
+            if (ADF_RB_PRIO == 4) {          // progress-based: the wave that is behind wins the SIMD's arbitration
+                if (ks == 0) __builtin_amdgcn_s_setprio(2);
+                else if (ks == 1) __builtin_amdgcn_s_setprio(1);
+                else if (ks == 2) __builtin_amdgcn_s_setprio(0);
+            }
             if (ADF_RB_PRIO == 2 && ks == 1 && wave >= 4) __builtin_amdgcn_s_setprio(2);
             if (ADF_RB_PRIO == 3 && ks == 1 && wave >= 4) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ADF_RB_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
         if (ADF_RB_PRIO == 3 && wave >= 4) __builtin_amdgcn_s_setprio(2);
+        if (ADF_RB_PRIO == 4) __builtin_amdgcn_s_setprio(3);
     };
 
     // Prologue of block dn (stage sn) as per-gap work in the three sub-steps of the block before it.  Parts 0 / 1 take the even /
@@ -684,10 +706,12 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         rd(std::integral_constant<int, 0>{}, rows[0]);
         rb_static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
+            if (ADF_RB_PRIO == 4 && p > 0 && (p * 4) % P == 0) __builtin_amdgcn_s_setprio(3 - (p * 4) / P);
             if constexpr (p + 1 < P) rd(std::integral_constant<int, p + 1>{}, rows[(p + 1) & 1]);
             if constexpr (p + 2 < P) wr(std::integral_constant<int, p + 2>{});
             process(pc, rows[p & 1]);
         });
+        if (ADF_RB_PRIO == 4) __builtin_amdgcn_s_setprio(3);
     };
 
 #ifdef ADF_RB_STAMP
@@ -735,14 +759,18 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     if constexpr (!RAW) gl = gn_load(b_first, tid < ctot0 ? tid : ctot0 - 1);
     tl(111);                                           // statistics / parameter loads issued
     // (blocks 0, 1 and 2 mod nb of the first tile -- or, with two blocks per tile, block 0 of the next one -- from the preloaded entries)
+    // Round 4 (profiles/r04_rb_launch_timeline_28_1_before.txt, fine stamps): the first barrier waited for the WHOLE fill -- block 0, its slab, the second
+    // slab and block 1: 96 KB per workgroup with every CU starting at once land at ~11 B/clk/CU = 9 K cycles (the older four waves had issued by cycle
+    // 2.5 K, the younger four got their DMAs out at 6-8 K behind them) -- although the first prologue and sub-step need only block 0 and one slab
+    // (49 KB).  Those go out first and are waited for; the rest of the fill follows and lands under the first block's prologue (3.4 K cycles).
     Blk dc = make_desc_of(e_first[0]);
     advance();
     issue_a01(dc, 0u); issue_a23(dc, 0u); issue_halo(dc, 0u);
     issue_w(dc.w, 0);
-    if (W3) issue_w(dc.w + (unsigned)(1 / NH) * slab + (unsigned)(1 % NH) * (unsigned)kPpWStage, 1);     // (a tile starts with a 3-tap block: its second sub-step)
+    if (W3 && !ADF_RB_FILL2) issue_w(dc.w + (unsigned)(1 / NH) * slab + (unsigned)(1 % NH) * (unsigned)kPpWStage, 1);     // (a tile starts with a 3-tap block: its second sub-step)
     Blk d1 = make_desc_of(e_first[1]);
     advance();
-    issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage);
+    if (!ADF_RB_FILL2) { issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage); }
     Blk d2 = make_desc_of(d_k == 0 ? e_first[0] : e_first[2]);
     advance();
     tl(112);                                           // first DMAs issued
@@ -755,6 +783,10 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
     kstamp(12);
     tl(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ADF_RB_FILL2) {
+        if (W3) issue_w(dc.w + (unsigned)(1 / NH) * slab + (unsigned)(1 % NH) * (unsigned)kPpWStage, 1);
+        issue_a01(d1, (unsigned)kPpAStage); issue_a23(d1, (unsigned)kPpAStage); issue_halo(d1, (unsigned)kPpAStage);
+    }
     __syncthreads();
     kstamp(13);
     tl(2);
@@ -772,6 +804,8 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                 for (int e = 0; e < 16; ++e) acc[hf][i][j][e] = bias_r[j];
     }
     if (RAW) zero_fill(dc, 0u); else transform_all(dc, 0u);
+    // (FILL2: block 1 and the second slab, issued behind the first wait, are read from the head of the first sub-step on -- part_begin)
+    if (ADF_RB_FILL2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     kstamp(14);
     tl(3);
@@ -828,6 +862,22 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto w_rotate = [&]() __attribute__((always_inline)) { const unsigned t = ws0; ws0 = ws1; ws1 = ws2; ws2 = t; };
+    // any count up to 31 (once per tile: a branch tree is fine here); a smaller count than asked for is always safe
+    auto wait_upto = [&](int n) __attribute__((always_inline)) {
+#define ADF_RB_WCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        switch (n < 0 ? 0 : (n > 31 ? 31 : n)) {
+            ADF_RB_WCASE(0) ADF_RB_WCASE(1) ADF_RB_WCASE(2) ADF_RB_WCASE(3) ADF_RB_WCASE(4) ADF_RB_WCASE(5) ADF_RB_WCASE(6) ADF_RB_WCASE(7)
+            ADF_RB_WCASE(8) ADF_RB_WCASE(9) ADF_RB_WCASE(10) ADF_RB_WCASE(11) ADF_RB_WCASE(12) ADF_RB_WCASE(13) ADF_RB_WCASE(14) ADF_RB_WCASE(15)
+            ADF_RB_WCASE(16) ADF_RB_WCASE(17) ADF_RB_WCASE(18) ADF_RB_WCASE(19) ADF_RB_WCASE(20) ADF_RB_WCASE(21) ADF_RB_WCASE(22) ADF_RB_WCASE(23)
+            ADF_RB_WCASE(24) ADF_RB_WCASE(25) ADF_RB_WCASE(26) ADF_RB_WCASE(27) ADF_RB_WCASE(28) ADF_RB_WCASE(29) ADF_RB_WCASE(30)
+            default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+        }
+#undef ADF_RB_WCASE
+    };
+    // vector-memory instructions this wave issued in the epilogue that has just run (0 = none pending): P stores, P residual loads, 2 statistics atomics per N half.
+    // Consumed by the wait at the end of the tile's first sub-step.
+    int epi_vm = 0;
+    bool slab1_pre = false;                            // two-stage ring: the slab of the tile's second sub-step went out ahead of the epilogue
     int aq_prev = 0;                                   // activation DMAs this wave issued in the previous sub-step (behind its slab)
     // one 3-tap block whose first sub-step reads W stage WP; the prologue of block g+1 (any kind) rides in its gaps
     auto block3 = [&](auto wpc) __attribute__((always_inline)) {
@@ -862,7 +912,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
                     [&](int ks) __attribute__((always_inline)) {
                         if (ks == 0) {
                             if (W3) wq = issue_ahead(u + 2, U, has1, has2);
-                            else if (u + 1 < U) issue_w(next_slab(u + 1, 3), (WP + u + 1) & 1);
+                            else if (u + 1 < U) { if (!(u == 0 && slab1_pre)) issue_w(next_slab(u + 1, 3), (WP + u + 1) & 1); }
                             else if (has1) issue_w(d1.w, (WP + u + 1) & 1);
                         } else if (ks == 1 && has2) {
                             if (u == 0) { issue_halo(d2, sa2); issue_a01(d2, sa2); aq = (wave == 0 && d2.taps == 3) ? 3 : 2; }
@@ -875,7 +925,13 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
             tl(4 + tseq * 26 + 2 + 2 * tl_sub);
 #endif
             // the next slab has landed; the activation pieces issued in this sub-step (the 2 youngest) may still fly
-            if (W3) {
+            if (u == 0 && epi_vm > 0) {
+                // first sub-step of a tile behind an epilogue: the next slab was issued BEFORE the epilogue's stores / residual loads / atomics, which
+                // may all still fly (they are younger), as may what this sub-step issued
+                wait_upto(epi_vm + (W3 ? aq_prev + wq + aq : aq));
+                epi_vm = 0; slab1_pre = false;
+                if (W3) { aq_prev = aq; w_rotate(); }
+            } else if (W3) {
                 // in flight behind the next sub-step's slab: the activations that followed it, this sub-step's slab and activations; the block's
                 // last sub-step also ends the flight of block g+2's activations (their prologue starts with the next sub-step)
                 wait_n((u == U - 1 ? 0 : aq_prev) + wq + aq);
@@ -954,6 +1010,14 @@ __global__ void __launch_bounds__(512) conv_gemm_rb_kernel(const RbArgs a) {
 #ifdef ADF_RB_STAMP
             if (tseq == 1) kstamp(15);
 #endif
+            if (ADF_RB_PRESLAB) {
+                // (a tile that ended with 1-tap blocks: the activations of the new tile's SECOND block went out in its last sub-step and are read from the
+                //  head of the first block on -- the wait block3 does for that, taken here, ahead of the epilogue's stores)
+                if (prev_one) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); aq_prev = 0; prev_one = false; }
+                // (two-stage ring: the stage the second sub-step's slab goes to was read last by the finished tile's last sub-step, whose barrier has passed)
+                if (!W3) { issue_w(next_slab(1, 3), 1); slab1_pre = true; }
+                epi_vm = NH * 4 * MH * (H.res != nullptr ? 2 : 1) + (H.stats != nullptr ? 2 * NH : 0);
+            }
             epilogue(tile_of(tseq - 1), cur_tile.n0, sa2);       // (sa2: the stage of the previous tile's last block, not yet refilled)
         }
 #ifdef ADF_RB_TL

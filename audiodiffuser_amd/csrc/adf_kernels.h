@@ -27,6 +27,8 @@ const char* launch_ln_rows(const void* x, void* y, int bf16, long long rows, int
 
 // Multi-head self-attention on a fused qkv tensor [B][N][3C] (q | k | v), out [B][N][C].
 const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N, int C, int heads, hipStream_t s);
+// split-bf16 mode (fp32 tensors; ADF_DTYPE_F32X3): MFMA attention with bf16 hi + lo operands where it applies, else launch_attention(.., 0, ..)
+const char* launch_attention_x3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s);
 
 // Input transform Conv1d(in_ch -> nf, k=wl, stride, pad) on the fp32 waveform x[B][in_ch][L], with the
 // EDM c_in scaling fused: out NLC [B][L/stride][nf].  coef may be null (c_in = 1).

@@ -529,6 +529,150 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
     }
 }
 
+// Self-attention of the split-bf16 mode (ADF_DTYPE_F32X3: fp32 q | k | v rows in, fp32 out), head dim 32, N <= 256 keys.  Same plan as the bf16 kernel above
+// -- S^T = K Q^T on the matrix cores with the query on the lane (lane-local softmax), P^T reused as the B operand of O^T += V^T P^T -- with every operand as
+// bf16 hi + lo and three MFMAs per product (lo hi, hi lo, hi hi; adf_common.h).  K (rows of 64 B hi / 64 B lo, pitch 80: conflict-free ds_read_b128 with the
+// key on the lane) and V^T (vt[d][key], pitch 2 N + 8 as above) of a (sample, head) pair are split ONCE, while they are staged into LDS by the waves that share
+// the pair; Q is split in registers, the probabilities after the exp2.  It replaces the one-query-per-lane vector kernel (attention_kernel<float, 32>: 430 us per
+// launch at 256 tokens and batch 64 = 11 % of a step of this mode).
+__global__ void __launch_bounds__(256) attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int N, int C, int heads,
+                                                           float scale_log2e, int qrep) {
+    constexpr int D = 32, KP = 80;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qtiles = (N + 31) >> 5;
+    const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);   // waves that share one (b, head) pair
+    const int ppb = 4 / wpp;                                    // pairs per block
+    const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
+    const int qg = blockIdx.x % qgroups, pg = blockIdx.x / qgroups;
+    const int pair = pg * ppb + wave / wpp;
+    const bool pair_ok = pair < B * heads;
+    const int pc = pair_ok ? pair : 0;
+    const int b = pc / heads, hd = pc - b * heads;
+    const size_t rowstride = (size_t)3 * C;
+    const float* base = qkv + (size_t)b * N * rowstride + (size_t)hd * D;
+    const int npad = qtiles * 32;
+    const int vpitch = npad * 2 + 8;
+    const size_t pair_bytes = (size_t)2 * npad * KP + (size_t)2 * D * vpitch;
+    char* kh = smem + (size_t)(wave / wpp) * pair_bytes;
+    char* kl = kh + (size_t)npad * KP;
+    char* vth = kl + (size_t)npad * KP;
+    char* vtl = vth + (size_t)D * vpitch;
+    {
+        const int tl = (wave % wpp) * 64 + lane, nthr = wpp * 64;
+        for (int idx = tl; idx < npad * 8; idx += nthr) {
+            const int key = idx >> 3, c = idx & 7;                  // 16-byte chunk c: head dims 4 c .. 4 c + 3
+            const int krow = key < N ? key : N - 1;                 // padded keys: any finite value (their probability is 0)
+            const f32x4_hw_t kv = *(const f32x4_hw_t*)(base + (size_t)krow * rowstride + C + c * 4);
+            const f32x4_hw_t vv = *(const f32x4_hw_t*)(base + (size_t)krow * rowstride + 2 * C + c * 4);
+            const float kf[4] = {kv.x, kv.y, kv.z, kv.w}, vf[4] = {vv.x, vv.y, vv.z, vv.w};
+            u32x2_t hi, lo;
+            split_bf16x4(kf, hi, lo);
+            *(u32x2_t*)(kh + key * KP + c * 8) = hi;
+            *(u32x2_t*)(kl + key * KP + c * 8) = lo;
+            split_bf16x4(vf, hi, lo);
+            const unsigned hw[2] = {hi.x, hi.y}, lw[2] = {lo.x, lo.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *(unsigned short*)(vth + (c * 4 + j) * vpitch + key * 2) = (unsigned short)((j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu));
+                *(unsigned short*)(vtl + (c * 4 + j) * vpitch + key * 2) = (unsigned short)((j & 1) ? (lw[j >> 1] >> 16) : (lw[j >> 1] & 0xffffu));
+            }
+        }
+    }
+    __syncthreads();
+    if (!pair_ok) return;
+    const char* vrow_h = vth + r * vpitch + hh * 8;     // this lane's head dim, first key group of a 16-key step
+    const char* vrow_l = vtl + r * vpitch + hh * 8;
+    for (int rep = 0; rep < qrep; ++rep) {
+        const int qt = (qg * qrep + rep) * wpp + wave % wpp;
+        if (qt >= qtiles) break;
+        const int query = qt * 32 + r;
+        const int qrow = query < N ? query : N - 1;
+        att_bf16x8_t qh[2], ql[2];                       // Q^T fragments (B operand): head dims 16 ks + 8 hh .. + 7 of this lane's query
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* qp = base + (size_t)qrow * rowstride + ks * 16 + hh * 8;
+            const f32x4_hw_t a0 = *(const f32x4_hw_t*)qp, a1 = *(const f32x4_hw_t*)(qp + 4);
+            const float f0[4] = {a0.x, a0.y, a0.z, a0.w}, f1[4] = {a1.x, a1.y, a1.z, a1.w};
+            u32x2_t h0, l0, h1, l1;
+            split_bf16x4(f0, h0, l0);
+            split_bf16x4(f1, h1, l1);
+            qh[ks] = __builtin_bit_cast(att_bf16x8_t, u32x4_t{h0.x, h0.y, h1.x, h1.y});
+            ql[ks] = __builtin_bit_cast(att_bf16x8_t, u32x4_t{l0.x, l0.y, l1.x, l1.y});
+        }
+        att_f32x16_t o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        float m = -INFINITY, l = 0.f;                   // running maximum in the scaled log2 domain (s * c), running sum
+        for (int kt = 0; kt < qtiles; ++kt) {
+            att_f32x16_t st;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const att_bf16x8_t fh = *(const att_bf16x8_t*)(kh + (kt * 32 + r) * KP + (ks * 2 + hh) * 16);
+                const att_bf16x8_t fl = *(const att_bf16x8_t*)(kl + (kt * 32 + r) * KP + (ks * 2 + hh) * 16);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[ks], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[ks], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[ks], st, 0, 0, 0);
+            }
+            if (kt == qtiles - 1 && (N & 31)) {               // uniform: the partial key tile
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    st[e] = key < N ? st[e] : -INFINITY;
+                }
+            }
+            float mt = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+#pragma unroll
+            for (int e = 4; e < 16; e += 2) mt = fmaxf(mt, fmaxf(st[e], st[e + 1]));
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+            if (!__all(mt <= m)) {                            // some query's maximum grew: rescale (else alpha == 1 exactly)
+                const float mn = fmaxf(m, mt);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                l *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] *= alpha;
+                m = mn;
+            }
+            float psum = 0.f;
+            const float negm = -m;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, negm)); st[e] = pv; psum += pv; }
+            l += psum;
+#pragma unroll
+            for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                float pf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = st[8 * sgrp + j];
+                u32x2_t h0, l0, h1, l1;
+                split_bf16x4(pf, h0, l0);
+                split_bf16x4(pf + 4, h1, l1);
+                const att_bf16x8_t ph = __builtin_bit_cast(att_bf16x8_t, u32x4_t{h0.x, h0.y, h1.x, h1.y});
+                const att_bf16x8_t pl = __builtin_bit_cast(att_bf16x8_t, u32x4_t{l0.x, l0.y, l1.x, l1.y});
+                // V^T fragments of this lane's head dim: elements j = 0 .. 3 = keys 16 s + 4 h + j, j = 4 .. 7 = keys 16 s + 8 + 4 h + (j - 4)
+                const int ko = (kt * 32 + 16 * sgrp) * 2;
+                const u32x2_t a0 = *(const u32x2_t*)(vrow_h + ko), a1 = *(const u32x2_t*)(vrow_h + ko + 16);
+                const u32x2_t b0 = *(const u32x2_t*)(vrow_l + ko), b1 = *(const u32x2_t*)(vrow_l + ko + 16);
+                const att_bf16x8_t vh = __builtin_bit_cast(att_bf16x8_t, u32x4_t{a0.x, a0.y, a1.x, a1.y});
+                const att_bf16x8_t vl = __builtin_bit_cast(att_bf16x8_t, u32x4_t{b0.x, b0.y, b1.x, b1.y});
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        if (query < N) {
+            float* orow = out + ((size_t)b * N + query) * C + (size_t)hd * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)      // registers 4g .. 4g+3 = head dims 8g + 4hh .. +3
+                *(f32x4_hw_t*)(orow + 8 * g + 4 * hh) = f32x4_hw_t{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+        }
+    }
+}
+
 template <typename T>
 static const char* attention_dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
     const int dh = C / heads;
@@ -576,6 +720,33 @@ const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N,
         return ADF_LAUNCH_CHECK("attention_mfma");
     }
     return bf16 ? attention_dispatch<bf16_t>(qkv, out, B, N, C, heads, s) : attention_dispatch<float>(qkv, out, B, N, C, heads, s);
+}
+
+// split-bf16 mode (fp32 tensors): the MFMA kernel above where it applies (head dim 32, <= 256 tokens), else the fp32 vector kernel
+const char* launch_attention_x3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
+    if (C % heads) return "attention: C % heads != 0";
+    static int use = -1;
+    if (use < 0) use = adf_route_switch("ADF_ATT_X3", 1);        // 0: the vector kernel (route test)
+    if (!use || C / heads != 32 || N < 1 || N > 256 || C % 4) return launch_attention(qkv, out, 0, B, N, C, heads, s);
+    const int qtiles = (N + 31) / 32;
+    const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);
+    const int ppb = 4 / wpp;
+    const int qrep = qtiles > wpp ? (qtiles + wpp - 1) / wpp : 1;          // every pair is staged once: its waves walk all of its query tiles
+    const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
+    const long long blocks = (long long)((B * heads + ppb - 1) / ppb) * qgroups;
+    const size_t npad = (size_t)qtiles * 32;
+    const size_t lds = (size_t)ppb * (2 * npad * 80 + 2 * 32 * (npad * 2 + 8));
+    if (lds > 80 * 1024 || blocks > 0x7fffffffLL) return launch_attention(qkv, out, 0, B, N, C, heads, s);
+    static bool attr_done[kMaxDevices] = {};
+    bool& attr = attr_done[current_device()];
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)attention_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+            return "attention_x3: hipFuncSetAttribute failed";
+        attr = true;
+    }
+    const float sl2e = (float)(1.4426950408889634 / sqrt(32.0));
+    hipLaunchKernelGGL(attention_x3_kernel, dim3((unsigned)blocks), dim3(256), lds, s, (const float*)qkv, (float*)out, B, N, C, heads, sl2e, qrep);
+    return ADF_LAUNCH_CHECK("attention_x3");
 }
 
 // =====================================================================================================
