@@ -644,6 +644,11 @@ const char* launch_conv2d(const Conv2dArgs& a, int bf16, hipStream_t s) {
         if (th8w1 && a.H % 8 == 0 && px / 256 * ny >= 256) return c2_trace("t8", a), bf16 ? launch_conv2d_tile<bf16_t, 8, 1>(a, s) : launch_conv2d_tile<float, 8, 1>(a, s);
         static const int wr2 = (int)adf_tuning("ADF_CONV2D_WR2", 0);     // 64 x 64 wave tiles on four waves (A/B runs)
         if (wr2 && a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4x2", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 2>(a, s) : launch_conv2d_tile<float, 4, 2>(a, s);
+        // (A/B: 160-pixel tiles also where 128-pixel ones divide the image, for convs of at most this many input channels -- few K iterations per tile, so the
+        //  tile's start-up and epilogue weigh most)
+        static const int prefer5 = (int)adf_tuning("ADF_CONV2D_PREFER5", 0);
+        if (prefer5 && a.cin <= prefer5 && a.H % 5 == 0 && px / 160 * ny >= 128)
+            return c2_trace("t5", a), bf16 ? launch_conv2d_tile<bf16_t, 5, 1>(a, s) : launch_conv2d_tile<float, 5, 1>(a, s);
         if (a.H % 4 == 0 && px / 128 * ny >= 128) return c2_trace("t4", a), bf16 ? launch_conv2d_tile<bf16_t, 4, 1>(a, s) : launch_conv2d_tile<float, 4, 1>(a, s);
         // heights such as 10 (the 80-row mel block three levels down): 160-pixel workgroups instead of 64-pixel ones -- 2.5 x fewer passes over the weights
         static const int th5 = (int)adf_tuning("ADF_CONV2D_TH5", 1);
