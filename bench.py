@@ -373,6 +373,18 @@ def pmc_traffic(a, level: int, conv: int):
         seq = [v for _, v in sorted(per.items(), key=lambda kv: int(kv[0]))]
         if len(seq) < 4:
             return None, f"no matching dispatch in the {counter} pass"
+        if a.config == "c5":
+            # round 4: the MEAN over the residual layers of one network pass (the child's eager pass: its first `residual_layers` dispatches), not the one
+            # replayed layer: a layer's traffic depends on its dilation and position (profiles/r04_c5_traffic_per_layer.txt: 9.0 GB at dilation 1-64 to
+            # 10.6 GB at dilation 2048 -- three disjoint windows, y is read twice from memory -- against 8.67 GB algorithmic), and the layers the replay
+            # picks as "slowest" trade places from run to run: that was the 9.6-11.1 GB spread of the round-3 lines
+            import audiodiffuser_amd as A_
+            nl = A_.config_c5().residual_layers
+            if len(seq) < nl:
+                return None, f"fewer than {nl} layer dispatches in the {counter} pass"
+            first = [v for _, v in seq[:nl]]
+            vals[counter] = (sum(first) / nl, f"mean over the {nl} residual layers of one pass (min {min(first):.0f} KB, max {max(first):.0f} KB)")
+            continue
         tail = seq[-4:]
         if len({nm for nm, _ in tail}) != 1:
             return None, f"the {counter} pass ended on mixed kernels"
