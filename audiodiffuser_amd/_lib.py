@@ -69,7 +69,7 @@ class AdfAdmConfig(C.Structure):
 class AdfRunCounters(C.Structure):
     """``adf_run_counters`` of include/audiodiffuser_amd.h."""
     _fields_ = [("sampler_runs", C.c_int64), ("sampler_evals", C.c_int64), ("graph_captures", C.c_int64),
-                ("graph_replays", C.c_int64), ("denoise_calls", C.c_int64), ("net_passes", C.c_int64), ("device_faults", C.c_int64)]
+                ("graph_replays", C.c_int64), ("denoise_calls", C.c_int64), ("net_passes", C.c_int64)]
 
 
 FLAG_NEAREST_UPSAMPLE = 2  # ADF_FLAG_NEAREST_UPSAMPLE

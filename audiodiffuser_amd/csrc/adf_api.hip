@@ -103,10 +103,6 @@ int adf_create(const adf_net_config* cfg, adf_handle** out) {
     h->esz = h->bf16 ? 2 : 4;
     h->kc = kRowBytes / h->esz;
     if (build_weights(h)) { g_create_error = h->err; adf_destroy(h); return 1; }
-    if (h->bf16) {                  // (not inside a stream capture later: allocated here)
-        h->chain_faults = (unsigned*)dalloc(h, 256);
-        if (!h->chain_faults) { g_create_error = "device allocation failed"; adf_destroy(h); return 1; }
-    }
     *out = h;
     return 0;
 }
@@ -487,13 +483,6 @@ int adf_abi_version(void) { return ADF_ABI_VERSION; }
 int adf_get_counters(const adf_handle* h, adf_run_counters* out) {
     if (!h || !out) return 1;
     *out = h->ctr;
-    out->device_faults = 0;
-    if (h->chain_faults) {          // the handle has launched the chained resblock kernel: its fault counter lives on the device
-        DeviceScope scope(h);
-        unsigned v = 0;
-        if (!scope.ok || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, h->chain_faults, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-        out->device_faults = (int64_t)v;
-    }
     return 0;
 }
 

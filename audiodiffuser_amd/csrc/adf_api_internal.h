@@ -183,7 +183,6 @@ struct adf_handle {
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     adf_run_counters ctr{};             // what the device loop has done so far (adf_get_counters): lets a test tell it from a host-side loop
-    unsigned* chain_faults = nullptr;   // device counter of timed-out sibling barriers (adf_resblock_split.h, chained kernel); allocated at adf_create (bf16 mode)
 };
 
 namespace adf_api {
@@ -356,37 +355,6 @@ struct Walker {
     int film2_bstride = 0;
     const float* film = nullptr;        // time part: Plan::film, or the evaluation's row of Plan::film_all
 
-    // short-level resblocks waiting to be launched as one chain (adf_resblock_split.h): consecutive blocks of one level, at most kRbChainMax
-    struct PendingRb { RbSplitArgs sa; int ntok, cin; };
-    std::vector<PendingRb> chain;
-    void flush_chain() {
-        if (chain.empty()) return;
-        const int ntok = chain[0].ntok, B = p->B;
-        static int rb_chain = -1;
-        // 1: the chained launch.  OFF in the product -- measured (round 4, profiles/r04_ab_resblock_chain.txt): correct (bit for bit the two-launch form, no timed-out
-        // barrier) but 238.7-239.3 against 236.4-237.2 ms per step: the 4-workgroup barriers sit across XCDs (workgroups are dealt to the 8 XCDs round-robin), an
-        // agent-scope atomic round trip + poll costs what a launch boundary inside a captured graph costs (~2-3 us), and with agent-scope FENCES (whole-L2 invalidate)
-        // the chained kernels ran 2.7 x slower than the launches they replace.  Kept as a route for the test and as the record of why the "one persistent launch for the
-        // bottom of the U" of VERDICT r3 item 3 does not pay on this part.
-        if (rb_chain < 0) rb_chain = adf_route_switch("ADF_RB_CHAIN", 0);
-        unsigned* flags = (unsigned*)alloc_stats();          // [B] arrival counters in the statistics arena: zero at every network pass (allocated on both routes: same plan)
-        bool chained = false;
-        if (live() && rb_chain) {
-            RbChainArgs c;
-            memset(&c, 0, sizeof(c));
-            c.nblk = (int)chain.size();
-            for (int k = 0; k < c.nblk; ++k) { c.blk[k] = chain[k].sa; c.blk[k].f.B = B; c.cin[k] = chain[k].cin; }
-            c.flags = flags; c.faults = h->chain_faults;
-            const char* err = nullptr;
-            const int rc = h->chain_faults ? launch_resblock_chain(c, B, ntok, s, &err) : 1;
-            if (rc == 0) chained = true;
-            else if (rc != 1) check(err ? err : "resblock_chain failed");
-        }
-        if (live() && !chained)
-            for (const PendingRb& b : chain) check(launch_resblock_split(b.sa, B, b.ntok, b.cin, s));
-        chain.clear();
-    }
-
     void check(const char* e) { if (e && !bad) { bad = true; h->err = e; } }
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
@@ -417,7 +385,6 @@ struct Walker {
     }
     double* ensure_stats(Act& t) {
         if (!t.stats) {
-            flush_chain();
             t.stats = alloc_stats();
             if (live()) check(launch_gn_stats(t.p, h->bf16, p->B, t.L, t.C, h->cfg.resnet_groups, t.stats, s));
         }
@@ -444,7 +411,6 @@ struct Walker {
         return sg;
     }
     void run_gemm(GemmArgs& g, Act& out, bool want_stats) {
-        flush_chain();
         const bool ask = want_stats && can_fuse_stats(out.C);      // also for the phase-scattered transposed convs
         if (ask) {
             out.stats = alloc_stats();
@@ -508,19 +474,14 @@ struct Walker {
                 Act hact = new_act(r.cout, x.L);
                 RbSplitArgs sa;
                 sa.f = fa; sa.hact = (bf16_t*)hact.p;
-                // not launched here: consecutive blocks of a level go out as ONE chained launch (flush_chain: at the third block, and from every
-                // other launch site of the walker / the end of a level in forward())
-                if (!chain.empty() && chain[0].ntok != x.L) flush_chain();
-                chain.push_back({sa, x.L, ctot});
-                if ((int)chain.size() == kRbChainMax) flush_chain();
-            } else { flush_chain(); if (live()) check(launch_resblock_small(fa, B, x.L, ctot, s)); }
+                if (live()) check(launch_resblock_split(sa, B, x.L, ctot, s));
+            } else if (live()) check(launch_resblock_small(fa, B, x.L, ctot, s));
             RbRec rec{name, GemmArgs{}, GemmArgs{}, r.cin, r.cout, x.L};
             rec.g1.nseg = 0;                               // marks a fused block for adf_bench_resblock (keeps the block numbering)
             p->rbs.push_back(rec);
             tap(name, y);
             return y;
         }
-        flush_chain();
         Act h1 = new_act(r.cout, x.L);
         GemmArgs g1 = gemm_base(h1, x.L, x.L, r.c1);
         if (short_level) {
@@ -567,7 +528,6 @@ struct Walker {
     }
 
     Act transformer(const std::string& name, Act& x, const TrW& t) {
-        flush_chain();
         const long long rows = (long long)p->B * x.L;
         // short levels in bf16 mode: the whole block in one launch (adf_transformer.h); ADF_TR_FUSED=0 keeps the nine launches
         static int tr_fused = -1;

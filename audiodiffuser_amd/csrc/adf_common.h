@@ -134,29 +134,6 @@ __device__ __forceinline__ const double* gn_select_ptr(bool second, const double
     asm volatile("" : "+s"(d));
     return (const double*)((const char*)p0 + (second ? d : 0ll));
 }
-// Agent-scope ("sc1") accesses for data that workgroups on different XCDs exchange INSIDE one launch (adf_resblock_split.h, chained kernel): each XCD has its
-// own L2, which is only written back / invalidated at kernel boundaries; a relaxed atomic at agent scope goes to the level all XCDs share.  No fence is used
-// for that exchange: an agent-scope acquire invalidates the XCD's whole L2 -- measured, the chained kernel with fences ran 2.7 x SLOWER than the launches it
-// replaced (every weight stream then came from memory).
-__device__ __forceinline__ u32x4_t coh_load16(const void* p) {
-    const unsigned long long* q = (const unsigned long long*)p;
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return u32x4_t{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
-}
-__device__ __forceinline__ void coh_store16(void* p, const u32x4_t& v) {
-    unsigned long long* q = (unsigned long long*)p;
-    __hip_atomic_store(q, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double coh_load_f64(const double* p) {
-    return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void coh_store_f64(double* p, double v) {
-    __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <bool COH = false>      // COH: the statistics were written by sibling workgroups of this launch (agent-scope loads)
 __device__ __forceinline__ GnRaw gn_affine_load(const GnFinalizeArgs& a, int b, int c) {
     const int ctot = a.c0 + a.c1;
     const int gs = ctot / a.G;
@@ -171,9 +148,7 @@ __device__ __forceinline__ GnRaw gn_affine_load(const GnFinalizeArgs& a, int b, 
     // one or two fine groups per coarse group in every shape served (one source, or two equal ones): both loads go out together; more in a loop
     const double* p0 = st + ((size_t)b * a.G + g0) * 2;
     const double* p1 = g0 + 1 < g1 ? p0 + 2 : p0;
-    double s0, q0, s1v, q1v;
-    if constexpr (COH) { s0 = coh_load_f64(p0); q0 = coh_load_f64(p0 + 1); s1v = coh_load_f64(p1); q1v = coh_load_f64(p1 + 1); }
-    else { s0 = p0[0]; q0 = p0[1]; s1v = p1[0]; q1v = p1[1]; }
+    const double s0 = p0[0], q0 = p0[1], s1v = p1[0], q1v = p1[1];
     const float gamma = a.gamma[c], beta = a.beta[c];
     const bool hf = a.film != nullptr, hf2 = hf && a.film2 != nullptr;                 // uniform
     int cd = c;                                        // opaque copy of the index: gamma[cd] through the dummy pointer must not be folded into the gamma load

@@ -165,7 +165,6 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         }
         skips_list.pop_back();
         if (up.attn) x = W.transformer("up" + std::to_string(u) + ".attn", x, up.tr);
-        W.flush_chain();
         const int f = up.factor;
         Act y = W.new_act(up.cout, x.L * f);
         bool done = false;
@@ -216,7 +215,6 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         W.tap("up" + std::to_string(u) + ".conv", y);
         x = y;
     }
-    W.flush_chain();
     if (W.live())
         W.check(launch_to_out(x.p, h->to_out_w, io.out, h->bf16, B, c.out_channels, x.L, c.num_filters, c.window_length, c.stride, pad,
                               io.mode, io.x_noisy, io.coef, io.coef_bstride, s));

@@ -23,7 +23,8 @@ struct RbSplitArgs {
     bf16_t* hact;             // [B][N][256]: silu(FiLM(GN2(h1))) as conv2 reads it
 };
 
-// the weight fragments of one wave for one phase: requested by rb_split_load_w (in the chained kernel: ahead of the barrier that precedes the phase)
+// the weight fragments of one wave for one phase, requested by rb_split_load_w ahead of everything else (round 4 split the kernel body into load / run so that
+// tools/experiments/adf_resblock_chain.h -- several blocks in one launch, measured slower -- could request them ahead of its barriers)
 template <int NTOK, int CIN, int PHASE>
 struct RbSplitWf {
     static constexpr int CO = 256;
@@ -53,8 +54,7 @@ __device__ __forceinline__ void rb_split_load_w(const RbSplitArgs& aa, int bq, R
 }
 
 // one phase of one block for workgroup `bq` (= sample * 4 + column quarter); smem: resblock_split_lds(NTOK, CIN) bytes
-// COH: the operand rows, statistics and outputs are exchanged with sibling workgroups inside this launch (chained kernel): agent-scope accesses
-template <int NTOK, int CIN, int PHASE, bool COH = false>
+template <int NTOK, int CIN, int PHASE>
 __device__ __forceinline__ void rb_split_run(const RbSplitArgs& aa, char* smem, int bq, const RbSplitWf<NTOK, CIN, PHASE>& Wreg) {
     const RbFusedArgs& a = aa.f;
     constexpr int CO = 256;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void rb_split_run(const RbSplitArgs& aa, char* smem, 
         ((float*)otile)[which * 64 + c] = v;
     }
     GnRaw gr = {};
-    if constexpr (PHASE == 1) gr = gn_affine_load<COH>(a.gn1, b, tid < CIN ? tid : 0);
+    if constexpr (PHASE == 1) gr = gn_affine_load(a.gn1, b, tid < CIN ? tid : 0);
     // ---- the rows this phase multiplies: all pieces of a thread in flight together ------------------------------------------------
     u32x4_t xv[PHASE == 1 ? XT : XT];
     constexpr int HT = NTOK * (CO / 8) / 512 > 0 ? NTOK * (CO / 8) / 512 : 1;
@@ -122,7 +122,7 @@ __device__ __forceinline__ void rb_split_run(const RbSplitArgs& aa, char* smem, 
             const int row = idx / CPR, cc = idx % CPR;
             const bool live = idx < NTOK * CPR;
             const long long off = ((long long)(live ? row : 0) * 256 + (cc < 32 ? cc : cc - 32) * 8) * 2 + (cc < 32 ? 0ll : dskip);
-            xv[k] = COH ? coh_load16((const char*)xb + off) : *(const u32x4_t*)((const char*)xb + off);
+            xv[k] = *(const u32x4_t*)((const char*)xb + off);
         }
     }
     if constexpr (PHASE == 2) {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void rb_split_run(const RbSplitArgs& aa, char* smem, 
         for (int k = 0; k < HT; ++k) {
             const int idx = tid + k * 512;
             const bool live = idx < NTOK * (CO / 8);
-            hv[k] = COH ? coh_load16(hb + (size_t)(live ? idx : 0) * 8) : *(const u32x4_t*)(hb + (size_t)(live ? idx : 0) * 8);
+            hv[k] = *(const u32x4_t*)(hb + (size_t)(live ? idx : 0) * 8);
         }
     }
     __syncthreads();                                      // the staged parameter vectors are in LDS
@@ -302,13 +302,7 @@ __device__ __forceinline__ void rb_split_run(const RbSplitArgs& aa, char* smem, 
                 for (int e = 0; e < 16; ++e) {
                     const int row = row_of(i, e);
                     float y = acc[i][e];
-                    if (!a.wr && row < NTOK) {
-                        if constexpr (COH) {         // (the aligned dword that holds the element)
-                            const size_t ei = (size_t)row * 256 + col;
-                            const unsigned w = __hip_atomic_load((const unsigned*)xb + (ei >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            y += __uint_as_float((ei & 1) ? (w & 0xffff0000u) : (w << 16));
-                        } else y += bf16_to_f32(xb[(size_t)row * 256 + col].v);
-                    }
+                    if (!a.wr && row < NTOK) y += bf16_to_f32(xb[(size_t)row * 256 + col].v);
                     const unsigned short qv = f32_to_bf16_hw(y + bias);
                     const float v = bf16_to_f32(qv);
                     if (row < NTOK) {
@@ -322,8 +316,7 @@ __device__ __forceinline__ void rb_split_run(const RbSplitArgs& aa, char* smem, 
                 for (int o = 32; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
                 if (lane == 0) {
                     double* sp = a.stats + ((size_t)b * 8 + q * 2 + ct) * 2;
-                    if constexpr (COH) { coh_store_f64(sp, d1); coh_store_f64(sp + 1, d2); }
-                    else { sp[0] = d1; sp[1] = d2; }
+                    sp[0] = d1; sp[1] = d2;
                 }
             }
         }
@@ -333,8 +326,7 @@ __device__ __forceinline__ void rb_split_run(const RbSplitArgs& aa, char* smem, 
         bf16_t* const ob = (PHASE == 1 ? aa.hact : a.out) + (size_t)b * NTOK * CO + q * 64;
         for (int idx = tid; idx < NTOK * 8; idx += 512) {
             const int row = idx >> 3, cc = idx & 7;
-            if constexpr (COH) coh_store16(ob + (size_t)row * CO + cc * 8, *(const u32x4_t*)(otile + row * 128 + cc * 16));
-            else *(u32x4_t*)(ob + (size_t)row * CO + cc * 8) = *(const u32x4_t*)(otile + row * 128 + cc * 16);
+            *(u32x4_t*)(ob + (size_t)row * CO + cc * 8) = *(const u32x4_t*)(otile + row * 128 + cc * 16);
         }
     }
 }
@@ -345,72 +337,6 @@ __global__ void __launch_bounds__(512) resblock_split_kernel(const RbSplitArgs a
     RbSplitWf<NTOK, CIN, PHASE> W;
     rb_split_load_w<NTOK, CIN, PHASE>(aa, (int)blockIdx.x, W);
     rb_split_run<NTOK, CIN, PHASE>(aa, smem, (int)blockIdx.x, W);
-}
-
-// ---- the blocks of one level chained in ONE launch (round 4) ----------------------------------------------------------------------------------------
-// Up to three consecutive resblocks of a level (down: 2, bottleneck: 1, up: 3) as one launch of the same B x 4 workgroups: the exchange between a block's
-// two phases and between consecutive blocks -- everything a launch boundary was needed for -- is a barrier among the FOUR workgroups of a sample: each
-// arrives on a per-sample counter in global memory and spins until its three siblings have.  The next phase's weight fragments are requested BEFORE the
-// barrier (they do not depend on the exchange), so their L2 round trip overlaps it.  A spin on sibling workgroups hangs if they are not co-resident: the
-// launcher takes this route only when hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs covers the whole grid (else the two-launch form above), and the
-// spin gives up after ~0.3 s, counting a fault (adf_run_counters::device_faults) instead of hanging the queue.
-constexpr int kRbChainMax = 3;
-struct RbChainArgs {
-    int nblk;
-    int cin[kRbChainMax];
-    RbSplitArgs blk[kRbChainMax];
-    unsigned* flags;          // [B] arrival counters, zero at launch (the statistics arena: one memset per network pass)
-    unsigned* faults;         // device counter of barriers that timed out
-};
-
-__device__ __forceinline__ void rb_group_barrier(unsigned* flag, unsigned target, unsigned* faults) {
-    // every wave: its (agent-scope) stores of this phase have been acknowledged before the arrival.  No fence: the exchanged tensors are written and read
-    // with agent-scope accesses (COH), everything else -- weights, parameters -- stays in this XCD's L2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 21)) { __hip_atomic_fetch_add(faults, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-}
-
-template <int NTOK, int CIN>
-__device__ __forceinline__ void rb_chain_block(const RbSplitArgs& aa, char* smem, int bq, bool first, unsigned* flag, unsigned& arrivals, unsigned* faults) {
-    {
-        RbSplitWf<NTOK, CIN, 1> W;
-        rb_split_load_w<NTOK, CIN, 1>(aa, bq, W);
-        if (!first) { arrivals += 4; rb_group_barrier(flag, arrivals, faults); }       // the previous block's output rows and statistics
-        rb_split_run<NTOK, CIN, 1, true>(aa, smem, bq, W);
-    }
-    {
-        RbSplitWf<NTOK, CIN, 2> W;
-        rb_split_load_w<NTOK, CIN, 2>(aa, bq, W);
-        arrivals += 4;
-        rb_group_barrier(flag, arrivals, faults);                                       // all four column quarters of silu(FiLM(GN2(h1)))
-        rb_split_run<NTOK, CIN, 2, true>(aa, smem, bq, W);
-    }
-}
-
-template <int NTOK>
-__global__ void __launch_bounds__(512) resblock_chain_kernel(const RbChainArgs c) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bq = (int)blockIdx.x;
-    unsigned* const flag = c.flags + (bq >> 2);
-    unsigned arrivals = 0;
-#define ADF_RB_CHAIN_BLOCK(k)                                                                                              \
-    if (k < c.nblk) {                                                                                                      \
-        if (c.cin[k] == 256) rb_chain_block<NTOK, 256>(c.blk[k], smem, bq, k == 0, flag, arrivals, c.faults);              \
-        else rb_chain_block<NTOK, 512>(c.blk[k], smem, bq, k == 0, flag, arrivals, c.faults);                              \
-    }
-    ADF_RB_CHAIN_BLOCK(0)
-    ADF_RB_CHAIN_BLOCK(1)
-    ADF_RB_CHAIN_BLOCK(2)
-#undef ADF_RB_CHAIN_BLOCK
 }
 
 inline size_t resblock_split_lds(int ntok, int cin) {
@@ -433,34 +359,6 @@ inline const char* launch_resblock_split_t(const RbSplitArgs& a, int B, hipStrea
     hipLaunchKernelGGL((resblock_split_kernel<NTOK, CIN, 1>), dim3(B * 4), dim3(512), lds, s, a);
     hipLaunchKernelGGL((resblock_split_kernel<NTOK, CIN, 2>), dim3(B * 4), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? nullptr : "resblock_split: launch failed";
-}
-
-// 0 = launched; 1 = not taken (the grid would not be co-resident on this device: use the two-launch form); else *err is set
-template <int NTOK>
-inline int launch_resblock_chain_t(const RbChainArgs& c, int B, hipStream_t s, const char** err) {
-    static int resident_dev[kMaxDevices] = {};       // 0 = not asked yet, -1 = attribute / query failed, else workgroups that can be resident at once
-    int& resident = resident_dev[current_device()];
-    const size_t lds = resblock_split_lds(NTOK, 512);
-    if (resident == 0) {
-        resident = -1;
-        int per_cu = 0, cus = 0, dev = 0;
-        if (hipFuncSetAttribute((const void*)resblock_chain_kernel<NTOK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)resblock_chain_kernel<NTOK>, 512, lds) == hipSuccess &&
-            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
-            resident = per_cu * cus;
-    }
-    if (resident < B * 4 || lds > 160 * 1024) return 1;
-    hipLaunchKernelGGL((resblock_chain_kernel<NTOK>), dim3(B * 4), dim3(512), lds, s, c);
-    if (hipGetLastError() != hipSuccess) { *err = "resblock_chain: launch failed"; return 2; }
-    return 0;
-}
-inline int launch_resblock_chain(const RbChainArgs& c, int B, int ntok, hipStream_t s, const char** err) {
-    *err = nullptr;
-    if (c.nblk < 1 || c.nblk > kRbChainMax || !c.flags || !c.faults) return 1;
-    for (int k = 0; k < c.nblk; ++k) if (c.cin[k] != 256 && c.cin[k] != 512) return 1;
-    if (ntok == 64) return launch_resblock_chain_t<64>(c, B, s, err);
-    if (ntok == 16) return launch_resblock_chain_t<16>(c, B, s, err);
-    return 1;
 }
 
 inline const char* launch_resblock_split(const RbSplitArgs& a, int B, int ntok, int cin, hipStream_t s) {

@@ -45,8 +45,7 @@ extern "C" {
  * 3: adf_sampler_run(n_injected), adf_sampler_desc.reflow, adf_get_counters.
  * 4: ADF_FLAG_NEAREST_UPSAMPLE (adf_net_config.flags bit 1; state-dict keys ...upsample.2.weight / .bias), WaveNetNoise in bf16 at 64 / 128
  *    residual channels, adf_debug_tap on a WaveNet handle keeps every layer while all of them fit 512 MiB (256 MiB before).
- * 5: ADF_DTYPE_F32X3 (a third value of adf_net_config.dtype: fp32 storage, every GEMM operand split into bf16 hi + lo, three bf16 MFMAs per product);
- *    adf_run_counters.device_faults. */
+ * 5: ADF_DTYPE_F32X3 (a third value of adf_net_config.dtype: fp32 storage, every GEMM operand split into bf16 hi + lo, three bf16 MFMAs per product). */
 #define ADF_ABI_VERSION 5
 int adf_abi_version(void);
 
@@ -197,9 +196,6 @@ typedef struct adf_run_counters {
     int64_t graph_replays;    /* adf_sampler_run calls served by hipGraphLaunch */
     int64_t denoise_calls;    /* adf_denoise calls */
     int64_t net_passes;       /* network passes enqueued by host code (eager, warm-up, capture) */
-    int64_t device_faults;    /* (ABI 5) in-kernel waits that gave up: a sibling-workgroup barrier of the chained short-level resblock kernel that timed out
-                                 (results of that pass are then wrong).  Read from the device: adf_get_counters synchronises the device when the handle has
-                                 launched such a kernel.  Always 0 on a healthy run; the GPU tests assert it. */
 } adf_run_counters;
 int adf_get_counters(const adf_handle* h, adf_run_counters* out);
 
