@@ -2,7 +2,7 @@
 # Runs ON the GPU box (gpurun): produces the small summaries that get committed under profiles/ (named per round).
 # usage: tools/collect_profiles.sh r01      -> gpurun_out/profiles_r01/*
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -46,6 +46,8 @@ if t:
     for g, v in sorted(d.items(), key=lambda kv: -int(kv[0])):
         print(f"grid_x {g}: {len(v)} launches, mean {sum(v)/len(v):.1f} us (under counter collection)")
 PY
+rm -rf /tmp/pt
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -- python3 bench.py --config c3 --sampler dpm --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-pmc --no-precision-check > /tmp/pt.log 2>&1 && python3 tools/attention_util.py /tmp/pa /tmp/pt > $out/${tag}_attention_mfma_utilisation.txt
 echo "[9/9] C3 bench line"
 timeout -k 10 400 python bench.py --config c3 --sampler dpm --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_c3_dpm.json
 echo "[10] WaveNet (config 5): bench line, kernel trace, parity report, phase stamps"
@@ -74,5 +76,8 @@ if [ -f audiodiffuser_amd/build/variants/libadf_hip_rbtl.so ]; then
   ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbtl.so timeout -k 10 200 python tools/rb_timeline.py 4 1 2>&1 | grep -v amdgpu.ids > $out/${tag}_rb_launch_timeline_n256.txt
   ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_rbtl.so timeout -k 10 200 python tools/rb_timeline.py 20 1 64 single 2>&1 | grep -v amdgpu.ids > $out/${tag}_rb_launch_timeline_L256.txt
 fi
-if [ -x tools/micro/bin/role_split ]; then timeout -k 5 100 tools/micro/bin/role_split > $out/${tag}_role_split_microbench_raw.txt 2>&1; fi
+if [ -x tools/micro/bin/rb_floor ]; then timeout -k 5 200 tools/micro/bin/rb_floor > $out/${tag}_rb_floor_microbench.txt 2>&1; fi
+echo "[13] split-bf16 mode: per-kernel table"; rm -rf /tmp/p8
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p8 -- python3 bench.py --dtype f32x3 --steps 1 --warmup 1 --no-cpu-baseline --no-precision-check --no-pmc --no-other-workloads > /tmp/p8.log 2>&1 && python3 tools/trace_summary.py $(ls /tmp/p8/*/*kernel_trace.csv | head -1) 198 --grid | sed "s#/tmp/p8/[^ ]*#rocprofv3 --kernel-trace --stats -- python3 bench.py --dtype f32x3 --steps 1 --warmup 1#" > $out/${tag}_f32x3_mode_per_nfe_summary.txt
+if [ -x tools/micro/bin/role_split ] && false; then timeout -k 5 100 tools/micro/bin/role_split > $out/${tag}_role_split_microbench_raw.txt 2>&1; fi
 ls -la $out
