@@ -19,7 +19,7 @@ SOURCES = ["adf_gemm.hip", "adf_kernels.hip", "adf_wavenet.hip", "adf_conv2d.hip
 # adf_gemm.hip: the SLP vectoriser would pair the prologue arithmetic that adf_gemm_pp.h places one element per MFMA gap
 # into v_pk_* operations (which are slower beside MFMAs and land in one gap instead of two)
 EXTRA_FLAGS = {"adf_gemm.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["adf_common.h", "adf_gemm.h", "adf_gemm_pp.h", "adf_gemm_rb.h", "adf_gemm_up.h", "adf_kernels.h", "adf_wavenet.h", "adf_conv2d.h", "adf_transformer.h", "adf_resblock_small.h", "adf_resblock_split.h", "adf_api_internal.h", os.path.join("..", "..", "include", "audiodiffuser_amd.h")]
+HEADERS = ["adf_common.h", "adf_gemm.h", "adf_gemm_pp.h", "adf_gemm_rb.h", "adf_gemm_rbx3.h", "adf_gemm_up.h", "adf_kernels.h", "adf_wavenet.h", "adf_conv2d.h", "adf_transformer.h", "adf_resblock_small.h", "adf_resblock_split.h", "adf_api_internal.h", os.path.join("..", "..", "include", "audiodiffuser_amd.h")]
 ARCH = "gfx950"
 
 

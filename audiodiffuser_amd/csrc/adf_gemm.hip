@@ -2,6 +2,7 @@
 #include "adf_gemm.h"
 #include "adf_gemm_pp.h"
 #include "adf_gemm_rb.h"
+#include "adf_gemm_rbx3.h"
 #include "adf_gemm_up.h"
 #include "adf_kernels.h"
 #include <cstdio>
@@ -262,6 +263,104 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
         else go(conv_gemm_rb_kernel<1, false, 1>);
     }
     if (hipGetLastError() != hipSuccess) *err = "conv_gemm_rb: launch failed";
+    return true;
+}
+
+// Split-bf16 form of the resblock conv kernel (adf_gemm_rbx3.h): fp32 storage, 32-channel K blocks, one 128-column N tile per workgroup tile.
+// Same shapes as try_launch_rb; returns false (and launches nothing) when the shape is not one the kernel is written for.
+bool try_launch_rbx3(const GemmArgs& a, long long min_tiles, hipStream_t stream, const char** err) {
+    *err = nullptr;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const GemmSeg& g0 = a.seg[0];
+    if (a.scatter_f || a.gelu || a.flat || a.mrows % 128 || a.lin != a.mrows || a.out_rows != a.mrows) return false;
+    if (a.n != a.n_pad || a.out_c != a.n || (a.n != 128 && a.n != 256) || a.bias_mod != a.n) return false;
+    if (!pow2(a.mrows / 128)) return false;
+    const bool raw0 = !g0.gn.gamma && !g0.ab && !g0.act && g0.c1 == 0;
+    if (!raw0 && (!g0.gn.gamma || !g0.act)) return false;
+    if (g0.taps != 3 || g0.off0 != -1 || g0.stride != 1 || g0.step != 1) return false;
+    if (g0.c0 % 64 || g0.c1 % 64 || (g0.c0 + g0.c1) / 32 > kRbx3MaxBlk) return false;      // an even number of 32-channel blocks per source
+    if (!raw0 && g0.c0 + g0.c1 > kPpMaxCin) return false;
+    if (!raw0) {
+        const GnFinalizeArgs& gn = g0.gn;
+        if (gn.G < 1 || (gn.c0 + gn.c1) % gn.G || gn.c0 % gn.G || gn.c1 % gn.G) return false;
+        const int gs = (gn.c0 + gn.c1) / gn.G;
+        if (gn.c0 % gs) return false;
+        for (int cs : {gn.c0, gn.c1}) {
+            if (cs == 0) continue;
+            const int fg = cs / gn.G;
+            if (gs != fg && gs != 2 * fg) return false;
+        }
+    }
+    if (raw0 && (a.nseg > 1 || a.res)) return false;
+    if (a.res && a.nseg > 1) return false;
+    Rbx3Args r;
+    memset(&r, 0, sizeof(r));
+    int nb = 0;
+    auto add_seg = [&](const void* s0, const void* s1, int c0, int c1, const void* w, int taps, bool table, float scale1) {
+        for (int c = 0; c < c0 + c1; c += 32, ++nb) {
+            const bool from1 = c >= c0;
+            RbBlk& e = r.blk[nb];
+            e.src = (const char*)(from1 ? s1 : s0) + (size_t)(from1 ? c - c0 : c) * 4;
+            e.pitch = (unsigned)(from1 ? c1 : c0) * 4u;
+            e.w = (const char*)w + (size_t)(c / 32) * taps * a.n_pad * kRowBytes;
+            e.tab = table ? c * 8 : -1;
+            e.scale = from1 ? scale1 : 1.0f;
+        }
+    };
+    add_seg(g0.src0, g0.src1, g0.c0, g0.c1, g0.w, 3, !raw0, 1.0f);
+    r.h.nb3 = nb;
+    if (a.nseg > 1) {
+        const GemmSeg& g1 = a.seg[1];
+        if (g1.taps != 1 || g1.off0 != 0 || g1.stride != 1 || g1.step != 1 || g1.ab || g1.gn.gamma || g1.act) return false;
+        if (g1.c0 % 64 || g1.c1 % 64 || nb + (g1.c0 + g1.c1) / 32 > kRbx3MaxBlk) return false;
+        add_seg(g1.src0, g1.src1, g1.c0, g1.c1, g1.w, 1, false, g1.scale1);
+    }
+    r.h.res = a.nseg == 1 ? a.res : nullptr;
+    r.h.nb1 = nb - r.h.nb3;
+    r.h.B = a.B; r.h.L = a.mrows;
+    auto tiles_at = [&](int tm_) -> long long {
+        if (a.mrows % tm_ || !pow2(a.mrows / tm_)) return 0;
+        return (long long)a.B * (a.mrows / tm_) * (a.n / kPpTN);
+    };
+    int tm = 256;
+    long long tiles_total = tiles_at(256);
+    if (tiles_total < min_tiles) { tm = 128; tiles_total = tiles_at(128); }
+    if (tiles_total > (1 << 22) || tiles_total < min_tiles) return false;
+    r.h.tiles_n = a.n / kPpTN;
+    r.h.tm_shift = 0;
+    while ((1 << r.h.tm_shift) < a.mrows / tm) ++r.h.tm_shift;
+    r.h.tiles_total = (int)tiles_total;
+    r.h.n = a.n;
+    r.h.gn = g0.gn;
+    r.h.bias0 = a.bias0; r.h.bias1 = a.bias1;
+    r.h.out = a.out;
+    r.h.stats = nullptr; r.h.stats_groups = 0;
+    if (a.phase_c && (!raw0 || (a.phase_c & (a.phase_c - 1)) || a.phase_c < 64 || a.n % a.phase_c)) return false;
+    if (a.stats) {
+        const int sc = a.phase_c ? a.phase_c : a.out_c;
+        const int gs = a.stats_groups > 0 ? sc / a.stats_groups : 0;
+        if (!(gs > 0 && gs * a.stats_groups == sc && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
+        r.h.stats = a.stats; r.h.stats_groups = a.stats_groups;
+        r.h.stats_mod = a.phase_c;
+    }
+    static bool attr_done[kMaxDevices] = {};
+    static int num_cu_dev[kMaxDevices] = {};
+    const int dev = current_device();
+    if (!attr_done[dev]) {
+        bool ok = true;
+        for (const void* k : {(const void*)conv_gemm_rbx3_kernel<2>, (const void*)conv_gemm_rbx3_kernel<1>})
+            ok = ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kRbLds) == hipSuccess;
+        if (!ok) {
+            *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize, rbx3) failed";
+            return true;
+        }
+        if (hipDeviceGetAttribute(&num_cu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu_dev[dev] < 1) num_cu_dev[dev] = 256;
+        attr_done[dev] = true;
+    }
+    const long long grid = tiles_total < num_cu_dev[dev] ? tiles_total : num_cu_dev[dev];
+    if (tm == 256) hipLaunchKernelGGL(conv_gemm_rbx3_kernel<2>, dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
+    else hipLaunchKernelGGL(conv_gemm_rbx3_kernel<1>, dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
+    if (hipGetLastError() != hipSuccess) *err = "conv_gemm_rbx3: launch failed";
     return true;
 }
 
@@ -550,6 +649,19 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype, hipStream_t stream
             static int use_rb = -1;
             if (use_rb < 0) use_rb = adf_route_switch("ADF_GEMM_RB", 1);
             const bool rb_raw = !gn_pending && !a.seg[0].ab && !a.seg[0].act && a.nseg == 1 && !a.res && a.seg[0].taps == 3;
+            // fp32 storage, split-bf16 products: the same data path on 32-channel blocks (adf_gemm_rbx3.h).  ADF_GEMM_RBX3=0: the generic kernel (A/B)
+            static int use_rbx3 = -1;
+            if (use_rbx3 < 0) use_rbx3 = adf_route_switch("ADF_GEMM_RBX3", 1);
+            if (use_rbx3 && x3 && !flat && ((gn_pending && gn_in_kernel && !a.gn_ready) || rb_raw)) {
+                const char* err = nullptr;
+                GemmArgs b = a;
+                b.stats = a_in.stats;
+                if (try_launch_rbx3(b, use_rbx3 >= 2 ? 32 : 256, stream, &err)) {
+                    if (stats_fused) *stats_fused = a_in.stats != nullptr;
+                    trace_route("rbx3", a, 256, 128);
+                    return err;
+                }
+            }
             if (use_rb && dtype_bf16 && !flat && ((gn_pending && gn_in_kernel && !a.gn_ready) || rb_raw)) {
                 const char* err = nullptr;
                 const void* ident = nullptr;

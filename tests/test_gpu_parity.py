@@ -74,7 +74,8 @@ F32X3_TOL = 2e-4      # split-bf16 mode per recorded tensor, free-running, max-n
 @pytest.mark.parametrize("tag,mk", CASES + [("c3short", A.config_c3)])
 def test_every_layer_f32x3(tag, mk):
     """ADF_DTYPE_F32X3 (fp32 storage, every GEMM operand split into bf16 hi + lo, three bf16 MFMAs per product): every recorded tensor of the net
-    against the fp32 oracle, free-running.  Routes: the generic implicit-GEMM kernel and the split-K kernel (the only two that take the mode)."""
+    against the fp32 oracle, free-running.  Routes at these sizes: the generic implicit-GEMM kernel and the split-K kernel (the resblock kernel of the long
+    levels, adf_gemm_rbx3.h, has its own test below)."""
     if tag == "c3short":
         x, t = generate_noise(5, 2, 4096) * 0.7, torch.tensor([-0.6, 0.4])
     else:
@@ -84,6 +85,30 @@ def test_every_layer_f32x3(tag, mk):
     bad = {k: v for k, v in errs.items() if not v < F32X3_TOL}
     assert not bad, bad
     assert max(errs.values()) > 1e-7          # (not silently the exact-fp32 route)
+
+
+def test_split_bf16_resblock_dma_kernel_on_small_batches_every_tensor_vs_fp32_oracle():
+    """adf_gemm_rbx3.h (the resblock conv kernel's data path on fp32 storage: 32-channel K blocks split into bf16 hi + lo in the MFMA gaps, three MFMAs
+    per product) on every shape it is written for: ADF_GEMM_RBX3=2 lets it take the resblock convs at batch 8, where the L = 256 level runs its
+    128-row form -- incl. the raw folded down conv, the identity-residual conv2, the 1x1-residual K segment and the two-source concat of the up path.
+    BASELINE configs[1] net, every recorded tensor free-running against the fp32 oracle at the mode's bound."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADF_GEMM_RBX3="2", ADF_GEMM_TRACE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "gpu_forced_report.py"), "c2", "8", "16384", "0", "f32x3"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    errs = rep["forced"]
+    assert rep["finite"]
+    routed = [l for l in r.stderr.splitlines() if "[adf gemm] rbx3" in l]
+    assert len(routed) >= 30, r.stderr[-3000:]
+    assert any("nseg=2" in l for l in routed) and any("ab=0 act=0" in l for l in routed), routed[:5]
+    assert {"down3.conv", "down3.block0.h1", "down3.block1", "up2.block0.h1", "up2.block2"} <= set(errs)
+    bad = {k: v for k, v in errs.items() if not v < F32X3_TOL}
+    assert not bad, bad
 
 
 def _assert_bf16_parity(cfg, x, t, chained=True, flags=0):
