@@ -1370,6 +1370,6 @@ __global__ void __launch_bounds__(256) conv_gemm_ksplit_kernel(const GemmArgs a)
 // dtype: 0 = fp32 (exact-fp32 MFMA), 1 = bf16 storage, 2 = fp32 storage with split-bf16 operands (f32x3_t, adf_common.h)
 const char* launch_conv_gemm(const GemmArgs& a, int dtype, hipStream_t stream, bool* stats_fused = nullptr);
 // would launch_conv_gemm route this phase_c > 0 conv to conv_gemm_rb_kernel (shape, tile count)?  No launch.
-bool conv_gemm_phase_eligible(const GemmArgs& a);
+bool conv_gemm_phase_eligible(const GemmArgs& a, int dtype);   // dtype as launch_conv_gemm: 1 -> adf_gemm_rb.h, 2 -> adf_gemm_rbx3.h
 
 }  // namespace adf

@@ -268,7 +268,7 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
 
 // Split-bf16 form of the resblock conv kernel (adf_gemm_rbx3.h): fp32 storage, 32-channel K blocks, one 128-column N tile per workgroup tile.
 // Same shapes as try_launch_rb; returns false (and launches nothing) when the shape is not one the kernel is written for.
-bool try_launch_rbx3(const GemmArgs& a, long long min_tiles, hipStream_t stream, const char** err) {
+bool try_launch_rbx3(const GemmArgs& a, long long min_tiles, hipStream_t stream, const char** err, bool dry = false) {
     *err = nullptr;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const GemmSeg& g0 = a.seg[0];
@@ -343,6 +343,7 @@ bool try_launch_rbx3(const GemmArgs& a, long long min_tiles, hipStream_t stream,
         r.h.stats = a.stats; r.h.stats_groups = a.stats_groups;
         r.h.stats_mod = a.phase_c;
     }
+    if (dry) return true;
     static bool attr_done[kMaxDevices] = {};
     static int num_cu_dev[kMaxDevices] = {};
     const int dev = current_device();
@@ -455,11 +456,16 @@ static long long rb_min_tiles() {
     if (use_rb < 0) use_rb = adf_route_switch("ADF_GEMM_RB", 1);
     return use_rb == 0 ? -1 : (use_rb >= 2 ? 32 : 256);        // ADF_GEMM_RB=2: also small batches (tests); 0: the route is off
 }
-bool conv_gemm_phase_eligible(const GemmArgs& a) {
-    const long long mt = rb_min_tiles();
-    if (mt < 0 || !a.phase_c || a.flat) return false;
+static long long rbx3_min_tiles() {
+    static int use_rbx3 = -1;
+    if (use_rbx3 < 0) use_rbx3 = adf_route_switch("ADF_GEMM_RBX3", 1);
+    return use_rbx3 == 0 ? -1 : (use_rbx3 >= 2 ? 32 : 256);    // ADF_GEMM_RBX3=2: also small batches (tests); 0: the route is off
+}
+bool conv_gemm_phase_eligible(const GemmArgs& a, int dtype) {
+    const long long mt = dtype == 2 ? rbx3_min_tiles() : rb_min_tiles();
+    if (dtype == 0 || mt < 0 || !a.phase_c || a.flat) return false;
     const char* err = nullptr;
-    return try_launch_rb(a, nullptr, mt, nullptr, &err, true);
+    return dtype == 2 ? try_launch_rbx3(a, mt, nullptr, &err, true) : try_launch_rb(a, nullptr, mt, nullptr, &err, true);
 }
 
 const char* launch_conv_gemm(const GemmArgs& a_in, int dtype, hipStream_t stream, bool* stats_fused) {
@@ -470,14 +476,15 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype, hipStream_t stream
     if (a.phase_c) {                 // only the resblock conv kernel's raw form knows the phase-major statistics
         // what try_launch_rb accepts drives the answer: declined with a statistics request (group size), it is asked again without one and the caller
         // runs the separate statistics pass (stats_fused stays false)
-        const long long mt = rb_min_tiles();
-        if (!dtype_bf16 || mt < 0 || a.flat) return "conv_gemm: a 3-tap-form transposed conv that conv_gemm_rb_kernel does not take";
+        const long long mt = x3 ? rbx3_min_tiles() : rb_min_tiles();
+        if (dtype == 0 || mt < 0 || a.flat) return "conv_gemm: a 3-tap-form transposed conv that conv_gemm_rb_kernel does not take";
         const char* err = nullptr;
-        bool taken = try_launch_rb(a, nullptr, mt, stream, &err);
-        if (!taken && a.stats) { a.stats = nullptr; taken = try_launch_rb(a, nullptr, mt, stream, &err); }
+        auto go = [&]() { return x3 ? try_launch_rbx3(a, mt, stream, &err) : try_launch_rb(a, nullptr, mt, stream, &err); };
+        bool taken = go();
+        if (!taken && a.stats) { a.stats = nullptr; taken = go(); }
         if (!taken) return "conv_gemm: a 3-tap-form transposed conv that conv_gemm_rb_kernel does not take";
         if (stats_fused) *stats_fused = a.stats != nullptr;
-        trace_route("rb", a, 256, 128);
+        trace_route(x3 ? "rbx3" : "rb", a, 256, 128);
         return err;
     }
     if (a.nseg < 1 || a.nseg > 2) return "conv_gemm: nseg must be 1 or 2";
@@ -650,13 +657,12 @@ const char* launch_conv_gemm(const GemmArgs& a_in, int dtype, hipStream_t stream
             if (use_rb < 0) use_rb = adf_route_switch("ADF_GEMM_RB", 1);
             const bool rb_raw = !gn_pending && !a.seg[0].ab && !a.seg[0].act && a.nseg == 1 && !a.res && a.seg[0].taps == 3;
             // fp32 storage, split-bf16 products: the same data path on 32-channel blocks (adf_gemm_rbx3.h).  ADF_GEMM_RBX3=0: the generic kernel (A/B)
-            static int use_rbx3 = -1;
-            if (use_rbx3 < 0) use_rbx3 = adf_route_switch("ADF_GEMM_RBX3", 1);
-            if (use_rbx3 && x3 && !flat && ((gn_pending && gn_in_kernel && !a.gn_ready) || rb_raw)) {
+            const long long rbx3_mt = rbx3_min_tiles();
+            if (rbx3_mt >= 0 && x3 && !flat && ((gn_pending && gn_in_kernel && !a.gn_ready) || rb_raw)) {
                 const char* err = nullptr;
                 GemmArgs b = a;
                 b.stats = a_in.stats;
-                if (try_launch_rbx3(b, use_rbx3 >= 2 ? 32 : 256, stream, &err)) {
+                if (try_launch_rbx3(b, rbx3_mt, stream, &err)) {
                     if (stats_fused) *stats_fused = a_in.stats != nullptr;
                     trace_route("rbx3", a, 256, 128);
                     return err;

@@ -40,7 +40,7 @@ const char* launch_to_in(const float* x, const float* w, void* out, int bf16, in
 
 // Output transform ConvTranspose1d(nf -> out_ch, k=wl, stride, pad) + EDM epilogue
 //   mode 0: out = F;  mode 1: out = clamp(c_skip*x_noisy + c_out*F, -1, 1).   out / x_noisy: fp32 [B][out_ch][L]
-const char* launch_to_out(const void* h, const float* w, float* out, int bf16, int B, int out_ch, int Lh, int nf,
+const char* launch_to_out(const void* h, const float* w, float* out, int dtype, int B, int out_ch, int Lh, int nf,
                           int wl, int stride, int pad, int mode, const float* x_noisy, const float* coef,
                           int coef_bstride, hipStream_t s);
 

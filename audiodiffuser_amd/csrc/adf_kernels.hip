@@ -1041,9 +1041,117 @@ __global__ void __launch_bounds__(256) to_out_mfma_kernel(const bf16_t* __restri
     }
 }
 
-const char* launch_to_out(const void* h, const float* w, float* out, int bf16, int B, int out_ch, int Lh, int nf,
+// Split-bf16 form (ADF_DTYPE_F32X3: fp32 rows, each operand as bf16 hi + lo, three MFMAs per product): the same skinny GEMM.  A tile of 32 rows x 64
+// channels (8 KB) is read as eight fully coalesced 1 KB pieces (4 rows x 256 bytes per wave instruction) into a wave-private LDS tile (pitch 272 bytes);
+// the lane's 8 channels of a K step (32 bytes) are split there into the hi and lo A fragments.  nf a multiple of 64.
+__global__ void __launch_bounds__(256) to_out_x3_kernel(const float* __restrict__ h, const float* __restrict__ w, float* __restrict__ out,
+                                                        int out_ch, int Lh, int nf, int wl, int stride, int pad, int mode,
+                                                        const float* __restrict__ x_noisy, const float* __restrict__ coef,
+                                                        int coef_bstride) {
+    constexpr int R = 256;                 // feature rows owned by a block
+    constexpr int MAXKS = 8;               // nf <= 128
+    constexpr int PITCH = 272;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = (wl + stride - 1) / stride;
+    float* P = (float*)smem;               // [ceil32(R + 2*halo)][wl]
+    const int b = blockIdx.y, oc = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ksteps = nf / 16;
+    // B operand: lane (r = tap column, hh) holds w[ci = 16 ks + 8 hh + j][oc][tap r], split once
+    to_bf16x8_t bh[MAXKS], bl[MAXKS];
+#pragma unroll
+    for (int ks = 0; ks < MAXKS; ++ks) {
+        u32x4_t qh = u32x4_t{0u, 0u, 0u, 0u}, ql = qh;
+        if (ks < ksteps && r < wl) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = w[((size_t)(16 * ks + 8 * hh + j) * out_ch + oc) * wl + r];
+            u32x2_t h0, l0, h1, l1;
+            split_bf16x4(f, h0, l0);
+            split_bf16x4(f + 4, h1, l1);
+            qh = u32x4_t{h0.x, h0.y, h1.x, h1.y};
+            ql = u32x4_t{l0.x, l0.y, l1.x, l1.y};
+        }
+        bh[ks] = __builtin_bit_cast(to_bf16x8_t, qh);
+        bl[ks] = __builtin_bit_cast(to_bf16x8_t, ql);
+    }
+    const int i0 = blockIdx.x * R - halo;
+    const int nrows = R + 2 * halo;
+    const int ntile = (nrows + 31) / 32;
+    char* const tl = (char*)(P + (size_t)ntile * 32 * wl) + wave * (32 * PITCH);
+    for (int t = wave; t < ntile; t += 4) {
+        to_f32x16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < MAXKS / 4; ++cc) {
+            const int c0 = cc * 64;
+            if (c0 >= nf) break;
+            u32x4_t rv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ii = i0 + t * 32 + q * 4 + (lane >> 4);
+                const int icc = ii < 0 ? 0 : (ii >= Lh ? Lh - 1 : ii);     // clamped: out-of-range rows are masked below
+                rv[q] = *(const u32x4_t*)(h + ((size_t)b * Lh + icc) * nf + c0 + (lane & 15) * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(u32x4_t*)(tl + (q * 4 + (lane >> 4)) * PITCH + (lane & 15) * 16) = rv[q];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const char* ap = tl + r * PITCH + (ks * 2 + hh) * 32;
+                const u32x4_t a0 = *(const u32x4_t*)ap, a1 = *(const u32x4_t*)(ap + 16);
+                u32x2_t h0, l0, h1, l1;
+                split_bf16x4((const float*)&a0, h0, l0);
+                split_bf16x4((const float*)&a1, h1, l1);
+                const to_bf16x8_t ah = __builtin_bit_cast(to_bf16x8_t, u32x4_t{h0.x, h0.y, h1.x, h1.y});
+                const to_bf16x8_t al = __builtin_bit_cast(to_bf16x8_t, u32x4_t{l0.x, l0.y, l1.x, l1.y});
+                const int kk = cc * 4 + ks;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();                 // the tile is rewritten in the next trip
+        }
+        if (r < wl) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int ii = i0 + rr;
+                if (rr < nrows) P[rr * wl + r] = (ii >= 0 && ii < Lh) ? acc[e] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int L = Lh * stride;
+    const int l0 = blockIdx.x * R * stride;
+    float c_skip = 0.f, c_out = 1.f;
+    if (mode == 1) { c_skip = coef[(size_t)b * coef_bstride + 2]; c_out = coef[(size_t)b * coef_bstride + 3]; }
+    for (int t = threadIdx.x; t < R * stride; t += 256) {
+        const int l = l0 + t;
+        if (l >= L) break;
+        float acc = 0.f;
+        const int k0 = (l + pad) % stride;
+        for (int k = k0; k < wl; k += stride) {
+            const int i = (l + pad - k) / stride;
+            if (i >= 0 && i < Lh && (l + pad - k) >= 0) acc += P[(i - i0) * wl + k];
+        }
+        const size_t o = ((size_t)b * out_ch + oc) * L + l;
+        float v = acc;
+        if (mode == 1) {
+            v = fmaf(c_skip, x_noisy[o], c_out * acc);
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+        }
+        out[o] = v;
+    }
+}
+
+// dtype: 0 = fp32 rows (VALU), 1 = bf16 rows, 2 = fp32 rows with split-bf16 products
+const char* launch_to_out(const void* h, const float* w, float* out, int dtype, int B, int out_ch, int Lh, int nf,
                           int wl, int stride, int pad, int mode, const float* x_noisy, const float* coef,
                           int coef_bstride, hipStream_t s) {
+    const int bf16 = dtype == 1;
     const int epc = bf16 ? 8 : 4;
     if (nf % epc) return "to_out: num_filters must be a multiple of a 16-byte chunk";
     if (wl > 16) return "to_out: window_length > 16 unsupported";
@@ -1053,6 +1161,11 @@ const char* launch_to_out(const void* h, const float* w, float* out, int bf16, i
         const size_t lds = (size_t)round_up(256 + 2 * halo, 32) * wl * sizeof(float) + 4 * 32 * 144;      // P + one staging tile per wave
         hipLaunchKernelGGL(to_out_mfma_kernel, grid, dim3(256), lds, s, (const bf16_t*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
         return ADF_LAUNCH_CHECK("to_out_mfma");
+    }
+    if (dtype == 2 && nf % 64 == 0 && nf <= 128) {
+        const size_t lds = (size_t)round_up(256 + 2 * halo, 32) * wl * sizeof(float) + 4 * 32 * 272;      // P + one staging tile per wave
+        hipLaunchKernelGGL(to_out_x3_kernel, grid, dim3(256), lds, s, (const float*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);
+        return ADF_LAUNCH_CHECK("to_out_x3");
     }
     const size_t lds = ((size_t)nf * wl + (size_t)(256 + 2 * halo) * wl) * sizeof(float);
     if (bf16) hipLaunchKernelGGL(to_out_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)h, w, out, out_ch, Lh, nf, wl, stride, pad, mode, x_noisy, coef, coef_bstride);

@@ -70,7 +70,7 @@ int build_weights(adf_handle* h) {
         }
         up.up.bias = R.reg_f32(pre + ".upsample.bias", up.cout);
         // (f = 2 only: the packing is written for any even factor, but no configuration with f = 4 and f * cout <= 256 is in the tests)
-        if (h->bf16 && up.up.w && f == 2 && (f * up.cout == 128 || f * up.cout == 256) && up.cin % 128 == 0 && up.cout % 64 == 0) {
+        if ((h->bf16 || h->x3) && up.up.w && f == 2 && (f * up.cout == 128 || f * up.cout == 256) && up.cin % 128 == 0 && up.cout % 64 == 0) {
             ConvW& w3 = up.up3;
             w3.cin = up.cin; w3.K = 2 * f; w3.f = f; w3.taps = 3;
             w3.n = f * up.cout; w3.n_pad = w3.n; w3.cout = w3.n;
@@ -193,8 +193,8 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
             const bool ask = u + 1 < n && W.can_fuse_stats(up.cout);
             g3.stats = ask ? (double*)(uintptr_t)256 : nullptr;                 // (a dry check: never dereferenced)
             g3.stats_groups = ask ? h->cfg.resnet_groups : 0;
-            bool elig = conv_gemm_phase_eligible(g3);
-            if (!elig && ask) { g3.stats = nullptr; g3.stats_groups = 0; elig = conv_gemm_phase_eligible(g3); }
+            bool elig = conv_gemm_phase_eligible(g3, h->gemm_dtype());
+            if (!elig && ask) { g3.stats = nullptr; g3.stats_groups = 0; elig = conv_gemm_phase_eligible(g3, h->gemm_dtype()); }
             if (elig) {
                 if (ask) { y.stats = W.alloc_stats(); if (g3.stats) g3.stats = y.stats; }
                 if (W.live()) {
@@ -216,7 +216,7 @@ int forward(adf_handle* h, Plan* p, const FwdIO& io, hipStream_t s) {
         x = y;
     }
     if (W.live())
-        W.check(launch_to_out(x.p, h->to_out_w, io.out, h->bf16, B, c.out_channels, x.L, c.num_filters, c.window_length, c.stride, pad,
+        W.check(launch_to_out(x.p, h->to_out_w, io.out, h->gemm_dtype(), B, c.out_channels, x.L, c.num_filters, c.window_length, c.stride, pad,
                               io.mode, io.x_noisy, io.coef, io.coef_bstride, s));
     return W.bad ? 1 : 0;
 }
