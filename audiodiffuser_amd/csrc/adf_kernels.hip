@@ -377,8 +377,18 @@ typedef __attribute__((ext_vector_type(16))) float att_f32x16_t;
 
 //   * a wave walks `qrep` query tiles of its pair one after the other: the transposed copy of V is staged once per
 //     wpp * qrep query tiles (at N = 1024 the staging was ~1/6 of a block's time with one tile per wave).
+// Round 4 (profiles/r04_attention_mfma_utilisation.txt: 42.5 vector instructions per MFMA, 11.8 % at N = 1024; the ISA of the key-tile loop had 136 per tile of 4 MFMAs):
+//   * two waves per SIMD asked of the register allocator (__launch_bounds__(256, 2)): with a 512-register budget hipcc keeps MFMA results in AccVGPRs and every
+//     key tile paid 16 v_accvgpr_read for the scores plus 16 for the output accumulator (hoisted above the rarely-taken rescale branch);
+//   * the tile maximum over the SCALED scores (8 v_pk_mul_f32, then 8 v_max3_f32: a product is a canonical value, so fmaxf needs no v_max(x, x) in front of
+//     every score -- 31 instructions before; the maximum of the scaled scores is the scaled maximum, bit for bit), scale / subtract and the row sum as
+//     packed-fp32 pairs (v_pk_fma_f32 / v_pk_add_f32: 8 + 9 instead of 16 + 17).  (v_max3_f32 by inline asm on the accumulators themselves is NOT safe: the
+//     hazard recognizer does not see an asm operand, and the branch into the block skipped the 11 wait states a VALU read of an MFMA result needs --
+//     two runs of one launch differed), K rows addressed as a uniform base + a 32-bit lane offset (3 instead of 9), the two halves of a
+//     query's keys exchanged by v_permlane32_swap_b32 instead of ds_bpermute_b32 + its wait.
+typedef __attribute__((ext_vector_type(2))) float att_f32x2_t;
 template <int D>
-__global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
+__global__ void __launch_bounds__(256, 2) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
                                                                 int C, int heads, float scale_log2e, int qrep) {
     constexpr int DT = D / 32, DK = D / 16;      // output tiles of 32 head dims, K steps of the score GEMM (head dim 32 or 64)
     constexpr bool kSplitP = D == 64;
@@ -403,14 +413,29 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
     {
         const int tl = (wave % wpp) * 64 + lane, nthr = wpp * 64;
         const bf16_t* vb = base + 2 * C;
-        for (int idx = tl; idx < npad * (D / 8); idx += nthr) {
-            const int key = idx / (D / 8), c = idx % (D / 8);
-            const int krow = key < N ? key : N - 1;                 // padded keys: any finite value (their probability is 0)
-            const u32x4_t v = *(const u32x4_t*)(vb + (size_t)krow * rowstride + c * 8);
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        // eight pieces per thread requested before the first is scattered (one load -> eight 2-byte stores per trip was 16 serialised memory round trips
+        // per block at N = 1024: about as long as the block's 64 key-tile loops)
+        const int total = npad * (D / 8);
+        for (int base = tl; base < total; base += 8 * nthr) {
+            u32x4_t v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                *(unsigned short*)(vt + (c * 8 + j) * pitch + key * 2) = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * nthr;
+                const int key = idx / (D / 8), c = idx % (D / 8);
+                const int krow = (idx < total && key < N) ? key : N - 1;    // padded keys: any finite value (their probability is 0)
+                v[u] = *(const u32x4_t*)(vb + (size_t)krow * rowstride + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * nthr;
+                if (idx < total) {
+                    const int key = idx / (D / 8), c = idx % (D / 8);
+                    const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *(unsigned short*)(vt + (c * 8 + j) * pitch + key * 2) = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+                }
+            }
         }
     }
     __syncthreads();
@@ -434,11 +459,13 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
         for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
     float m = -INFINITY, l = 0.f;                       // running maximum in the scaled log2 domain (s * c), running sum
     // K fragments (A operand: lane = key) straight from global, one tile ahead of their use
+    const char* const kbase = (const char*)kb + hh * 16;       // (a sample's q | k | v rows are < 4 GB: 32-bit lane offsets)
+    const unsigned krowbytes = (unsigned)rowstride * 2u;
     auto load_k = [&](int kt, u32x4_t (&kq)[DK]) __attribute__((always_inline)) {
         const int key_r = kt * 32 + r;
-        const int krow = key_r < N ? key_r : N - 1;
+        const unsigned koff = (unsigned)(key_r < N ? key_r : N - 1) * krowbytes;
 #pragma unroll
-        for (int ks = 0; ks < DK; ++ks) kq[ks] = *(const u32x4_t*)(kb + (size_t)krow * rowstride + ks * 16 + hh * 8);
+        for (int ks = 0; ks < DK; ++ks) kq[ks] = *(const u32x4_t*)(kbase + koff + ks * 32);
     };
     u32x4_t kcur[DK], knext[DK];
     load_k(0, kcur);
@@ -459,10 +486,21 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
                 st[e] = key < N ? st[e] : -INFINITY;
             }
         }
-        float mt = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+        const att_f32x2_t c2 = {scale_log2e, scale_log2e};
+        float mt;
+        {
+            att_f32x2_t ts[8];
 #pragma unroll
-        for (int e = 4; e < 16; e += 2) mt = fmaxf(mt, fmaxf(st[e], st[e + 1]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+            for (int e = 0; e < 8; ++e) ts[e] = att_f32x2_t{st[2 * e], st[2 * e + 1]} * c2;
+            mt = fmaxf(fmaxf(ts[0].x, ts[0].y), ts[1].x);
+#pragma unroll
+            for (int e = 3; e < 15; e += 2) mt = fmaxf(fmaxf(mt, ts[e >> 1][e & 1]), ts[(e + 1) >> 1][(e + 1) & 1]);
+            mt = fmaxf(mt, ts[7].y);
+            // the other 16 keys of this query sit in lane ^ 32: v_permlane32_swap_b32 (no LDS round trip as ds_bpermute)
+            const unsigned mu = __float_as_uint(mt);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         if (!__all(mt <= m)) {                            // some query's maximum grew: rescale (else alpha == 1 exactly)
             const float mn = fmaxf(m, mt);
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -473,11 +511,16 @@ __global__ void __launch_bounds__(256) attention_mfma32_kernel(const bf16_t* __r
                 for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
             m = mn;
         }
-        float psum = 0.f;
-        const float negm = -m;
+        const att_f32x2_t negm2 = {-m, -m};
+        att_f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, negm)); st[e] = pv; psum += pv; }
-        l += psum;
+        for (int e = 0; e < 16; e += 2) {
+            const att_f32x2_t x = att_f32x2_t{st[e], st[e + 1]} * c2 + negm2;
+            const att_f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            st[e] = pv.x; st[e + 1] = pv.y;
+            psum2 += pv;
+        }
+        l += psum2.x + psum2.y;
 #pragma unroll
         for (int sgrp = 0; sgrp < 2; ++sgrp) {
             u32x4_t pw;

@@ -474,15 +474,17 @@ __global__ void __launch_bounds__(512) wn_layer_bf16_kernel(const bf16_t* __rest
 // LDS holds two 128-row buffers: taps 0 and 1 of the dilated conv are staged into X and G, tap 2 waits in registers and
 // replaces tap 0 once every wave has left the first two taps; the gated tile then replaces tap 1; after GEMM 2 both buffers
 // together are the fp32 exchange tile through which the residual and the skip accumulators reach 16-byte global pieces.
-template <int C, int TM>
-__global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ y_next, float* __restrict__ skip,
+template <int C, int TM, int CW = 32>
+__global__ void __launch_bounds__(C / CW * 64, CW == 64 ? 2 : 1) wn_layer_bf16_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ y_next, float* __restrict__ skip,
                                                                  const void* __restrict__ w1, const float* __restrict__ b1,
                                                                  const void* __restrict__ w2, const float* __restrict__ b2,
                                                                  const float* __restrict__ e, int e_bstride, int n, int dil, int first, int Tn) {
     using Tl = WnTile<C, TM>;
     constexpr int PA = Tl::PA, MT = Tl::MT, SPT = Tl::SPT;
-    constexpr int NT = 2 * C;                              // threads: C / 32 waves, each 32 gate columns and the 32 matching filter columns
-    static_assert((C == 256 || C == 128 || C == 64) && TM == 128, "a wave per 32 gate columns (2 / 4 / 8 waves); two 128-row buffers");
+    constexpr int NT = C / CW * 64;                        // threads: C / CW waves, each CW gate columns and the CW matching filter columns
+    constexpr int NG = CW / 32, NN = 2 * NG;               // column tiles of a wave: NG gate (residual) tiles, then NG filter (skip) tiles
+    static_assert((C == 256 || C == 128 || C == 64) && (TM == 128 || TM == 64) && (CW == 32 || CW == 64) && C % CW == 0 && NN * (TM / 32) == 8,
+                  "a wave per CW gate columns; two TM-row buffers; eight accumulator tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const bufX = smem;                               // [TM][PA]: tap 0, then tap 2
     char* const bufG = smem + TM * PA;                     // [TM][PA]: tap 1, then the gated activation
@@ -512,12 +514,14 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
     constexpr int CPR = C / 8;
     constexpr int NST = TM * CPR / NT;                     // 16-byte pieces of one window per thread
     auto row_of = [&](int i, int q) __attribute__((always_inline)) -> int { return i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh; };
-    const int nb2[2] = {wave * 32, C + wave * 32};
-    const int col = wave * 32 + r;
-    wn_f32x16_t acc[2][MT];
+    int nb2[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) nb2[j] = (j < NG ? 0 : C) + wave * CW + (j % NG) * 32;
+    const int col0 = wave * CW + r;                        // column of this lane in column tile g: col0 + 32 g
+    wn_f32x16_t acc[NN][MT];
     auto zero = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NN; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -568,7 +572,7 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
         WN_STAMP(1);
         __syncthreads();
         WN_STAMP(2);
-        wn_gemm<C, TM, 2 * C, 2, 3, 4>(bufX, w1, nb2, acc, r, hh, dil);
+        wn_gemm<C, TM, 2 * C, NN, 3, 4>(bufX, w1, nb2, acc, r, hh, dil);
         __syncthreads();                                   // every wave has left the windows: G may be overwritten
     } else {
         // ---- large dilation: three disjoint windows.  Taps 0 and 1 go to X and G, tap 2 waits in registers and replaces tap 0
@@ -601,7 +605,7 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
         WN_STAMP(1);
         __syncthreads();
         WN_STAMP(2);
-        wn_gemm<C, TM, 2 * C, 2, 2, 4>(bufX, w1, nb2, acc, r, hh);
+        wn_gemm<C, TM, 2 * C, NN, 2, 4>(bufX, w1, nb2, acc, r, hh);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
@@ -610,20 +614,22 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
             *(u32x4_t*)(bufX + (size_t)i * PA + cc * 16) = w2v[k];
         }
         __syncthreads();
-        wn_gemm<C, TM, 2 * C, 2, 1, 4>(bufX, (const char*)w1 + (size_t)2 * SPT * 2 * (2 * C) * 16, nb2, acc, r, hh);
+        wn_gemm<C, TM, 2 * C, NN, 1, 4>(bufX, (const char*)w1 + (size_t)2 * SPT * 2 * (2 * C) * 16, nb2, acc, r, hh);
         // (every wave has left tap 1 at the barrier above: G may be overwritten)
     }
     WN_STAMP(3);
     // gate: sigmoid(a) tanh(b) = (E - 1) / ((1 + exp(-a)) (1 + E)), E = exp(2 b) clamped so that (1 + E) stays finite: one
     // reciprocal per element instead of two
-    {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int col = col0 + 32 * g;
         const float bg = prm[col], bf = prm[C + col];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float ea = __builtin_amdgcn_exp2f((acc[0][i][q] + bg) * -1.4426950408889634f);
-                const float eb = __builtin_amdgcn_exp2f(fminf((acc[1][i][q] + bf) * 2.8853900817779268f, 60.0f));
+                const float ea = __builtin_amdgcn_exp2f((acc[g][i][q] + bg) * -1.4426950408889634f);
+                const float eb = __builtin_amdgcn_exp2f(fminf((acc[NG + g][i][q] + bf) * 2.8853900817779268f, 60.0f));
                 const float v = (eb - 1.0f) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
                 *(unsigned short*)(bufG + (size_t)row_of(i, q) * PA + col * 2) = f32_to_bf16_hw(v);
             }
@@ -634,7 +640,7 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
 
     // ---- GEMM 2 ----------------------------------------------------------------------------------------------------------
     zero();
-    wn_gemm<C, TM, 2 * C, 2, 1, 4>(bufG, w2, nb2, acc, r, hh);
+    wn_gemm<C, TM, 2 * C, NN, 1, 4>(bufG, w2, nb2, acc, r, hh);
     asm volatile("" ::: "memory");                         // keep the epilogue's global loads below the GEMM (register pressure)
     WN_STAMP(6);
 
@@ -668,12 +674,16 @@ __global__ void __launch_bounds__(2 * C) wn_layer_bf16_wide_kernel(const bf16_t*
         }
     }
     __syncthreads();                                       // every wave has left GEMM 2: X and G become the exchange tile
-    auto put = [&](int j, int boff) __attribute__((always_inline)) {
-        const float bias = prm[boff + col];
+    auto put = [&](int part, int boff) __attribute__((always_inline)) {       // part 0: residual tiles, 1: skip tiles
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int g = 0; g < NG; ++g) {
+            const int col = col0 + 32 * g;
+            const float bias = prm[boff + col];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) *(float*)(smem + (size_t)row_of(i, q) * PS + col * 4) = acc[j][i][q] + bias;
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) *(float*)(smem + (size_t)row_of(i, q) * PS + col * 4) = acc[part * NG + g][i][q] + bias;
+        }
     };
     put(0, 2 * C);
     __syncthreads();
@@ -753,6 +763,21 @@ const char* launch_wn_layer(const WnIO& io, const WnLayerArgs& a, hipStream_t s)
         }
         // route switch (the parity tests run both): 1 = 128-position tiles, 0 = 64-position tiles
         static const int wide = adf_route_switch("ADF_WN_WIDE", 1);
+        if (wide == 2) {
+            // 64-position tiles on four waves (64 gate + 64 filter columns each): 74 KB of LDS, so a CU holds TWO workgroups and one's staging / gate /
+            // epilogue runs under the other's GEMMs -- at twice the weight stream per position
+            static bool attr2[kMaxDevices] = {};
+            bool& a2 = attr2[current_device()];
+            if (!a2) {
+                if (hipFuncSetAttribute((const void*)wn_layer_bf16_wide_kernel<C, TM, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return "wn_layer: hipFuncSetAttribute failed";
+                a2 = true;
+            }
+            const size_t lds2 = (size_t)2 * TM * WnTile<C, TM>::PA + 6 * C * 4;
+            hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<C, TM, 64>), dim3(ceil_div(io.T, TM), io.B), dim3(256), lds2, s, (const bf16_t*)a.y,
+                               (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+            return WN_LAUNCH_CHECK("wn_layer_bf16_pair");
+        }
         if (wide) {
             const size_t ldsw = (size_t)2 * TMW * WnTile<C, TMW>::PA + 6 * C * 4;
             hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<C, TMW>), dim3(ceil_div(io.T, TMW), io.B), dim3(512), ldsw, s, (const bf16_t*)a.y,

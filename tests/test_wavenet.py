@@ -155,9 +155,10 @@ def test_bf16_other_widths_every_layer_vs_bf16_storage_oracle(width):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("wide", ["0", "1", "2"])
 def test_bf16_both_layer_kernel_routes_in_a_child_process(wide):
-    """The layer kernel has two routes (128-position tiles, default; 64-position tiles, ADF_WN_WIDE=0); the switch is read once
+    """The layer kernel has three routes (128-position tiles, default; 64-position tiles, ADF_WN_WIDE=0; 64-position tiles on four waves, two
+    workgroups per CU, ADF_WN_WIDE=2); the switch is read once
     per process, so each runs in its own child: per-layer teacher-forced deviation, the fp32 path, the free-running bf16 net."""
     import json, subprocess, sys
     env = dict(os.environ, ADF_WN_WIDE=wide)
