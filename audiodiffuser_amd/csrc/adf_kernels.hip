@@ -387,8 +387,10 @@ typedef __attribute__((ext_vector_type(16))) float att_f32x16_t;
 //     two runs of one launch differed), K rows addressed as a uniform base + a 32-bit lane offset (3 instead of 9), the two halves of a
 //     query's keys exchanged by v_permlane32_swap_b32 instead of ds_bpermute_b32 + its wait.
 typedef __attribute__((ext_vector_type(2))) float att_f32x2_t;
-template <int D>
-__global__ void __launch_bounds__(256, 2) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
+//   * NW = 8 waves per workgroup sharing one pair's V^T (N >= 512 at head dim 32): 16 waves per CU instead of 8 under the same LDS footprint, four per SIMD
+//     to fill each other's transcendental / MFMA latencies (the loop is bound by its vector instructions: 58 + 16 v_exp_f32 per key tile of 4 MFMAs).
+template <int D, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
                                                                 int C, int heads, float scale_log2e, int qrep) {
     constexpr int DT = D / 32, DK = D / 16;      // output tiles of 32 head dims, K steps of the score GEMM (head dim 32 or 64)
     constexpr bool kSplitP = D == 64;
@@ -396,8 +398,8 @@ __global__ void __launch_bounds__(256, 2) attention_mfma32_kernel(const bf16_t* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qtiles = (N + 31) >> 5;
-    const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);   // waves that share one (b, head) pair
-    const int ppb = 4 / wpp;                                    // pairs per block
+    const int wpp = qtiles >= NW ? NW : (qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1));   // waves that share one (b, head) pair
+    const int ppb = NW / wpp;                                   // pairs per block
     const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
     const int qg = blockIdx.x % qgroups, pg = blockIdx.x / qgroups;
     const int pair = pg * ppb + wave / wpp;
@@ -458,6 +460,9 @@ __global__ void __launch_bounds__(256, 2) attention_mfma32_kernel(const bf16_t* 
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
     float m = -INFINITY, l = 0.f;                       // running maximum in the scaled log2 domain (s * c), running sum
+    // (the running sum on the matrix cores -- ones^T P^T, 2 MFMAs per key tile instead of 12 vector instructions -- was tried: it sums the bf16-ROUNDED
+    //  probabilities, which moves one attention output of the C3 net from 1.4e-3 to 1.55e-3 of the bf16-storage oracle, whose normaliser sums the unrounded
+    //  ones as the fused transformer kernel does; not kept)
     // K fragments (A operand: lane = key) straight from global, one tile ahead of their use
     const char* const kbase = (const char*)kb + hh * 16;       // (a sample's q | k | v rows are < 4 GB: 32-bit lane offsets)
     const unsigned krowbytes = (unsigned)rowstride * 2u;
@@ -739,24 +744,30 @@ const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N,
     const int dh_ = C / heads;
     if (bf16 && (dh_ == 32 || dh_ == 64) && N >= 1 && N <= (dh_ == 32 ? 1024 : 512)) {        // V^T of a pair in LDS: dh x (N padded to 32) bf16 <= 72 KB
         const int qtiles = (N + 31) / 32;
-        const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);
-        const int ppb = 4 / wpp;
+        // eight waves per workgroup from 16 query tiles on (head dim 32; ADF_ATT_NW=4 keeps four: A/B)
+        static int att_nw = -1;
+        if (att_nw < 0) att_nw = adf_route_switch("ADF_ATT_NW", 8);
+        const int nw = (dh_ == 32 && qtiles >= 16 && att_nw == 8) ? 8 : 4;
+        const int wpp = qtiles >= nw ? nw : (qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1));
+        const int ppb = nw / wpp;
         // query tiles per wave: 2 from 8 tiles on, as long as >= 4 blocks per CU remain
         const int qrep = (qtiles >= 8 && (long long)B * heads * (qtiles / 8) >= 1024) ? 2 : 1;
         const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
         const long long blocks = (long long)((B * heads + ppb - 1) / ppb) * qgroups;
         const size_t lds = (size_t)ppb * dh_ * ((size_t)qtiles * 64 + 8);      // vt[dh][keys padded to 32] + 8 bytes of row padding, per pair
         if (lds > 72 * 1024) return "attention_mfma: V^T does not fit LDS";
-        static bool attr_done[kMaxDevices][2] = {};
-        bool& attr = attr_done[current_device()][dh_ == 64];
-        const void* fn = dh_ == 32 ? (const void*)attention_mfma32_kernel<32> : (const void*)attention_mfma32_kernel<64>;
+        static bool attr_done[kMaxDevices][3] = {};
+        bool& attr = attr_done[current_device()][dh_ == 64 ? 1 : (nw == 8 ? 2 : 0)];
+        const void* fn = dh_ == 32 ? (nw == 8 ? (const void*)attention_mfma32_kernel<32, 8> : (const void*)attention_mfma32_kernel<32>) : (const void*)attention_mfma32_kernel<64>;
         if (!attr) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
                 return "attention_mfma: hipFuncSetAttribute failed";
             attr = true;
         }
         const float sl2e = (float)(1.4426950408889634 / sqrt((double)dh_));
-        if (dh_ == 32)
+        if (dh_ == 32 && nw == 8)
+            hipLaunchKernelGGL((attention_mfma32_kernel<32, 8>), dim3((unsigned)blocks), dim3(512), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C, heads, sl2e, qrep);
+        else if (dh_ == 32)
             hipLaunchKernelGGL(attention_mfma32_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C, heads, sl2e, qrep);
         else
             hipLaunchKernelGGL(attention_mfma32_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, N, C, heads, sl2e, qrep);
