@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) attention_mfma32_ker
 // key on the lane) and V^T (vt[d][key], pitch 2 N + 8 as above) of a (sample, head) pair are split ONCE, while they are staged into LDS by the waves that share
 // the pair; Q is split in registers, the probabilities after the exp2.  It replaces the one-query-per-lane vector kernel (attention_kernel<float, 32>: 430 us per
 // launch at 256 tokens and batch 64 = 11 % of a step of this mode).
-__global__ void __launch_bounds__(256) attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int N, int C, int heads,
+__global__ void __launch_bounds__(256, 2) attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int N, int C, int heads,
                                                            float scale_log2e, int qrep) {
     constexpr int D = 32, KP = 80;
     extern __shared__ __attribute__((aligned(16))) char smem[];
