@@ -478,7 +478,7 @@ template <int C, int TM, int CW = 32>
 __global__ void __launch_bounds__(C / CW * 64, CW == 64 ? 2 : 1) wn_layer_bf16_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ y_next, float* __restrict__ skip,
                                                                  const void* __restrict__ w1, const float* __restrict__ b1,
                                                                  const void* __restrict__ w2, const float* __restrict__ b2,
-                                                                 const float* __restrict__ e, int e_bstride, int n, int dil, int first, int Tn) {
+                                                                 const float* __restrict__ e, int e_bstride, int n, int dil, int first, int Tn, int pf_stride) {
     using Tl = WnTile<C, TM>;
     constexpr int PA = Tl::PA, MT = Tl::MT, SPT = Tl::SPT;
     constexpr int NT = C / CW * 64;                        // threads: C / CW waves, each CW gate columns and the CW matching filter columns
@@ -498,7 +498,11 @@ __global__ void __launch_bounds__(C / CW * 64, CW == 64 ? 2 : 1) wn_layer_bf16_w
 #if ADF_WN_XCD
     const unsigned ltile = adf_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int b = (int)(ltile / gridDim.x), t0 = (int)(ltile % gridDim.x) * TM;
+    const unsigned lin_next = blockIdx.y * gridDim.x + blockIdx.x + (unsigned)pf_stride;
+    const unsigned ltile_next = adf_xcd_tile(lin_next, gridDim.x * gridDim.y);
 #else
+    const unsigned lin_next = blockIdx.y * gridDim.x + blockIdx.x + (unsigned)pf_stride;
+    const unsigned ltile_next = lin_next;
     const int b = blockIdx.y, t0 = blockIdx.x * TM;
 #endif
     // Global pieces are addressed as a wave-uniform base + a 32-bit per-lane byte offset derived from a freshly pinned thread id
@@ -673,6 +677,34 @@ __global__ void __launch_bounds__(C / CW * 64, CW == 64 ? 2 : 1) wn_layer_bf16_w
             if (!in) sk[k] = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
+    // ---- L2 prefetch for the workgroup that follows this one on the XCD.  A tile's first 11-15 K cycles (of ~88 K) were the latency of its window loads
+    // (tools/wn_stamps.py: entry -> "staging issued") with nothing else to run: one workgroup fills the CU.  Workgroups are handed to the XCDs round-robin,
+    // so workgroup lin + pf_stride (pf_stride = resident workgroups of the grid, a multiple of 8) runs on THIS XCD next: one dword of each 128-byte line of
+    // its windows is requested here, an epilogue (~19 K cycles) before it starts -- early enough to have landed in the XCD's L2, late enough not to be evicted
+    // by the ~0.5 MB per tile that flow through it.  The loads are LDS-DMA (no destination registers) into 256 scratch bytes per wave behind the parameters
+    // that nobody reads; the kernel waits for them before it ends (the LDS is the next workgroup's by then).
+    constexpr int LPR = C * 2 / 128;                       // 128-byte lines per row
+    constexpr int NPF = (3 * TM * LPR + NT - 1) / NT;
+    if (pf_stride > 0 && lin_next < gridDim.x * gridDim.y) {
+        const unsigned scratch = (unsigned)(2 * TM * PA + 6 * C * 4) + (unsigned)wave * 256u;
+        const int bn = (int)(ltile_next / gridDim.x), tn0 = (int)(ltile_next % gridDim.x) * TM;
+        const char* const ybn = (const char*)(y + (size_t)bn * Tn * C);
+        const int tq = pin();
+        const bool overlap = 2 * dil <= TM;
+        const int nlines = (overlap ? TM + 2 * dil : 3 * TM) * LPR;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int li = tq + u * NT;
+            const int row = li / LPR;
+            const int t = overlap ? tn0 - dil + row : tn0 + (row % TM) + (row / TM - 1) * dil;
+            if (li < nlines && t >= 0 && t < Tn) {
+                const char* const ptr = ybn + (size_t)t * (C * 2) + (li % LPR) * 128;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(ptr), "s"(scratch) : "memory");
+            }
+        }
+    }
     __syncthreads();                                       // every wave has left GEMM 2: X and G become the exchange tile
     auto put = [&](int part, int boff) __attribute__((always_inline)) {       // part 0: residual tiles, 1: skip tiles
 #pragma unroll
@@ -726,11 +758,22 @@ __global__ void __launch_bounds__(C / CW * 64, CW == 64 ? 2 : 1) wn_layer_bf16_w
         }
     }
     WN_STAMP(9);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the prefetch DMAs have landed: the LDS may be handed on
 }
 
 
 const char* launch_wn_layer(const WnIO& io, const WnLayerArgs& a, hipStream_t s) {
     if (io.bf16) {
+        // next-tile L2 prefetch of the 128-position kernels (ADF_WN_PREFETCH=1; off by default): the stride to the workgroup that follows on the same XCD = the
+        // workgroups resident at once = one per CU (two for the paired 64-position form).  Measured (tools/calls/r04_call22.sh, profiles/r04_wavenet_layer_stamps.txt):
+        // it does what it is for -- a tile's window-load latency drops from 11-15 K to 4-5 K cycles, the tile from 88.2 K to 80.3 K cycles at dilation 1 -- and the
+        // launch takes the same 3.56-3.60 ms: the clock the chip holds falls from 2.13 to 1.92 GHz (0.47 -> 0.52 ns per cycle).  The layer kernel runs against the
+        // power-management loop, not against its own stalls, exactly as the resblock conv kernel: removed wait cycles come back as frequency.
+        static const int wn_pf = adf_route_switch("ADF_WN_PREFETCH", 0);
+        static int num_cu_dev[kMaxDevices] = {};
+        int& ncu = num_cu_dev[current_device()];
+        if (ncu == 0 && (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || ncu < 8)) ncu = 256;
+        int pf_stride = wn_pf ? ncu / 8 * 8 : 0;
         constexpr int C = 256, TM = 64, TMW = 128;
         if (io.C == 128 || io.C == 64) {                   // other widths: the 128-position kernel with C / 32 waves
             static bool attr_n[kMaxDevices] = {};
@@ -742,13 +785,13 @@ const char* launch_wn_layer(const WnIO& io, const WnLayerArgs& a, hipStream_t s)
                 an = true;
             }
             const dim3 grid(ceil_div(io.T, TMW), io.B);
-            constexpr size_t lds128 = (size_t)2 * TMW * (128 * 2 + 16) + 6 * 128 * 4, lds64 = (size_t)2 * TMW * (64 * 2 + 16) + 6 * 64 * 4;
+            constexpr size_t lds128 = (size_t)2 * TMW * (128 * 2 + 16) + 6 * 128 * 4 + 2048, lds64 = (size_t)2 * TMW * (64 * 2 + 16) + 6 * 64 * 4 + 2048;
             if (io.C == 128)
                 hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<128, TMW>), grid, dim3(256), lds128, s, (const bf16_t*)a.y,
-                                   (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+                                   (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T, pf_stride);
             else
                 hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<64, TMW>), grid, dim3(128), lds64, s, (const bf16_t*)a.y,
-                                   (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+                                   (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T, pf_stride);
             return WN_LAUNCH_CHECK("wn_layer_bf16_wide");
         }
         if (io.C != C) return "WaveNet bf16 mode: the MFMA layer kernels are built for residual_channels = 64, 128 or 256 (use fp32 for other widths)";
@@ -773,15 +816,15 @@ const char* launch_wn_layer(const WnIO& io, const WnLayerArgs& a, hipStream_t s)
                     return "wn_layer: hipFuncSetAttribute failed";
                 a2 = true;
             }
-            const size_t lds2 = (size_t)2 * TM * WnTile<C, TM>::PA + 6 * C * 4;
+            const size_t lds2 = (size_t)2 * TM * WnTile<C, TM>::PA + 6 * C * 4 + 2048;
             hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<C, TM, 64>), dim3(ceil_div(io.T, TM), io.B), dim3(256), lds2, s, (const bf16_t*)a.y,
-                               (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+                               (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T, 2 * pf_stride);
             return WN_LAUNCH_CHECK("wn_layer_bf16_pair");
         }
         if (wide) {
-            const size_t ldsw = (size_t)2 * TMW * WnTile<C, TMW>::PA + 6 * C * 4;
+            const size_t ldsw = (size_t)2 * TMW * WnTile<C, TMW>::PA + 6 * C * 4 + 2048;
             hipLaunchKernelGGL((wn_layer_bf16_wide_kernel<C, TMW>), dim3(ceil_div(io.T, TMW), io.B), dim3(512), ldsw, s, (const bf16_t*)a.y,
-                               (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T);
+                               (bf16_t*)a.y_next, a.skip, a.w1, a.b1, a.w2, a.b2, io.e, io.e_bstride, a.n, a.dilation, a.first, io.T, pf_stride);
             return WN_LAUNCH_CHECK("wn_layer_bf16_wide");
         }
         hipLaunchKernelGGL((wn_layer_bf16_kernel<C, TM>), dim3(ceil_div(io.T, TM), io.B), dim3(512), lds, s, (const bf16_t*)a.y, (bf16_t*)a.y_next,

@@ -155,13 +155,15 @@ def test_bf16_other_widths_every_layer_vs_bf16_storage_oracle(width):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wide", ["0", "1", "2"])
+@pytest.mark.parametrize("wide", ["0", "1", "2", "1+prefetch"])
 def test_bf16_both_layer_kernel_routes_in_a_child_process(wide):
     """The layer kernel has three routes (128-position tiles, default; 64-position tiles, ADF_WN_WIDE=0; 64-position tiles on four waves, two
     workgroups per CU, ADF_WN_WIDE=2); the switch is read once
     per process, so each runs in its own child: per-layer teacher-forced deviation, the fp32 path, the free-running bf16 net."""
     import json, subprocess, sys
-    env = dict(os.environ, ADF_WN_WIDE=wide)
+    prefetch = wide.endswith("+prefetch")        # the next-tile L2 prefetch of the 128-position kernel (ADF_WN_PREFETCH=1; off by default: no wall-clock gain)
+    wide = wide.split("+")[0]
+    env = dict(os.environ, ADF_WN_WIDE=wide, ADF_WN_PREFETCH="1" if prefetch else "0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "gpu_wn_report.py"), "1500", "2"], capture_output=True, text=True,
                        env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
