@@ -60,7 +60,9 @@ cp gpurun_out/wn_parity_report_wide1.json $out/${tag}_wavenet_bf16_parity_wide.j
 if [ -f audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so ]; then
   { for l in 0 5 11 35; do ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so timeout -k 10 200 python tools/wn_stamps.py $l 128 2>&1 | grep -v amdgpu.ids; done
     echo "# --- 64-position route (ADF_WN_WIDE=0)"
-    ADF_WN_WIDE=0 ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so timeout -k 10 200 python tools/wn_stamps.py 5 128 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_wavenet_layer_stamps.txt
+    ADF_WN_WIDE=0 ADF_HIP_LIB=audiodiffuser_amd/build/variants/libadf_hip_wnstamp.so timeout -k 10 200 python tools/wn_stamps.py 5 128 2>&1 | grep -v amdgpu.ids; } > /tmp/wn_stamps.txt
+  # (a stale variant build fails to load: round 2's committed file was once overwritten by such a traceback -- keep the output only when every run reported rc 0)
+  if grep -q Traceback /tmp/wn_stamps.txt; then echo "wn_stamps failed (stale variant build?): not kept"; else cp /tmp/wn_stamps.txt $out/${tag}_wavenet_layer_stamps_collection.txt; fi
 fi
 echo "[11] ADM 2-D U-Net (config 4): bench line, kernel trace"
 timeout -k 10 600 python bench.py --config c4 --steps 1 --warmup 1 2>/dev/null | tail -1 > $out/${tag}_bench_c4_adm.json
