@@ -288,3 +288,13 @@ def test_bench_defaults_per_config():
     a = bench.parse(["--config", "c5", "--batch", "32"])
     assert (a.batch, a.length, a.num_steps, a.sampler) == (32, 22050, 6, "heun")
     assert bench.adm_conv_flops(A.config_c4(), 1, 80, 256) > 2.0e11          # ~0.25 TFLOP per 1 x 80 x 256 block and evaluation
+
+
+def test_nearest_upsample_index_map_is_integer_division():
+    """ADVICE r3 (low): ``upsample_nearest_pad_kernel`` (adf_kernels.hip) takes source row ``i // f``; ``nn.Upsample(mode='nearest')`` computes
+    ``floor(i * float(1 / f))``.  The two agree for every factor a UNet1dBase level can have here (2 .. 32) at lengths beyond the longest level."""
+    for f in range(2, 33):
+        n = 8192 if f <= 8 else 1024
+        x = torch.arange(n, dtype=torch.float32)[None, None]
+        y = torch.nn.Upsample(scale_factor=f, mode="nearest")(x)[0, 0].long()
+        assert torch.equal(y, torch.arange(n * f) // f), f
