@@ -387,7 +387,7 @@ typedef __attribute__((ext_vector_type(16))) float att_f32x16_t;
 //     two runs of one launch differed), K rows addressed as a uniform base + a 32-bit lane offset (3 instead of 9), the two halves of a
 //     query's keys exchanged by v_permlane32_swap_b32 instead of ds_bpermute_b32 + its wait.
 typedef __attribute__((ext_vector_type(2))) float att_f32x2_t;
-//   * NW = 8 waves per workgroup sharing one pair's V^T (N >= 512 at head dim 32): 16 waves per CU instead of 8 under the same LDS footprint, four per SIMD
+//   * NW = 8 waves per workgroup sharing one pair's V^T (N >= 256 at head dim 32): 16 waves per CU instead of 8 under the same LDS footprint, four per SIMD
 //     to fill each other's transcendental / MFMA latencies (the loop is bound by its vector instructions: 58 + 16 v_exp_f32 per key tile of 4 MFMAs).
 template <int D, int NW = 4>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) attention_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
@@ -744,10 +744,10 @@ const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N,
     const int dh_ = C / heads;
     if (bf16 && (dh_ == 32 || dh_ == 64) && N >= 1 && N <= (dh_ == 32 ? 1024 : 512)) {        // V^T of a pair in LDS: dh x (N padded to 32) bf16 <= 72 KB
         const int qtiles = (N + 31) / 32;
-        // eight waves per workgroup from 16 query tiles on (head dim 32; ADF_ATT_NW=4 keeps four: A/B)
+        // eight waves per workgroup from 8 query tiles on (head dim 32; ADF_ATT_NW=4 keeps four: A/B)
         static int att_nw = -1;
         if (att_nw < 0) att_nw = adf_route_switch("ADF_ATT_NW", 8);
-        const int nw = (dh_ == 32 && qtiles >= 16 && att_nw == 8) ? 8 : 4;
+        const int nw = (dh_ == 32 && att_nw == 8 && qtiles >= 8) ? 8 : 4;      // (256 tokens: one workgroup per pair, 21.9 -> 19.9 us; 1024: 204 -> 183 us)
         const int wpp = qtiles >= nw ? nw : (qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1));
         const int ppb = nw / wpp;
         // query tiles per wave: 2 from 8 tiles on, as long as >= 4 blocks per CU remain
