@@ -538,6 +538,18 @@ def test_config3_bf16_attention_at_1024_tokens_vs_bf16_oracle():
     assert "down2.attn" in forced and "up3.attn" in forced
 
 
+def test_config3_bf16_attention_at_token_counts_that_do_not_fill_the_workgroups():
+    """The MFMA attention kernel shares one (sample, head) pair's V^T among the 8 / 4 / 2 / 1 waves of a workgroup and hands them query tiles in groups: at
+    L = 5120 the C3 net attends over 320 / 80 / 20 / 5 / 5 tokens -- ten query tiles on eight-wave workgroups (a second group with six idle waves), three on
+    two-wave ones, and key counts that are no multiple of the 32-key tile -- every stored tensor against the bf16-storage oracle, fp32 against the oracle."""
+    x, t = generate_noise(11, 2, 5120) * 0.7, torch.tensor([-0.7, 0.3])
+    forced, chain = _assert_bf16_parity(A.config_c3(), x, t)
+    assert "down2.attn" in forced and "up3.attn" in forced
+    errs, _, _ = tap_errors(A.config_c3(), x, t, "fp32", 0)
+    bad = {k: v for k, v in errs.items() if not v < FP32_TIGHT}
+    assert not bad, bad
+
+
 def test_config3_dpm_sampler_full_length_vs_oracle():
     """BASELINE config 3's sampler on its network: DPMSampler(order 3, multistep, 50 sigmas = 49 NFE) on the C3 net, one
     16384-sample waveform, fp32 mode, against oracle.samplers.dpm_multistep_sampler on the CPU."""
