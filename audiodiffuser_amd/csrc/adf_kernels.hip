@@ -583,15 +583,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) attention_mfma32_ker
 // key on the lane) and V^T (vt[d][key], pitch 2 N + 8 as above) of a (sample, head) pair are split ONCE, while they are staged into LDS by the waves that share
 // the pair; Q is split in registers, the probabilities after the exp2.  It replaces the one-query-per-lane vector kernel (attention_kernel<float, 32>: 430 us per
 // launch at 256 tokens and batch 64 = 11 % of a step of this mode).
-__global__ void __launch_bounds__(256, 2) attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int N, int C, int heads,
+// NW waves per workgroup; KG: the K rows come from global memory tile by tile and are split in registers (257 .. 1024 tokens, where K hi | lo of a pair
+// (160 B per key) no longer fits beside V^T hi | lo (128 B per key): eight waves then share the 132 KB of one pair's V^T and walk all of its query tiles).
+template <int NW, bool KG>
+__global__ void __launch_bounds__(NW * 64, 2) attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int N, int C, int heads,
                                                            float scale_log2e, int qrep) {
     constexpr int D = 32, KP = 80;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qtiles = (N + 31) >> 5;
-    const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);   // waves that share one (b, head) pair
-    const int ppb = 4 / wpp;                                    // pairs per block
+    const int wpp = qtiles >= NW ? NW : (qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1));   // waves that share one (b, head) pair
+    const int ppb = NW / wpp;                                   // pairs per block
     const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
     const int qg = blockIdx.x % qgroups, pg = blockIdx.x / qgroups;
     const int pair = pg * ppb + wave / wpp;
@@ -602,29 +605,46 @@ __global__ void __launch_bounds__(256, 2) attention_x3_kernel(const float* __res
     const float* base = qkv + (size_t)b * N * rowstride + (size_t)hd * D;
     const int npad = qtiles * 32;
     const int vpitch = npad * 2 + 8;
-    const size_t pair_bytes = (size_t)2 * npad * KP + (size_t)2 * D * vpitch;
+    const size_t kbytes = KG ? 0 : (size_t)npad * KP;
+    const size_t pair_bytes = 2 * kbytes + (size_t)2 * D * vpitch;
     char* kh = smem + (size_t)(wave / wpp) * pair_bytes;
-    char* kl = kh + (size_t)npad * KP;
-    char* vth = kl + (size_t)npad * KP;
+    char* kl = kh + kbytes;
+    char* vth = kl + kbytes;
     char* vtl = vth + (size_t)D * vpitch;
     {
         const int tl = (wave % wpp) * 64 + lane, nthr = wpp * 64;
-        for (int idx = tl; idx < npad * 8; idx += nthr) {
-            const int key = idx >> 3, c = idx & 7;                  // 16-byte chunk c: head dims 4 c .. 4 c + 3
-            const int krow = key < N ? key : N - 1;                 // padded keys: any finite value (their probability is 0)
-            const f32x4_hw_t kv = *(const f32x4_hw_t*)(base + (size_t)krow * rowstride + C + c * 4);
-            const f32x4_hw_t vv = *(const f32x4_hw_t*)(base + (size_t)krow * rowstride + 2 * C + c * 4);
-            const float kf[4] = {kv.x, kv.y, kv.z, kv.w}, vf[4] = {vv.x, vv.y, vv.z, vv.w};
-            u32x2_t hi, lo;
-            split_bf16x4(kf, hi, lo);
-            *(u32x2_t*)(kh + key * KP + c * 8) = hi;
-            *(u32x2_t*)(kl + key * KP + c * 8) = lo;
-            split_bf16x4(vf, hi, lo);
-            const unsigned hw[2] = {hi.x, hi.y}, lw[2] = {lo.x, lo.y};
+        // four pieces per thread requested before the first is split and scattered (see the bf16 kernel: a load per trip serialises the memory round trips)
+        const int total = npad * 8;
+        for (int base_i = tl; base_i < total; base_i += 4 * nthr) {
+            f32x4_hw_t kvv[4], vvv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *(unsigned short*)(vth + (c * 4 + j) * vpitch + key * 2) = (unsigned short)((j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu));
-                *(unsigned short*)(vtl + (c * 4 + j) * vpitch + key * 2) = (unsigned short)((j & 1) ? (lw[j >> 1] >> 16) : (lw[j >> 1] & 0xffffu));
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base_i + u * nthr;
+                const int key = idx >> 3, c = idx & 7;              // 16-byte chunk c: head dims 4 c .. 4 c + 3
+                const int krow = (idx < total && key < N) ? key : N - 1;    // padded keys: any finite value (their probability is 0)
+                if (!KG) kvv[u] = *(const f32x4_hw_t*)(base + (size_t)krow * rowstride + C + c * 4);
+                vvv[u] = *(const f32x4_hw_t*)(base + (size_t)krow * rowstride + 2 * C + c * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base_i + u * nthr;
+                if (idx >= total) continue;
+                const int key = idx >> 3, c = idx & 7;
+                u32x2_t hi, lo;
+                if (!KG) {
+                    const float kf[4] = {kvv[u].x, kvv[u].y, kvv[u].z, kvv[u].w};
+                    split_bf16x4(kf, hi, lo);
+                    *(u32x2_t*)(kh + key * KP + c * 8) = hi;
+                    *(u32x2_t*)(kl + key * KP + c * 8) = lo;
+                }
+                const float vf[4] = {vvv[u].x, vvv[u].y, vvv[u].z, vvv[u].w};
+                split_bf16x4(vf, hi, lo);
+                const unsigned hw[2] = {hi.x, hi.y}, lw[2] = {lo.x, lo.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *(unsigned short*)(vth + (c * 4 + j) * vpitch + key * 2) = (unsigned short)((j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu));
+                    *(unsigned short*)(vtl + (c * 4 + j) * vpitch + key * 2) = (unsigned short)((j & 1) ? (lw[j >> 1] >> 16) : (lw[j >> 1] & 0xffffu));
+                }
             }
         }
     }
@@ -653,17 +673,42 @@ __global__ void __launch_bounds__(256, 2) attention_x3_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = 0.f;
         float m = -INFINITY, l = 0.f;                   // running maximum in the scaled log2 domain (s * c), running sum
+        // KG: this lane's key row of a tile (head dims 16 ks + 8 hh .. + 7, two K steps = 64 bytes) straight from global, one tile ahead of its use
+        f32x4_hw_t kreg[4], knext[4];
+        auto load_k = [&](int kt, f32x4_hw_t (&kq)[4]) __attribute__((always_inline)) {
+            const int key_r = kt * 32 + r;
+            const float* kp = base + (size_t)(key_r < N ? key_r : N - 1) * rowstride + C + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { kq[2 * ks] = *(const f32x4_hw_t*)(kp + ks * 16); kq[2 * ks + 1] = *(const f32x4_hw_t*)(kp + ks * 16 + 4); }
+        };
+        if (KG) load_k(0, kreg);
         for (int kt = 0; kt < qtiles; ++kt) {
+            if (KG) load_k(kt + 1 < qtiles ? kt + 1 : kt, knext);
             att_f32x16_t st;
 #pragma unroll
             for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const att_bf16x8_t fh = *(const att_bf16x8_t*)(kh + (kt * 32 + r) * KP + (ks * 2 + hh) * 16);
-                const att_bf16x8_t fl = *(const att_bf16x8_t*)(kl + (kt * 32 + r) * KP + (ks * 2 + hh) * 16);
+                att_bf16x8_t fh, fl;
+                if (KG) {
+                    const float f0[4] = {kreg[2 * ks].x, kreg[2 * ks].y, kreg[2 * ks].z, kreg[2 * ks].w};
+                    const float f1[4] = {kreg[2 * ks + 1].x, kreg[2 * ks + 1].y, kreg[2 * ks + 1].z, kreg[2 * ks + 1].w};
+                    u32x2_t h0, l0, h1, l1;
+                    split_bf16x4(f0, h0, l0);
+                    split_bf16x4(f1, h1, l1);
+                    fh = __builtin_bit_cast(att_bf16x8_t, u32x4_t{h0.x, h0.y, h1.x, h1.y});
+                    fl = __builtin_bit_cast(att_bf16x8_t, u32x4_t{l0.x, l0.y, l1.x, l1.y});
+                } else {
+                    fh = *(const att_bf16x8_t*)(kh + (kt * 32 + r) * KP + (ks * 2 + hh) * 16);
+                    fl = *(const att_bf16x8_t*)(kl + (kt * 32 + r) * KP + (ks * 2 + hh) * 16);
+                }
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[ks], st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[ks], st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[ks], st, 0, 0, 0);
+            }
+            if (KG) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kreg[u] = knext[u];
             }
             if (kt == qtiles - 1 && (N & 31)) {               // uniform: the partial key tile
 #pragma unroll
@@ -672,10 +717,21 @@ __global__ void __launch_bounds__(256, 2) attention_x3_kernel(const float* __res
                     st[e] = key < N ? st[e] : -INFINITY;
                 }
             }
-            float mt = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+            // (the vector-instruction trims of attention_mfma32_kernel: maximum over the scaled scores as v_max3, packed fp32, v_permlane32_swap)
+            const att_f32x2_t c2 = {scale_log2e, scale_log2e};
+            float mt;
+            {
+                att_f32x2_t ts[8];
 #pragma unroll
-            for (int e = 4; e < 16; e += 2) mt = fmaxf(mt, fmaxf(st[e], st[e + 1]));
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+                for (int e = 0; e < 8; ++e) ts[e] = att_f32x2_t{st[2 * e], st[2 * e + 1]} * c2;
+                mt = fmaxf(fmaxf(ts[0].x, ts[0].y), ts[1].x);
+#pragma unroll
+                for (int e = 3; e < 15; e += 2) mt = fmaxf(fmaxf(mt, ts[e >> 1][e & 1]), ts[(e + 1) >> 1][(e + 1) & 1]);
+                mt = fmaxf(mt, ts[7].y);
+                const unsigned mu = __float_as_uint(mt);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             if (!__all(mt <= m)) {                            // some query's maximum grew: rescale (else alpha == 1 exactly)
                 const float mn = fmaxf(m, mt);
                 const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -684,11 +740,16 @@ __global__ void __launch_bounds__(256, 2) attention_x3_kernel(const float* __res
                 for (int e = 0; e < 16; ++e) o[e] *= alpha;
                 m = mn;
             }
-            float psum = 0.f;
-            const float negm = -m;
+            const att_f32x2_t negm2 = {-m, -m};
+            att_f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { const float pv = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, negm)); st[e] = pv; psum += pv; }
-            l += psum;
+            for (int e = 0; e < 16; e += 2) {
+                const att_f32x2_t x = att_f32x2_t{st[e], st[e + 1]} * c2 + negm2;
+                const att_f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                st[e] = pv.x; st[e + 1] = pv.y;
+                psum2 += pv;
+            }
+            l += psum2.x + psum2.y;
 #pragma unroll
             for (int sgrp = 0; sgrp < 2; ++sgrp) {
                 float pf[8];
@@ -776,30 +837,34 @@ const char* launch_attention(const void* qkv, void* out, int bf16, int B, int N,
     return bf16 ? attention_dispatch<bf16_t>(qkv, out, B, N, C, heads, s) : attention_dispatch<float>(qkv, out, B, N, C, heads, s);
 }
 
-// split-bf16 mode (fp32 tensors): the MFMA kernel above where it applies (head dim 32, <= 256 tokens), else the fp32 vector kernel
+// split-bf16 mode (fp32 tensors): the MFMA kernel above where it applies (head dim 32, <= 1024 tokens), else the fp32 vector kernel
 const char* launch_attention_x3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
     if (C % heads) return "attention: C % heads != 0";
     static int use = -1;
     if (use < 0) use = adf_route_switch("ADF_ATT_X3", 1);        // 0: the vector kernel (route test)
-    if (!use || C / heads != 32 || N < 1 || N > 256 || C % 4) return launch_attention(qkv, out, 0, B, N, C, heads, s);
+    if (!use || C / heads != 32 || N < 1 || N > 1024 || C % 4) return launch_attention(qkv, out, 0, B, N, C, heads, s);
     const int qtiles = (N + 31) / 32;
-    const int wpp = qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1);
-    const int ppb = 4 / wpp;
+    const bool kg = N > 256;                                      // K from global (split in registers), eight waves per workgroup
+    const int nw = kg ? 8 : 4;
+    const int wpp = qtiles >= nw ? nw : (qtiles >= 4 ? 4 : (qtiles >= 2 ? 2 : 1));
+    const int ppb = nw / wpp;
     const int qrep = qtiles > wpp ? (qtiles + wpp - 1) / wpp : 1;          // every pair is staged once: its waves walk all of its query tiles
     const int qgroups = (qtiles + wpp * qrep - 1) / (wpp * qrep);
     const long long blocks = (long long)((B * heads + ppb - 1) / ppb) * qgroups;
     const size_t npad = (size_t)qtiles * 32;
-    const size_t lds = (size_t)ppb * (2 * npad * 80 + 2 * 32 * (npad * 2 + 8));
-    if (lds > 80 * 1024 || blocks > 0x7fffffffLL) return launch_attention(qkv, out, 0, B, N, C, heads, s);
-    static bool attr_done[kMaxDevices] = {};
-    bool& attr = attr_done[current_device()];
+    const size_t lds = (size_t)ppb * ((kg ? 0 : 2 * npad * 80) + 2 * 32 * (npad * 2 + 8));
+    if (lds > (kg ? 136 : 80) * 1024 || blocks > 0x7fffffffLL) return launch_attention(qkv, out, 0, B, N, C, heads, s);
+    static bool attr_done[kMaxDevices][2] = {};
+    bool& attr = attr_done[current_device()][kg];
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)attention_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-            return "attention_x3: hipFuncSetAttribute failed";
+        const hipError_t e = kg ? hipFuncSetAttribute((const void*)attention_x3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)
+                                : hipFuncSetAttribute((const void*)attention_x3_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return "attention_x3: hipFuncSetAttribute failed";
         attr = true;
     }
     const float sl2e = (float)(1.4426950408889634 / sqrt(32.0));
-    hipLaunchKernelGGL(attention_x3_kernel, dim3((unsigned)blocks), dim3(256), lds, s, (const float*)qkv, (float*)out, B, N, C, heads, sl2e, qrep);
+    if (kg) hipLaunchKernelGGL((attention_x3_kernel<8, true>), dim3((unsigned)blocks), dim3(512), lds, s, (const float*)qkv, (float*)out, B, N, C, heads, sl2e, qrep);
+    else hipLaunchKernelGGL((attention_x3_kernel<4, false>), dim3((unsigned)blocks), dim3(256), lds, s, (const float*)qkv, (float*)out, B, N, C, heads, sl2e, qrep);
     return ADF_LAUNCH_CHECK("attention_x3");
 }
 

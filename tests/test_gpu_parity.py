@@ -548,6 +548,19 @@ def test_config3_bf16_attention_at_token_counts_that_do_not_fill_the_workgroups(
     errs, _, _ = tap_errors(A.config_c3(), x, t, "fp32", 0)
     bad = {k: v for k, v in errs.items() if not v < FP32_TIGHT}
     assert not bad, bad
+    errs, _, _ = tap_errors(A.config_c3(), x, t, "f32x3", 0)      # 320 tokens: the split-bf16 attention kernel's K-from-global form on eight waves
+    bad = {k: v for k, v in errs.items() if not v < F32X3_TOL}
+    assert not bad, bad
+
+
+def test_config3_f32x3_attention_at_1024_tokens_vs_oracle():
+    """BASELINE config 3 in the split-bf16 mode at full length: ``attention_x3_kernel<8, true>`` (K rows from global memory split in registers, one pair's
+    V^T hi | lo = 132 KB of LDS shared by eight waves) at N = 1024 tokens, every recorded tensor against the fp32 oracle."""
+    errs, _, _ = tap_errors(A.config_c3(), generate_noise(3, 1, 16384) * 0.6, torch.tensor([0.2]), "f32x3", 0)
+    assert "down2.attn" in errs and "up3.attn" in errs
+    bad = {k: v for k, v in errs.items() if not v < F32X3_TOL}
+    assert not bad, bad
+    assert max(errs.values()) > 1e-7
 
 
 def test_config3_dpm_sampler_full_length_vs_oracle():
