@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) attention_mfma32_ker
     }
 }
 
-// Self-attention of the split-bf16 mode (ADF_DTYPE_F32X3: fp32 q | k | v rows in, fp32 out), head dim 32, N <= 256 keys.  Same plan as the bf16 kernel above
+// Self-attention of the split-bf16 mode (ADF_DTYPE_F32X3: fp32 q | k | v rows in, fp32 out), head dim 32, N <= 1024 keys (K from LDS up to 256, from global beyond: template parameter KG).  Same plan as the bf16 kernel above
 // -- S^T = K Q^T on the matrix cores with the query on the lane (lane-local softmax), P^T reused as the B operand of O^T += V^T P^T -- with every operand as
 // bf16 hi + lo and three MFMAs per product (lo hi, hi lo, hi hi; adf_common.h).  K (rows of 64 B hi / 64 B lo, pitch 80: conflict-free ds_read_b128 with the
 // key on the lane) and V^T (vt[d][key], pitch 2 N + 8 as above) of a (sample, head) pair are split ONCE, while they are staged into LDS by the waves that share
