@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(512) conv_gemm_rbx3_kernel(const Rbx3Args a) {
         int taps;
     };
     // Every block goes through the same prologue code: y = act ? silu(a x + b) : a x + b with (a, b) from the GroupNorm table,
-    // or (scale, 0) for a raw block (a raw block with scale 1 comes back bit for bit: bf16 * 1.0 + 0 rounds to itself).  One code
+    // or (scale, 0) for a raw block (a raw block with scale 1 is split from x * 1.0 + 0 = x exactly).  One code
     // path = one register assignment for the accumulators over the whole loop (an if / else around two copies of a sub-step
     // made the register allocator move accumulator tiles through scratch).
     int d_t = 0, d_k = 0;                              // (tile, block) cursor of the descriptor stream
