@@ -140,20 +140,30 @@ const char* launch_pp(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm_pp: launch failed";
 }
 
-// Resblock conv kernel (adf_gemm_rb.h): fills the K-block table of one tile and launches one 512-thread block per CU.
-// Returns false (and launches nothing) when the shape is not one the kernel is written for.
-bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hipStream_t stream, const char** err, bool dry = false) {
-    *err = nullptr;
+// What the two forms of the resblock conv kernel (adf_gemm_rb.h: bf16 rows, 64-channel K blocks; adf_gemm_rbx3.h: fp32 rows, 32-channel K blocks) share on the
+// host: the shape checks, the K-block table of one tile and the argument head -- everything but the tile shape.  false: not a shape the kernel is written for.
+struct RbForm {
+    int esz;            // bytes per stored element
+    int blk_ch;         // channels of a K block (a 128-byte row)
+    int max_blk;        // blocks of the argument table
+    bool even_pairs;    // bf16 form: an even number of 64-channel blocks per tile (the ring parity of the first block of a tile is a compile-time constant)
+};
+template <typename ArgsT>
+static bool rb_build_args(const GemmArgs& a, const RbForm& f, ArgsT& r, bool& raw0) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const GemmSeg& g0 = a.seg[0];
     if (a.scatter_f || a.gelu || a.flat || a.mrows % 128 || a.lin != a.mrows || a.out_rows != a.mrows) return false;
     if (a.n != a.n_pad || a.out_c != a.n || (a.n != 128 && a.n != 256) || a.bias_mod != a.n) return false;
     if (!pow2(a.mrows / 128)) return false;
-    // segment 0: GroupNorm + SiLU with the table derived in the kernel, or raw (the folded down convs)
-    const bool raw0 = !g0.gn.gamma && !g0.ab && !g0.act && g0.c1 == 0;
+    // segment 0: GroupNorm + SiLU with the table derived in the kernel, or raw (the folded down convs, the 3-tap form of a transposed conv)
+    raw0 = !g0.gn.gamma && !g0.ab && !g0.act && g0.c1 == 0;
     if (!raw0 && (!g0.gn.gamma || !g0.act)) return false;
     if (g0.taps != 3 || g0.off0 != -1 || g0.stride != 1 || g0.step != 1) return false;
-    if (g0.c0 % 64 || g0.c1 % 64 || ((g0.c0 + g0.c1) / 64) % 2 || (g0.c0 + g0.c1) / 64 > kRbMaxBlk) return false;
+    auto seg_ok = [&](int c0, int c1, int nb_before) {
+        if (c0 % 64 || c1 % 64 || nb_before + (c0 + c1) / f.blk_ch > f.max_blk) return false;
+        return !(f.even_pairs && ((c0 + c1) / 64) % 2);
+    };
+    if (!seg_ok(g0.c0, g0.c1, 0)) return false;
     if (!raw0 && g0.c0 + g0.c1 > kPpMaxCin) return false;
     if (!raw0) {
         // the kernel's table fill sums one or two stored (fine) statistics groups per GroupNorm group: one source, or two equal ones
@@ -169,16 +179,15 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     }
     if (raw0 && (a.nseg > 1 || a.res)) return false;
     if (a.res && a.nseg > 1) return false;
-    RbArgs r;
     memset(&r, 0, sizeof(r));
     int nb = 0;
     auto add_seg = [&](const void* s0, const void* s1, int c0, int c1, const void* w, int taps, bool table, float scale1) {
-        for (int c = 0; c < c0 + c1; c += 64, ++nb) {
+        for (int c = 0; c < c0 + c1; c += f.blk_ch, ++nb) {
             const bool from1 = c >= c0;
             RbBlk& e = r.blk[nb];
-            e.src = (const char*)(from1 ? s1 : s0) + (size_t)(from1 ? c - c0 : c) * 2;
-            e.pitch = (unsigned)(from1 ? c1 : c0) * 2u;
-            e.w = (const char*)w + (size_t)(c / 64) * taps * a.n_pad * kRowBytes;
+            e.src = (const char*)(from1 ? s1 : s0) + (size_t)(from1 ? c - c0 : c) * f.esz;
+            e.pitch = (unsigned)(from1 ? c1 : c0) * (unsigned)f.esz;
+            e.w = (const char*)w + (size_t)(c / f.blk_ch) * taps * a.n_pad * kRowBytes;
             e.tab = table ? c * 8 : -1;
             e.scale = from1 ? scale1 : 1.0f;
         }
@@ -188,13 +197,43 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     if (a.nseg > 1) {
         const GemmSeg& g1 = a.seg[1];
         if (g1.taps != 1 || g1.off0 != 0 || g1.stride != 1 || g1.step != 1 || g1.ab || g1.gn.gamma || g1.act) return false;
-        if (g1.c0 % 64 || g1.c1 % 64 || ((g1.c0 + g1.c1) / 64) % 2 || nb + (g1.c0 + g1.c1) / 64 > kRbMaxBlk) return false;
+        if (!seg_ok(g1.c0, g1.c1, nb)) return false;
         add_seg(g1.src0, g1.src1, g1.c0, g1.c1, g1.w, 1, false, g1.scale1);
     }
     r.h.res = a.nseg == 1 ? a.res : nullptr;                             // identity residual: added in the epilogue (fp32, before the rounding)
-    (void)ident;
     r.h.nb1 = nb - r.h.nb3;
     r.h.B = a.B; r.h.L = a.mrows;
+    r.h.n = a.n;
+    r.h.gn = g0.gn;
+    r.h.bias0 = a.bias0; r.h.bias1 = a.bias1;
+    r.h.out = a.out;
+    r.h.stats = nullptr; r.h.stats_groups = 0;
+    if (a.phase_c && (!raw0 || (a.phase_c & (a.phase_c - 1)) || a.phase_c < 64 || a.n % a.phase_c)) return false;
+    if (a.stats) {
+        const int sc = a.phase_c ? a.phase_c : a.out_c;                      // channels the statistics are over
+        const int gs = a.stats_groups > 0 ? sc / a.stats_groups : 0;
+        if (!(gs > 0 && gs * a.stats_groups == sc && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
+        r.h.stats = a.stats; r.h.stats_groups = a.stats_groups;
+        r.h.stats_mod = a.phase_c;
+    }
+    return true;
+}
+static int rb_num_cus() {
+    static int num_cu_dev[kMaxDevices] = {};
+    int& n = num_cu_dev[current_device()];
+    if (n == 0 && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || n < 1)) n = 256;
+    return n;
+}
+
+// Resblock conv kernel (adf_gemm_rb.h): fills the K-block table of one tile and launches one 512-thread block per CU.
+// Returns false (and launches nothing) when the shape is not one the kernel is written for.
+bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hipStream_t stream, const char** err, bool dry = false) {
+    *err = nullptr;
+    (void)ident;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    RbArgs r;
+    bool raw0 = false;
+    if (!rb_build_args(a, RbForm{2, 64, kRbMaxBlk, true}, r, raw0)) return false;
     // Tile shape.  n = 256: one 256 x 256 tile per 256 rows (the activations are fetched and activated once) when that still gives
     // every CU a tile, else two 256 x 128 tiles; when even those leave CUs idle (L = 256 at batch 64), 128-row tiles.
     // ADF_RB_M128_NH=2 (A/B): 128 x 256 tiles there -- half as many thread blocks, each activation prepared once.
@@ -219,22 +258,8 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
     r.h.tm_shift = 0;
     while ((1 << r.h.tm_shift) < a.mrows / tm) ++r.h.tm_shift;
     r.h.tiles_total = (int)tiles_total;
-    r.h.n = a.n;
-    r.h.gn = g0.gn;
-    r.h.bias0 = a.bias0; r.h.bias1 = a.bias1;
-    r.h.out = a.out;
-    r.h.stats = nullptr; r.h.stats_groups = 0;
-    if (a.phase_c && (!raw0 || (a.phase_c & (a.phase_c - 1)) || a.phase_c < 64 || a.n % a.phase_c)) return false;
-    if (a.stats) {
-        const int sc = a.phase_c ? a.phase_c : a.out_c;                      // channels the statistics are over
-        const int gs = a.stats_groups > 0 ? sc / a.stats_groups : 0;
-        if (!(gs > 0 && gs * a.stats_groups == sc && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
-        r.h.stats = a.stats; r.h.stats_groups = a.stats_groups;
-        r.h.stats_mod = a.phase_c;
-    }
     if (dry) return true;
     static bool attr_done[kMaxDevices] = {};
-    static int num_cu_dev[kMaxDevices] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
         bool ok = true;
@@ -246,10 +271,10 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
             *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize, rb) failed";
             return true;
         }
-        if (hipDeviceGetAttribute(&num_cu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu_dev[dev] < 1) num_cu_dev[dev] = 256;
         attr_done[dev] = true;
     }
-    const long long grid = tiles_total < num_cu_dev[dev] ? tiles_total : num_cu_dev[dev];
+    const int ncu = rb_num_cus();
+    const long long grid = tiles_total < ncu ? tiles_total : ncu;
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kRbLds, stream, r); };
     if (tm == 256) {
         if (nh == 2 && raw0) go(conv_gemm_rb_kernel<2, true, 2>);
@@ -271,53 +296,9 @@ bool try_launch_rb(const GemmArgs& a, const void* ident, long long min_tiles, hi
 bool try_launch_rbx3(const GemmArgs& a, long long min_tiles, hipStream_t stream, const char** err, bool dry = false) {
     *err = nullptr;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    const GemmSeg& g0 = a.seg[0];
-    if (a.scatter_f || a.gelu || a.flat || a.mrows % 128 || a.lin != a.mrows || a.out_rows != a.mrows) return false;
-    if (a.n != a.n_pad || a.out_c != a.n || (a.n != 128 && a.n != 256) || a.bias_mod != a.n) return false;
-    if (!pow2(a.mrows / 128)) return false;
-    const bool raw0 = !g0.gn.gamma && !g0.ab && !g0.act && g0.c1 == 0;
-    if (!raw0 && (!g0.gn.gamma || !g0.act)) return false;
-    if (g0.taps != 3 || g0.off0 != -1 || g0.stride != 1 || g0.step != 1) return false;
-    if (g0.c0 % 64 || g0.c1 % 64 || (g0.c0 + g0.c1) / 32 > kRbx3MaxBlk) return false;      // an even number of 32-channel blocks per source
-    if (!raw0 && g0.c0 + g0.c1 > kPpMaxCin) return false;
-    if (!raw0) {
-        const GnFinalizeArgs& gn = g0.gn;
-        if (gn.G < 1 || (gn.c0 + gn.c1) % gn.G || gn.c0 % gn.G || gn.c1 % gn.G) return false;
-        const int gs = (gn.c0 + gn.c1) / gn.G;
-        if (gn.c0 % gs) return false;
-        for (int cs : {gn.c0, gn.c1}) {
-            if (cs == 0) continue;
-            const int fg = cs / gn.G;
-            if (gs != fg && gs != 2 * fg) return false;
-        }
-    }
-    if (raw0 && (a.nseg > 1 || a.res)) return false;
-    if (a.res && a.nseg > 1) return false;
     Rbx3Args r;
-    memset(&r, 0, sizeof(r));
-    int nb = 0;
-    auto add_seg = [&](const void* s0, const void* s1, int c0, int c1, const void* w, int taps, bool table, float scale1) {
-        for (int c = 0; c < c0 + c1; c += 32, ++nb) {
-            const bool from1 = c >= c0;
-            RbBlk& e = r.blk[nb];
-            e.src = (const char*)(from1 ? s1 : s0) + (size_t)(from1 ? c - c0 : c) * 4;
-            e.pitch = (unsigned)(from1 ? c1 : c0) * 4u;
-            e.w = (const char*)w + (size_t)(c / 32) * taps * a.n_pad * kRowBytes;
-            e.tab = table ? c * 8 : -1;
-            e.scale = from1 ? scale1 : 1.0f;
-        }
-    };
-    add_seg(g0.src0, g0.src1, g0.c0, g0.c1, g0.w, 3, !raw0, 1.0f);
-    r.h.nb3 = nb;
-    if (a.nseg > 1) {
-        const GemmSeg& g1 = a.seg[1];
-        if (g1.taps != 1 || g1.off0 != 0 || g1.stride != 1 || g1.step != 1 || g1.ab || g1.gn.gamma || g1.act) return false;
-        if (g1.c0 % 64 || g1.c1 % 64 || nb + (g1.c0 + g1.c1) / 32 > kRbx3MaxBlk) return false;
-        add_seg(g1.src0, g1.src1, g1.c0, g1.c1, g1.w, 1, false, g1.scale1);
-    }
-    r.h.res = a.nseg == 1 ? a.res : nullptr;
-    r.h.nb1 = nb - r.h.nb3;
-    r.h.B = a.B; r.h.L = a.mrows;
+    bool raw0 = false;
+    if (!rb_build_args(a, RbForm{4, 32, kRbx3MaxBlk, false}, r, raw0)) return false;
     auto tiles_at = [&](int tm_) -> long long {
         if (a.mrows % tm_ || !pow2(a.mrows / tm_)) return 0;
         return (long long)a.B * (a.mrows / tm_) * (a.n / kPpTN);
@@ -330,22 +311,8 @@ bool try_launch_rbx3(const GemmArgs& a, long long min_tiles, hipStream_t stream,
     r.h.tm_shift = 0;
     while ((1 << r.h.tm_shift) < a.mrows / tm) ++r.h.tm_shift;
     r.h.tiles_total = (int)tiles_total;
-    r.h.n = a.n;
-    r.h.gn = g0.gn;
-    r.h.bias0 = a.bias0; r.h.bias1 = a.bias1;
-    r.h.out = a.out;
-    r.h.stats = nullptr; r.h.stats_groups = 0;
-    if (a.phase_c && (!raw0 || (a.phase_c & (a.phase_c - 1)) || a.phase_c < 64 || a.n % a.phase_c)) return false;
-    if (a.stats) {
-        const int sc = a.phase_c ? a.phase_c : a.out_c;
-        const int gs = a.stats_groups > 0 ? sc / a.stats_groups : 0;
-        if (!(gs > 0 && gs * a.stats_groups == sc && (gs & (gs - 1)) == 0 && gs >= 8 && gs <= 64)) return false;
-        r.h.stats = a.stats; r.h.stats_groups = a.stats_groups;
-        r.h.stats_mod = a.phase_c;
-    }
     if (dry) return true;
     static bool attr_done[kMaxDevices] = {};
-    static int num_cu_dev[kMaxDevices] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
         bool ok = true;
@@ -355,10 +322,10 @@ bool try_launch_rbx3(const GemmArgs& a, long long min_tiles, hipStream_t stream,
             *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize, rbx3) failed";
             return true;
         }
-        if (hipDeviceGetAttribute(&num_cu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu_dev[dev] < 1) num_cu_dev[dev] = 256;
         attr_done[dev] = true;
     }
-    const long long grid = tiles_total < num_cu_dev[dev] ? tiles_total : num_cu_dev[dev];
+    const int ncu = rb_num_cus();
+    const long long grid = tiles_total < ncu ? tiles_total : ncu;
     if (tm == 256) hipLaunchKernelGGL(conv_gemm_rbx3_kernel<2>, dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
     else hipLaunchKernelGGL(conv_gemm_rbx3_kernel<1>, dim3((unsigned)grid), dim3(512), kRbLds, stream, r);
     if (hipGetLastError() != hipSuccess) *err = "conv_gemm_rbx3: launch failed";
